@@ -1,0 +1,223 @@
+/*
+ * magicdec_hip.h -- C ABI of libmagicdec_hip.so (MI355X / gfx950).
+ *
+ * This is the drop-in boundary for MagicDec's speculative draft/verify decode
+ * path.  In the reference every device kernel on that path sits behind seven
+ * `torch.library` operators ("mylib::*") whose bodies call flashinfer, plus a
+ * handful of ATen ops (RMSNorm, SiLU*mul, argmax, SnapKV select, StreamingLLM
+ * evict, the accept/rollback loop).  Each entry point below names the
+ * reference interface it replaces (file:line under the reference checkout).
+ *
+ * Conventions
+ *   - plain C, no C++/torch types; every pointer is a DEVICE pointer unless
+ *     the parameter name ends in `_host`;
+ *   - bf16 tensors are passed as `const void*` / `void*` (2-byte elements);
+ *   - every call is asynchronous on `stream` (a hipStream_t passed as void*);
+ *     nothing synchronises, allocates or frees device memory;
+ *   - return value: MD_OK (0) or a negative MD_ERR_* code; the message for
+ *     the calling thread's last error is md_last_error_string();
+ *   - page tables use the reference's (flashinfer 0.1.x) triple
+ *     (indices, indptr, last_page_len), int32 on device, NHD page layout
+ *     cache[page][2][page_size][KH][D] (Engine/SnapKV/model.py:84).
+ *   - sequence length of request b:
+ *        len_b = (indptr[b+1]-indptr[b]-1)*page_size + last_page_len[b]
+ *   - safe to capture into a hipGraph: no host reads of device memory, all
+ *     lengths are read on the device at execution time.
+ */
+#ifndef MAGICDEC_HIP_H
+#define MAGICDEC_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MD_OK 0
+#define MD_ERR_INVALID_ARG (-1)
+#define MD_ERR_UNSUPPORTED (-2)
+#define MD_ERR_LAUNCH (-3)
+#define MD_ERR_WORKSPACE (-4)
+
+typedef void* md_stream_t; /* hipStream_t */
+
+/* ABI version (bumped on any signature change). */
+int md_abi_version(void);
+/* Message of the calling thread's most recent error ("" if none). Host. */
+const char* md_last_error_string(void);
+
+/* ------------------------------------------------------------------------
+ * K4  mylib::update_kv  ->  flashinfer.append_paged_kv_cache
+ *     reference: Engine/utils.py:31-54, callers Engine/SnapKV/model.py:90-112
+ * Row j of request b (n_b = append_indptr[b+1]-append_indptr[b] rows) is
+ * written to position len_b - n_b + j of the request (the page table must
+ * already include the appended rows).  k/v: [nnz, KH, D] with a row stride in
+ * elements (a slice of the fused wqkv output can be passed without a copy).
+ * n_max >= max_b n_b (host upper bound, sizes the grid).
+ * ---------------------------------------------------------------------- */
+int md_append_paged_kv(const void* k, const void* v, int64_t k_row_stride, int64_t v_row_stride,
+                       const int32_t* append_indptr, void* cache, const int32_t* page_indices,
+                       const int32_t* page_indptr, const int32_t* last_page_len, int B, int n_max,
+                       int KH, int D, int page_size, md_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * K5  mylib::rope / mylib::draft_rope -> flashinfer.rope.apply_rope /
+ *     apply_llama31_rope (interleave=True)
+ *     reference: Engine/SnapKV/model.py:133-156
+ * Token j of request b has position offsets[b]+j; the pair (x[2i],x[2i+1]) is
+ * rotated by angle pos*freq[i].  `cos_sin` is a host-precomputed device table
+ * float32 [max_pos][D/2][2] (cos, sin) -- see md_rope_fill_table_host for the
+ * frequency definition.  Out-of-table positions are an error flagged in
+ * *err_flag (device int32, may be NULL).  q_out/k_out are contiguous
+ * [nnz,H,D] / [nnz,KH,D]; q/k carry a row stride in elements.  k/k_out may
+ * be NULL (rotate q only).
+ * ---------------------------------------------------------------------- */
+int md_rope(const void* q, const void* k, int64_t q_row_stride, int64_t k_row_stride, void* q_out,
+            void* k_out, const int32_t* indptr, const int32_t* offsets, int B, int n_max, int H,
+            int KH, int D, const float* cos_sin, int max_pos, md_stream_t stream);
+
+/* Host helper: fills table[max_pos][D/2][2] with cos/sin of pos*freq[i],
+ * freq[i] = theta^(-2i/D); plain rope: freq/rope_scale; Llama-3.1 smoothing
+ * when low_freq_factor>0 (Engine/SnapKV/model.py:140: rope_scale,
+ * low/high_freq_factor, old_context_len).  Angles and trig in float64,
+ * rounded once to float32. */
+int md_rope_fill_table_host(float* table_host, int max_pos, int D, double theta, double rope_scale,
+                            double low_freq_factor, double high_freq_factor, double old_context_len);
+
+/* Fused K5+K4 for the decode/verify/prefill step (our Engine's fast path;
+ * same results as md_rope followed by md_append_paged_kv on the rotated k):
+ * reads q,k,v rows of the fused wqkv output, writes rotated q to q_out
+ * (contiguous) and rotated k plus v straight into the pages.  When
+ * cache2 != NULL the same rows are also appended to a second cache with its
+ * own page table (self-spec verify writes target and draft caches,
+ * Engine/SnapKV/model.py:347-348). */
+int md_rope_append(const void* q, const void* k, const void* v, int64_t q_row_stride,
+                   int64_t k_row_stride, int64_t v_row_stride, void* q_out,
+                   const int32_t* indptr, const int32_t* offsets, int B, int n_max, int H, int KH,
+                   int D, const float* cos_sin, int max_pos, void* cache,
+                   const int32_t* page_indices, const int32_t* page_indptr,
+                   const int32_t* last_page_len, void* cache2, const int32_t* page_indices2,
+                   const int32_t* page_indptr2, const int32_t* last_page_len2, int page_size,
+                   md_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * K1/K2/K3  mylib::target_decode / target_prefill / draft_decode /
+ *     draft_prefill -> flashinfer BatchPrefillWithPagedKVCacheWrapper.plan+run
+ *     reference: Engine/SnapKV/backend.py:56-107,146-159; backend_draft.py:42-92
+ * q: [nnz, H, D] (row stride in elements), out: [nnz, H, D] contiguous.
+ * Query row i of request b (m_b rows) attends kv positions <= len_b-m_b+i
+ * (causal) or all len_b positions; q head h reads kv head h/(H/KH);
+ * softmax(q.k * sm_scale) in fp32; bf16 in/out.  The kernel variant
+ * (verify / draft / chunked prefill) is chosen from (n_max, H/KH).
+ * max_pages_per_req: host upper bound of pages of any request (sizes the
+ * split-KV decomposition; no host read of the page table is made).
+ * workspace: md_paged_attn_workspace_bytes() bytes of scratch.
+ * ---------------------------------------------------------------------- */
+size_t md_paged_attn_workspace_bytes(int B, int n_max, int H, int KH, int D,
+                                     int max_pages_per_req, int page_size);
+int md_paged_attn(const void* q, int64_t q_row_stride, const void* cache, void* out,
+                  const int32_t* qo_indptr, const int32_t* page_indices,
+                  const int32_t* page_indptr, const int32_t* last_page_len, int B, int n_max,
+                  int H, int KH, int D, int page_size, int causal, float sm_scale,
+                  int max_pages_per_req, void* workspace, size_t workspace_bytes,
+                  md_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * K6  Attention.gen_draft_kv  (SnapKV select)
+ *     reference: Engine/SnapKV/model.py:389-439 (+ caller :381-382)
+ * q_win: rotated queries of the last chunk [B*window, H, D] (contiguous);
+ * cache/page table: the request's full KV (ctx_len tokens each, same for all
+ * requests as in the reference: context_len = offsets[0]+seqlen).
+ * Reproduces the reference's rounding sequence (bf16 scores, fp32 softmax ->
+ * bf16, bf16 partial sums in chunk order, avg_pool1d k=kernel, group sum,
+ * top-(budget-window) in descending-score order) and appends, per request
+ * and kv head, the selected rows followed by the last `window` rows to the
+ * draft cache at positions [draft_len_b - budget, draft_len_b).
+ * idx_out: [B, KH, budget-window] int32 (selected positions, reference order).
+ * ---------------------------------------------------------------------- */
+size_t md_snapkv_workspace_bytes(int B, int H, int KH, int ctx_len, int window);
+int md_snapkv_select(const void* q_win, const void* cache, const int32_t* page_indices,
+                     const int32_t* page_indptr, int B, int H, int KH, int D, int page_size,
+                     int ctx_len, int window, int budget, int pool_kernel, void* draft_cache,
+                     const int32_t* draft_page_indices, const int32_t* draft_page_indptr,
+                     const int32_t* draft_last_page_len, int32_t* idx_out, void* workspace,
+                     size_t workspace_bytes, md_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * K7  KVCache.prefill / prefill_draft  (StreamingLLM sink+window eviction)
+ *     reference: Engine/StreamingLLM/model_draft.py:102-143, model.py:116-157
+ * In-place equivalent of: keep rows [0,sink) and the most recent
+ * (kv_len-sink) of (old rows [sink,kv_len) ++ the n new rows) in the
+ * request's contiguous slot range [0,kv_len).  `cache` holds UN-rotated keys.
+ * rot_cache (same shape) receives, for every request, rows [0,valid_len)
+ * with K rotated to cache-relative position = slot index and V copied
+ * (the reference's per-chunk rotated clone); pass rot_cache == cache on the
+ * last chunk to reproduce `self.kv_cache.copy_(rotated_kv)`.
+ * Requests own pages_per_req consecutive pages starting at b*pages_per_req
+ * (Engine/StreamingLLM/backend_draft.py:160).
+ * ---------------------------------------------------------------------- */
+int md_streaming_shift_append(const void* k_new, const void* v_new, int64_t k_row_stride,
+                              int64_t v_row_stride, void* cache, int B, int n_new, int kv_len,
+                              int sink, int pages_per_req, int KH, int D, int page_size,
+                              void* scratch, size_t scratch_bytes, md_stream_t stream);
+int md_streaming_rotate(const void* cache, void* rot_cache, int B, int valid_len,
+                        int pages_per_req, int KH, int D, int page_size, const float* cos_sin,
+                        int max_pos, md_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * K9  RMSNorm / SiLU*mul / residual   reference: Engine/SnapKV/model.py:451-469
+ * rmsnorm: y = bf16( x_f32 * rsqrt(mean(x^2)+eps) ) * w   (weight multiply in
+ * bf16, model.py:467-469).  add_rmsnorm: h = x + r (bf16 add), then the same
+ * norm of h; writes h_out and y.  silu_mul: y = bf16(silu(a)) * b with the
+ * reference's bf16 rounding points (F.silu in bf16, product in bf16).
+ * ---------------------------------------------------------------------- */
+int md_rmsnorm(const void* x, const void* weight, void* y, int rows, int dim, float eps,
+               md_stream_t stream);
+int md_add_rmsnorm(const void* x, const void* r, const void* weight, void* h_out, void* y,
+                   int rows, int dim, float eps, md_stream_t stream);
+int md_silu_mul(const void* a, const void* b, int64_t a_row_stride, int64_t b_row_stride, void* y,
+                int rows, int dim, md_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * K10  argmax over a vocab shard / TP merge
+ *     reference: Engine/SnapKV/model.py:175-188
+ * argmax: per row, max bf16 logit and its lowest index (+index_offset).
+ * tp_argmax_merge: vals/idx [rows, tp] -> token of the lowest rank among
+ * equal maxima (torch.argmax over [..,tp], model.py:185).
+ * ---------------------------------------------------------------------- */
+int md_argmax(const void* logits, int64_t row_stride, int rows, int vocab, int64_t index_offset,
+              void* max_val_out /* bf16 [rows], may be NULL */, int64_t* idx_out,
+              md_stream_t stream);
+int md_tp_argmax_merge(const void* vals /* bf16 [rows,tp] */, const int64_t* idx /* [rows,tp] */,
+                       int rows, int tp, int64_t* out, md_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * a1  the verify loop body (accept / rollback / scatter / bonus / terminate)
+ *     reference: tests/SnapKV/longspec_benchmark.py:208-281 (= StreamingLLM
+ *     twin :205-278).  One launch, all-integer, no host sync.
+ * Inputs: tokens_buffer [B,gamma+1], target_tokens [B,gamma+1] (int64).
+ * In/out: output [B,out_cols] int64, num_nodes [B] int64, target
+ *   cachelens/last_page_len [B] int32 (already advanced by gamma+1 by the
+ *   verify call), draft cachelens/last_page_len [B] int32 (already advanced
+ *   by gamma; may be NULL), draft_rollback = gamma (longspec) or gamma+1
+ *   (selfspec), draft_cap = max tokens the draft keeps (gamma for longspec:
+ *   min(accept,gamma); gamma+1 for selfspec).
+ * Outputs: accept_nums [B] int64, bonus [B] int64, double_buffer [B,2]
+ *   int64, cachelens_update [B] int64, flags[0]=terminal, flags[1]=any row
+ *   accepted all gamma (next_double).  On terminal the bonus token is also
+ *   written to output[b, num_nodes[b]] and num_nodes += 1 (:283-285); else
+ *   tokens_buffer[:,0] = bonus.
+ * ---------------------------------------------------------------------- */
+int md_accept_rollback(int64_t* tokens_buffer, const int64_t* target_tokens, int64_t* output,
+                       int out_cols, int64_t* num_nodes, int32_t* cachelens,
+                       int32_t* last_page_len, int32_t* draft_cachelens,
+                       int32_t* draft_last_page_len, int B, int gamma, int draft_rollback,
+                       int draft_cap, int64_t eot_1, int64_t eot_2, int64_t max_nodes,
+                       int64_t* accept_nums, int64_t* bonus, int64_t* double_buffer,
+                       int64_t* cachelens_update, int32_t* flags, md_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MAGICDEC_HIP_H */

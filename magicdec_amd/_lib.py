@@ -1,0 +1,81 @@
+"""ctypes binding of libmagicdec_hip.so (the C ABI declared in include/magicdec_hip.h).
+
+There is exactly one backend: the HIP library.  If it is missing or fails to
+load, every op raises -- there is no CPU or PyTorch fallback.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_char_p, c_double, c_float, c_int, c_int64, c_size_t, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmagicdec_hip.so")
+ABI_VERSION = 1
+
+_lib = None
+_err = None
+
+P = c_void_p
+I = c_int
+L = c_int64
+
+_SIGNATURES = {
+    "md_abi_version": (c_int, []),
+    "md_last_error_string": (c_char_p, []),
+    "md_append_paged_kv": (c_int, [P, P, L, L, P, P, P, P, P, I, I, I, I, I, P]),
+    "md_rope": (c_int, [P, P, L, L, P, P, P, P, I, I, I, I, I, P, I, P]),
+    "md_rope_fill_table_host": (c_int, [P, I, I, c_double, c_double, c_double, c_double, c_double]),
+    "md_rope_append": (c_int, [P, P, P, L, L, L, P, P, P, I, I, I, I, I, P, I, P, P, P, P, P, P, P, P, I, P]),
+    "md_paged_attn_workspace_bytes": (c_size_t, [I, I, I, I, I, I, I]),
+    "md_paged_attn": (c_int, [P, L, P, P, P, P, P, P, I, I, I, I, I, I, I, c_float, I, P, c_size_t, P]),
+    "md_snapkv_workspace_bytes": (c_size_t, [I, I, I, I, I]),
+    "md_snapkv_select": (c_int, [P, P, P, P, I, I, I, I, I, I, I, I, I, P, P, P, P, P, P, c_size_t, P]),
+    "md_streaming_shift_append": (c_int, [P, P, L, L, P, I, I, I, I, I, I, I, I, P, c_size_t, P]),
+    "md_streaming_rotate": (c_int, [P, P, I, I, I, I, I, I, P, I, P]),
+    "md_rmsnorm": (c_int, [P, P, P, I, I, c_float, P]),
+    "md_add_rmsnorm": (c_int, [P, P, P, P, P, I, I, c_float, P]),
+    "md_silu_mul": (c_int, [P, P, L, L, P, I, I, P]),
+    "md_argmax": (c_int, [P, L, I, I, L, P, P, P]),
+    "md_tp_argmax_merge": (c_int, [P, P, I, I, P, P]),
+    "md_accept_rollback": (c_int, [P, P, P, I, P, P, P, P, P, I, I, I, I, L, L, L, P, P, P, P, P, P]),
+}
+
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+
+class MagicDecHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the library once; raise MagicDecHipError if that is impossible."""
+    global _lib, _err
+    if _lib is not None:
+        return _lib
+    if _err is not None:
+        raise MagicDecHipError(_err)
+    if not os.path.exists(LIB_PATH):
+        _err = (f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `make -C magicdec_amd/csrc`.  magicdec_amd has no CPU fallback.")
+        raise MagicDecHipError(_err)
+    try:
+        import torch  # noqa: F401  (loads the HIP runtime torch was built with first)
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        if lib.md_abi_version() != ABI_VERSION:
+            raise OSError(f"ABI version {lib.md_abi_version()} != expected {ABI_VERSION}")
+    except (OSError, AttributeError) as e:  # missing symbol / loader failure
+        _err = f"cannot load {LIB_PATH}: {e}"
+        raise MagicDecHipError(_err) from e
+    _lib = lib
+    return _lib
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        msg = load().md_last_error_string()
+        raise MagicDecHipError(f"{what} failed (rc={rc}): {msg.decode() if msg else ''}")

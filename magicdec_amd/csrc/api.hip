@@ -1,0 +1,17 @@
+// Host-side plumbing of libmagicdec_hip.so: error strings, ABI version.
+#include "md_common.h"
+#include <string.h>
+
+namespace {
+thread_local char g_err[512] = "";
+}
+
+void md_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" int md_abi_version(void) { return 1; }
+extern "C" const char* md_last_error_string(void) { return g_err; }

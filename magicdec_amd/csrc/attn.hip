@@ -1,0 +1,546 @@
+// Paged attention for the MagicDec draft/verify decode path on gfx950 (MI355X).
+//
+// Replaces flashinfer's BatchPrefillWithPagedKVCacheWrapper.run as used by
+// mylib::target_decode / draft_decode / target_prefill / draft_prefill
+// (reference: Engine/SnapKV/backend.py:56-107, backend_draft.py:42-92,
+//  StreamingLLM twins).  Semantics restated in oracle/flashinfer_ref.py.
+//
+// Design (decode is HBM-bound: every K/V byte is read exactly once):
+//   * one wavefront owns a stream of 32-key tiles of one (request, kv head):
+//     coalesced 16 B/lane global loads (whole 128/256-B rows) -> registers ->
+//     wave-private LDS image -> MFMA fragments.  Waves never synchronise
+//     inside the tile loop (no s_barrier); the next tile's global loads are
+//     in flight while the current tile is computed.
+//   * S^T = K.Q^T and O^T = V^T.P^T on v_mfma_f32_16x16x32_bf16, so the
+//     softmax statistics of query row (lane&15) are lane-local and P never
+//     moves between lanes: the S^T accumulator registers ARE the B operand of
+//     the PV MFMA (after bf16 packing) with the key permutation
+//     slot(c,t) -> key (t>>2)*16 + c*4 + (t&3).
+//   * K image: row-major, 16-B chunks XOR-swizzled by (row & (CH-1)) ->
+//     conflict-free ds_read_b128 fragment reads.  V image: [d/16][32 keys][16]
+//     sub-tiles read with ds_read_b64_tr_b16 (hardware transpose).
+//   * g*(gamma+1) query rows share every K/V tile (16 rows for Llama-3.1-8B
+//     at gamma=3 = exactly one MFMA M tile).
+//   * verify/draft ("decode" variant): the 4 waves of a workgroup split the KV
+//     range of one (request, kv head, kv-split) and merge (m,l,O) through
+//     LDS; optional split-KV across workgroups + a small merge kernel.
+//   * chunked prefill ("splitq" variant): the 4 waves own different 16/32-row
+//     query tiles and each streams the causal KV range; workgroups sharing a
+//     (request, kv head) are placed on one XCD (block id mod 8) to share L2.
+#include "md_common.h"
+
+namespace {
+
+struct AttnParams {
+    const bf16_t* q;
+    const bf16_t* cache;
+    bf16_t* out;
+    const int32_t* qo_indptr;
+    const int32_t* page_indices;
+    const int32_t* page_indptr;
+    const int32_t* last_page_len;
+    float* ws_o;
+    float* ws_ml;
+    int64_t q_row_stride;  // elements
+    int64_t page_stride;   // elements: 2*page_size*KH*D
+    int64_t kv_half;       // elements: page_size*KH*D
+    int slot_stride;       // elements: KH*D
+    int B, H, KH, g, page_size, causal, nsplit, n_qgroups;
+    float scale_log2;
+};
+
+constexpr int kVSub = 1056;  // bytes per [32 keys][16 d] V sub-tile (+32 B pad: conflict-free ds_write_b128)
+
+template <int D, int QT>
+__host__ __device__ constexpr int attn_wave_lds() {
+    int stage = 32 * D * 2 + (D / 16) * kVSub;
+    int merge = QT * D * 64 + QT * 128;
+    int m = stage > merge ? stage : merge;
+    return (m + 255) / 256 * 256;
+}
+
+__device__ __forceinline__ bf16x8 lds_read_b128(const unsigned char* p) {
+    return *reinterpret_cast<const bf16x8*>(p);
+}
+__device__ __forceinline__ bf16x4 lds_read_tr(const unsigned char* p) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+        (__attribute__((address_space(3))) bf16x4*)(p));
+}
+
+template <int D, int QT, bool SPLITQ>
+__global__ __launch_bounds__(256, 2) void paged_attn_kernel(const AttnParams p) {
+    constexpr int CH = D / 8;     // 16-B chunks per K/V row
+    constexpr int RPI = 64 / CH;  // rows per wave-wide load instruction
+    constexpr int NL = 32 / RPI;  // load instructions per 32-key tile (K or V)
+    constexpr int KS = D / 32;    // MFMA k-steps of QK^T
+    constexpr int NB = D / 16;    // 16-wide d blocks of PV
+    constexpr int KROW = D * 2;
+    constexpr int K_BYTES = 32 * KROW;
+    constexpr int WAVE_LDS = attn_wave_lds<D, QT>();
+    constexpr int TSTEP = SPLITQ ? 1 : 4;
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    const int lq = lane & 15, lc = lane >> 4;
+
+    // block -> ((request, kv head), (q group, kv split)); blocks of one pair
+    // differ by multiples of 8 in block id (same XCD -> shared L2).
+    const int bid = blockIdx.x;
+    const int nsub = p.n_qgroups * p.nsplit;
+    const int xcd = bid & 7;
+    const int r0 = bid >> 3;
+    const int sub = r0 % nsub;
+    const int pair = (r0 / nsub) * 8 + xcd;
+    if (pair >= p.B * p.KH) return;
+    const int qg = sub / p.nsplit, split = sub % p.nsplit;
+    const int b = pair / p.KH, kvh = pair % p.KH;
+    const int g = p.g;
+
+    const int q0 = p.qo_indptr[b];
+    const int n_b = p.qo_indptr[b + 1] - q0;
+    const int pg0 = p.page_indptr[b];
+    const int npages = p.page_indptr[b + 1] - pg0;
+    const int kv_len = npages > 0 ? (npages - 1) * p.page_size + p.last_page_len[b] : 0;
+    const int nrows = n_b * g;
+    const int tile_base = SPLITQ ? (qg * 4 + wave) * QT : qg * QT;
+
+    // per-lane query row (column lq of S^T) and its causal limit
+    int lim[QT];
+    int hi = -1, lo = 0x7fffffff;
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+        const int R = (tile_base + qt) * 16 + lq;
+        const bool valid = R < nrows;
+        const int i = R / g;
+        lim[qt] = valid ? (p.causal ? kv_len - n_b + i : kv_len - 1) : -1;
+        hi = max(hi, lim[qt]);
+        if (valid) lo = min(lo, lim[qt]);
+    }
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) {
+        hi = max(hi, __shfl_xor(hi, o));
+        lo = min(lo, __shfl_xor(lo, o));
+    }
+    hi = __builtin_amdgcn_readfirstlane(hi);
+    lo = __builtin_amdgcn_readfirstlane(lo);
+
+    const int kv_end = min(hi + 1, kv_len);
+    const int ntiles = kv_end > 0 ? (kv_end + 31) >> 5 : 0;
+    const int tps = (ntiles + p.nsplit - 1) / p.nsplit;
+    const int t_begin = split * tps;
+    const int t_end = min(ntiles, t_begin + tps);
+
+    // Q fragments (B operand of S^T = K.Q^T): lane (lq,lc) holds Q[row lq][s*32+lc*8 .. +8]
+    bf16x8 qf[QT][KS];
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+        const int R = (tile_base + qt) * 16 + lq;
+        const bool valid = R < nrows;
+        const int i = R / g, r = R - i * g;
+        const bf16_t* qp = p.q + (int64_t)(q0 + i) * p.q_row_stride + (kvh * g + r) * D + lc * 8;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+            qf[qt][s] = valid ? *reinterpret_cast<const bf16x8*>(qp + s * 32) : z;
+        }
+    }
+
+    f32x4 o[QT][NB];
+    float m[QT], l[QT];
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+        m[qt] = -1e30f;
+        l[qt] = 0.f;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) o[qt][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+
+    unsigned char* ldsK = smem + wave * WAVE_LDS;
+    unsigned char* ldsV = ldsK + K_BYTES;
+
+    // staging (write) side: lane -> (row wrow + j*RPI, 16-B chunk wch)
+    const int wrow = lane / CH, wch = lane % CH;
+    int kw[NL], vw[NL];
+#pragma unroll
+    for (int j = 0; j < NL; ++j) {
+        const int row = wrow + j * RPI;
+        kw[j] = row * KROW + ((wch ^ (row & (CH - 1))) << 4);
+        vw[j] = (wch >> 1) * kVSub + row * 32 + (wch & 1) * 16;
+    }
+    // fragment (read) side
+    int kra[2][KS];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const int row = kb * 16 + lq, ch = s * 4 + lc;
+            kra[kb][s] = row * KROW + ((ch ^ (row & (CH - 1))) << 4);
+        }
+    const int vra = (lc * 4 + (lq >> 2)) * 32 + (lq & 3) * 8;  // + nb*kVSub + kb*512
+    const int goff = wrow * p.slot_stride + kvh * D + wch * 8;  // elements
+
+    u32x4 kreg[NL], vreg[NL];
+    auto issue = [&](int tt) {
+        const int pos0 = tt * 32;
+        const int page = pos0 / p.page_size;
+        const int slot0 = pos0 - page * p.page_size;
+        const int pid = __builtin_amdgcn_readfirstlane(p.page_indices[pg0 + page]);
+        const bf16_t* kb_ = p.cache + (int64_t)pid * p.page_stride + (int64_t)slot0 * p.slot_stride + goff;
+        const bf16_t* vb_ = kb_ + p.kv_half;
+#pragma unroll
+        for (int j = 0; j < NL; ++j)
+            kreg[j] = *reinterpret_cast<const u32x4*>(kb_ + (int64_t)j * RPI * p.slot_stride);
+#pragma unroll
+        for (int j = 0; j < NL; ++j)
+            vreg[j] = *reinterpret_cast<const u32x4*>(vb_ + (int64_t)j * RPI * p.slot_stride);
+    };
+
+    int t = t_begin + (SPLITQ ? 0 : wave);
+    if (t < t_end) issue(t);
+
+    for (; t < t_end; t += TSTEP) {
+        const bool need_mask = (t * 32 + 31) > lo;
+        if (need_mask) {
+            // rows past the request's length may hold anything (even NaN): zero V so 0*V stays 0
+#pragma unroll
+            for (int j = 0; j < NL; ++j)
+                if (t * 32 + wrow + j * RPI >= kv_len) vreg[j] = u32x4{0u, 0u, 0u, 0u};
+        }
+#pragma unroll
+        for (int j = 0; j < NL; ++j) *reinterpret_cast<u32x4*>(ldsK + kw[j]) = kreg[j];
+#pragma unroll
+        for (int j = 0; j < NL; ++j) *reinterpret_cast<u32x4*>(ldsV + vw[j]) = vreg[j];
+        if (t + TSTEP < t_end) issue(t + TSTEP);
+        // same-wave LDS hand-off: LDS ops of one wave execute in order
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+        // ---- S^T = K.Q^T : s[qt][kb][j] = score(key kb*16+lc*4+j, query lq)
+        f32x4 s[QT][2];
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) {
+            s[qt][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+            s[qt][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const bf16x8 kf = lds_read_b128(ldsK + kra[kb][ks]);
+#pragma unroll
+                for (int qt = 0; qt < QT; ++qt)
+                    s[qt][kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qt][ks], s[qt][kb], 0, 0, 0);
+            }
+
+        // ---- online softmax (log2 domain), statistics are per lane (query lq)
+        bf16x8 pf[QT];
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) {
+            float v[8];
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[kb * 4 + j] = s[qt][kb][j] * p.scale_log2;
+            if (need_mask) {
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int pos = t * 32 + kb * 16 + lc * 4 + j;
+                        if (pos > lim[qt]) v[kb * 4 + j] = -INFINITY;
+                    }
+            }
+            float mx = v[0];
+#pragma unroll
+            for (int e = 1; e < 8; ++e) mx = fmaxf(mx, v[e]);
+            mx = fmaxf(mx, __shfl_xor(mx, 16));
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            const float mnew = fmaxf(m[qt], mx);
+            const float alpha = __builtin_amdgcn_exp2f(m[qt] - mnew);
+            m[qt] = mnew;
+            float ps = 0.f;
+            f32x8 pv;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float pe = __builtin_amdgcn_exp2f(v[e] - mnew);
+                pv[e] = pe;
+                ps += pe;
+            }
+            l[qt] = l[qt] * alpha + ps;
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) o[qt][nb] *= alpha;
+            pf[qt] = __builtin_convertvector(pv, bf16x8);
+        }
+
+        // ---- O^T += V^T.P^T : A = V fragment (d x key slots) via transpose read
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            const bf16x4 v0 = lds_read_tr(ldsV + nb * kVSub + vra);
+            const bf16x4 v1 = lds_read_tr(ldsV + nb * kVSub + 512 + vra);
+            const bf16x8 vf = __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+            for (int qt = 0; qt < QT; ++qt)
+                o[qt][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[qt], o[qt][nb], 0, 0, 0);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+
+    // row sums live as per-lane partials over the 4 lane groups of a query
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+        l[qt] += __shfl_xor(l[qt], 16);
+        l[qt] += __shfl_xor(l[qt], 32);
+    }
+
+    if constexpr (SPLITQ) {
+        // each wave owns its query tiles: normalise and store (lane: row lq, d = nb*16+lc*4+{0..3})
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) {
+            const int R = (tile_base + qt) * 16 + lq;
+            if (R < nrows) {
+                const int i = R / g, r = R - i * g;
+                const float inv = l[qt] > 0.f ? 1.f / l[qt] : 0.f;
+                bf16_t* op = p.out + ((int64_t)(q0 + i) * p.H + kvh * g + r) * D + lc * 4;
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) {
+                    const f32x4 ov = o[qt][nb] * inv;
+                    *reinterpret_cast<bf16x4*>(op + nb * 16) = __builtin_convertvector(ov, bf16x4);
+                }
+            }
+        }
+    } else {
+        // merge the 4 waves' (m, l, O) through LDS
+        __syncthreads();
+        float* mo = reinterpret_cast<float*>(smem + wave * WAVE_LDS);
+        float* mst = mo + QT * D * 16;
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) {
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) mo[(qt * D + nb * 16 + lc * 4 + r) * 16 + lq] = o[qt][nb][r];
+            if (lc == 0) {
+                mst[(qt * 16 + lq) * 2 + 0] = m[qt];
+                mst[(qt * 16 + lq) * 2 + 1] = l[qt];
+            }
+        }
+        __syncthreads();
+        constexpr int ROWS = QT * 16;
+        const int item = pair * p.n_qgroups + qg;
+        for (int e = tid; e < ROWS * D; e += 256) {
+            const int Rl = e / D, d = e - Rl * D;  // local row (qt*16+q), d
+            const int R = qg * ROWS + Rl;
+            if (R >= nrows) continue;
+            const int qt = Rl >> 4, qq = Rl & 15;
+            float M = -1e30f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                const float* st = reinterpret_cast<const float*>(smem + w * WAVE_LDS) + QT * D * 16;
+                M = fmaxf(M, st[(qt * 16 + qq) * 2]);
+            }
+            float L = 0.f, acc = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                const float* ow = reinterpret_cast<const float*>(smem + w * WAVE_LDS);
+                const float* st = ow + QT * D * 16;
+                const float sc = __builtin_amdgcn_exp2f(st[(qt * 16 + qq) * 2] - M);
+                L += st[(qt * 16 + qq) * 2 + 1] * sc;
+                acc += ow[(qt * D + d) * 16 + qq] * sc;
+            }
+            if (p.nsplit == 1) {
+                const int i = R / g, r = R - i * g;
+                const float val = L > 0.f ? acc / L : 0.f;
+                p.out[((int64_t)(q0 + i) * p.H + kvh * g + r) * D + d] = f32_to_bf16(val);
+            } else {
+                const int64_t slot = ((int64_t)item * p.nsplit + split) * ROWS + Rl;
+                p.ws_o[slot * D + d] = acc;
+                if (d == 0) {
+                    p.ws_ml[slot * 2 + 0] = M;
+                    p.ws_ml[slot * 2 + 1] = L;
+                }
+            }
+        }
+    }
+}
+
+// combine split-KV partials: one block per (request, kv head) item
+template <int D>
+__global__ __launch_bounds__(256) void attn_merge_kernel(const AttnParams p, int rows_cap) {
+    const int item = blockIdx.x;  // pair * n_qgroups + qg  (n_qgroups == 1 in decode mode)
+    const int pair = item / p.n_qgroups, qg = item % p.n_qgroups;
+    const int b = pair / p.KH, kvh = pair % p.KH;
+    const int q0 = p.qo_indptr[b];
+    const int n_b = p.qo_indptr[b + 1] - q0;
+    const int nrows = n_b * p.g;
+    for (int e = threadIdx.x; e < rows_cap * D; e += 256) {
+        const int Rl = e / D, d = e - Rl * D;
+        const int R = qg * rows_cap + Rl;
+        if (R >= nrows) continue;
+        float M = -1e30f;
+        for (int s = 0; s < p.nsplit; ++s) {
+            const int64_t slot = ((int64_t)item * p.nsplit + s) * rows_cap + Rl;
+            M = fmaxf(M, p.ws_ml[slot * 2]);
+        }
+        float L = 0.f, acc = 0.f;
+        for (int s = 0; s < p.nsplit; ++s) {
+            const int64_t slot = ((int64_t)item * p.nsplit + s) * rows_cap + Rl;
+            const float sc = __builtin_amdgcn_exp2f(p.ws_ml[slot * 2] - M);
+            L += p.ws_ml[slot * 2 + 1] * sc;
+            acc += p.ws_o[slot * D + d] * sc;
+        }
+        const int i = R / p.g, r = R - i * p.g;
+        const float val = L > 0.f ? acc / L : 0.f;
+        p.out[((int64_t)(q0 + i) * p.H + kvh * p.g + r) * D + d] = f32_to_bf16(val);
+    }
+}
+
+struct AttnPlan {
+    bool splitq;
+    int qt;
+    int n_qgroups;
+    int nsplit;
+    int rows_cap;  // rows per item in the workspace (decode mode)
+};
+
+constexpr int kTargetWGs = 1024;  // 256 CUs x 2 workgroups/CU x 2 rounds
+
+AttnPlan make_plan(int B, int n_max, int H, int KH, int max_pages, int page_size) {
+    AttnPlan pl;
+    const int g = H / KH;
+    const int rows = n_max * g;
+    if (rows <= 32) {
+        pl.splitq = false;
+        pl.qt = rows <= 16 ? 1 : 2;
+        pl.n_qgroups = 1;
+        const long max_tiles = (long)max_pages * page_size / 32;
+        long want = (kTargetWGs + (long)B * KH - 1) / ((long)B * KH);
+        long cap = max_tiles / 16;  // >= 16 tiles (4 per wave) per workgroup
+        if (cap < 1) cap = 1;
+        if (want > cap) want = cap;
+        if (want > 64) want = 64;
+        if (want < 1) want = 1;
+        pl.nsplit = (int)want;
+        pl.rows_cap = pl.qt * 16;
+    } else {
+        pl.splitq = true;
+        pl.qt = rows >= 128 ? 2 : 1;
+        pl.n_qgroups = (rows + 64 * pl.qt - 1) / (64 * pl.qt);
+        pl.nsplit = 1;
+        pl.rows_cap = 0;
+    }
+    return pl;
+}
+
+template <int D, int QT, bool SPLITQ>
+int launch_attn(const AttnParams& p, int grid, hipStream_t st) {
+    constexpr int lds = 4 * attn_wave_lds<D, QT>();
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(
+            reinterpret_cast<const void*>(&paged_attn_kernel<D, QT, SPLITQ>),
+            hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) {
+            md_set_error("md_paged_attn: hipFuncSetAttribute(%d B LDS) failed: %s", lds, hipGetErrorString(e));
+            return MD_ERR_LAUNCH;
+        }
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((paged_attn_kernel<D, QT, SPLITQ>), dim3(grid), dim3(256), lds, st, p);
+    MD_CHECK_LAUNCH("md_paged_attn");
+    return MD_OK;
+}
+
+}  // namespace
+
+extern "C" size_t md_paged_attn_workspace_bytes(int B, int n_max, int H, int KH, int D,
+                                                int max_pages_per_req, int page_size) {
+    if (B <= 0 || KH <= 0 || H % KH != 0) return 0;
+    const AttnPlan pl = make_plan(B, n_max, H, KH, max_pages_per_req, page_size);
+    if (pl.splitq || pl.nsplit == 1) return 256;
+    const size_t slots = (size_t)B * KH * pl.nsplit * pl.rows_cap;
+    return slots * (size_t)D * 4 + slots * 8 + 256;
+}
+
+extern "C" int md_paged_attn(const void* q, int64_t q_row_stride, const void* cache, void* out,
+                             const int32_t* qo_indptr, const int32_t* page_indices,
+                             const int32_t* page_indptr, const int32_t* last_page_len, int B,
+                             int n_max, int H, int KH, int D, int page_size, int causal,
+                             float sm_scale, int max_pages_per_req, void* workspace,
+                             size_t workspace_bytes, md_stream_t stream) {
+    MD_CHECK_ARG(q && cache && out && qo_indptr && page_indices && page_indptr && last_page_len,
+                 "md_paged_attn: null pointer argument");
+    MD_CHECK_ARG(B > 0 && n_max > 0 && H > 0 && KH > 0 && H % KH == 0,
+                 "md_paged_attn: bad shape B=%d n_max=%d H=%d KH=%d", B, n_max, H, KH);
+    if (D != 64 && D != 128) {
+        md_set_error("md_paged_attn: head_dim %d unsupported (64 or 128)", D);
+        return MD_ERR_UNSUPPORTED;
+    }
+    MD_CHECK_ARG(page_size > 0 && page_size % 32 == 0, "md_paged_attn: page_size %d must be a multiple of 32", page_size);
+    MD_CHECK_ARG(q_row_stride % 8 == 0 && ((uintptr_t)q & 15) == 0 && ((uintptr_t)cache & 15) == 0 &&
+                     ((uintptr_t)out & 7) == 0,
+                 "md_paged_attn: q/cache must be 16-byte aligned with a row stride multiple of 8");
+    MD_CHECK_ARG(max_pages_per_req > 0, "md_paged_attn: max_pages_per_req must be > 0");
+
+    const AttnPlan pl = make_plan(B, n_max, H, KH, max_pages_per_req, page_size);
+    AttnParams p;
+    p.q = (const bf16_t*)q;
+    p.cache = (const bf16_t*)cache;
+    p.out = (bf16_t*)out;
+    p.qo_indptr = qo_indptr;
+    p.page_indices = page_indices;
+    p.page_indptr = page_indptr;
+    p.last_page_len = last_page_len;
+    p.q_row_stride = q_row_stride;
+    p.slot_stride = KH * D;
+    p.kv_half = (int64_t)page_size * KH * D;
+    p.page_stride = 2 * p.kv_half;
+    p.B = B;
+    p.H = H;
+    p.KH = KH;
+    p.g = H / KH;
+    p.page_size = page_size;
+    p.causal = causal ? 1 : 0;
+    p.nsplit = pl.nsplit;
+    p.n_qgroups = pl.n_qgroups;
+    p.scale_log2 = sm_scale * 1.4426950408889634f;
+    p.ws_o = nullptr;
+    p.ws_ml = nullptr;
+    if (!pl.splitq && pl.nsplit > 1) {
+        const size_t slots = (size_t)B * KH * pl.nsplit * pl.rows_cap;
+        const size_t need = slots * (size_t)D * 4 + slots * 8;
+        if (!workspace || workspace_bytes < need || ((uintptr_t)workspace & 15)) {
+            md_set_error("md_paged_attn: workspace too small or misaligned (%zu < %zu)", workspace_bytes, need);
+            return MD_ERR_WORKSPACE;
+        }
+        p.ws_o = (float*)workspace;
+        p.ws_ml = p.ws_o + slots * (size_t)D;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const int npairs8 = (B * KH + 7) / 8 * 8;
+    const int grid = npairs8 * pl.n_qgroups * pl.nsplit;
+    int rc;
+    if (D == 128) {
+        if (pl.splitq)
+            rc = pl.qt == 2 ? launch_attn<128, 2, true>(p, grid, st) : launch_attn<128, 1, true>(p, grid, st);
+        else
+            rc = pl.qt == 2 ? launch_attn<128, 2, false>(p, grid, st) : launch_attn<128, 1, false>(p, grid, st);
+    } else {
+        if (pl.splitq)
+            rc = pl.qt == 2 ? launch_attn<64, 2, true>(p, grid, st) : launch_attn<64, 1, true>(p, grid, st);
+        else
+            rc = pl.qt == 2 ? launch_attn<64, 2, false>(p, grid, st) : launch_attn<64, 1, false>(p, grid, st);
+    }
+    if (rc != MD_OK) return rc;
+    if (!pl.splitq && pl.nsplit > 1) {
+        if (D == 128)
+            hipLaunchKernelGGL((attn_merge_kernel<128>), dim3(B * KH), dim3(256), 0, st, p, pl.rows_cap);
+        else
+            hipLaunchKernelGGL((attn_merge_kernel<64>), dim3(B * KH), dim3(256), 0, st, p, pl.rows_cap);
+        MD_CHECK_LAUNCH("md_paged_attn(merge)");
+    }
+    return MD_OK;
+}
