@@ -68,8 +68,7 @@ int md_append_paged_kv(const void* k, const void* v, int64_t k_row_stride, int64
  * Token j of request b has position offsets[b]+j; the pair (x[2i],x[2i+1]) is
  * rotated by angle pos*freq[i].  `cos_sin` is a host-precomputed device table
  * float32 [max_pos][D/2][2] (cos, sin) -- see md_rope_fill_table_host for the
- * frequency definition.  Out-of-table positions are an error flagged in
- * *err_flag (device int32, may be NULL).  q_out/k_out are contiguous
+ * frequency definition.  Positions are clamped to [0, max_pos).  q_out/k_out are contiguous
  * [nnz,H,D] / [nnz,KH,D]; q/k carry a row stride in elements.  k/k_out may
  * be NULL (rotate q only).
  * ---------------------------------------------------------------------- */
@@ -137,6 +136,10 @@ int md_paged_attn(const void* q, int64_t q_row_stride, const void* cache, void* 
  * idx_out: [B, KH, budget-window] int32 (selected positions, reference order).
  * ---------------------------------------------------------------------- */
 size_t md_snapkv_workspace_bytes(int B, int H, int KH, int ctx_len, int window);
+/* byte offset, inside the (256-byte aligned) workspace, of the pooled group
+ * scores bf16 [B, KH, ctx_len-window] the top-k ran on (valid after the call;
+ * exposed so tests can compare scores, not only indices). */
+size_t md_snapkv_scores_offset(int B, int H, int KH, int ctx_len, int window);
 int md_snapkv_select(const void* q_win, const void* cache, const int32_t* page_indices,
                      const int32_t* page_indptr, int B, int H, int KH, int D, int page_size,
                      int ctx_len, int window, int budget, int pool_kernel, void* draft_cache,
@@ -160,7 +163,7 @@ int md_snapkv_select(const void* q_win, const void* cache, const int32_t* page_i
 int md_streaming_shift_append(const void* k_new, const void* v_new, int64_t k_row_stride,
                               int64_t v_row_stride, void* cache, int B, int n_new, int kv_len,
                               int sink, int pages_per_req, int KH, int D, int page_size,
-                              void* scratch, size_t scratch_bytes, md_stream_t stream);
+                              md_stream_t stream);
 int md_streaming_rotate(const void* cache, void* rot_cache, int B, int valid_len,
                         int pages_per_req, int KH, int D, int page_size, const float* cos_sin,
                         int max_pos, md_stream_t stream);

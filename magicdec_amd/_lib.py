@@ -30,8 +30,9 @@ _SIGNATURES = {
     "md_paged_attn_workspace_bytes": (c_size_t, [I, I, I, I, I, I, I]),
     "md_paged_attn": (c_int, [P, L, P, P, P, P, P, P, I, I, I, I, I, I, I, c_float, I, P, c_size_t, P]),
     "md_snapkv_workspace_bytes": (c_size_t, [I, I, I, I, I]),
+    "md_snapkv_scores_offset": (c_size_t, [I, I, I, I, I]),
     "md_snapkv_select": (c_int, [P, P, P, P, I, I, I, I, I, I, I, I, I, P, P, P, P, P, P, c_size_t, P]),
-    "md_streaming_shift_append": (c_int, [P, P, L, L, P, I, I, I, I, I, I, I, I, P, c_size_t, P]),
+    "md_streaming_shift_append": (c_int, [P, P, L, L, P, I, I, I, I, I, I, I, I, P]),
     "md_streaming_rotate": (c_int, [P, P, I, I, I, I, I, I, P, I, P]),
     "md_rmsnorm": (c_int, [P, P, P, I, I, c_float, P]),
     "md_add_rmsnorm": (c_int, [P, P, P, P, P, I, I, c_float, P]),

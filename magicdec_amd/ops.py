@@ -1,0 +1,296 @@
+"""Tensor-level wrappers over the C ABI (include/magicdec_hip.h).
+
+These are the seven ``mylib::*`` operators of the reference (Engine/utils.py:31-66,
+Engine/SnapKV/backend.py:56-107, Engine/SnapKV/model.py:133-156) plus the fused
+small ops of the decode loop, with the same tensor-level signatures, backed by
+hand-written gfx950 kernels.  Differences from the reference's op boundary:
+
+* no hidden ``plan()`` state: the page table is passed to the attention op
+  explicitly and read on the device (no host sync, graph-capturable);
+* tensors must live on the GPU; there is no CPU implementation here
+  (``MagicDecHipError`` if the library is missing, ``ValueError`` for CPU tensors).
+"""
+from __future__ import annotations
+
+import ctypes
+import math
+
+import torch
+
+from . import _lib
+from ._lib import MagicDecHipError, check  # noqa: F401
+
+PAGE_SIZE = 128
+
+
+def _p(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _gpu(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise ValueError("magicdec_amd.ops: tensors must be on the GPU (no CPU path exists)")
+
+
+def _i32(t):
+    if t.dtype != torch.int32:
+        raise TypeError("page-table tensors must be int32")
+    return t
+
+
+def _row_stride(t):
+    """[rows, heads, D] view whose last two dims are dense; returns the row stride in elements."""
+    if t.dim() != 3 or t.stride(2) != 1 or t.stride(1) != t.shape[2]:
+        raise ValueError("expected a [rows, heads, D] tensor with dense (heads, D)")
+    return t.stride(0)
+
+
+# ----------------------------------------------------------------------------- K4
+def update_kv(k, v, kv_append_indptr, kv_cache, kv_page_indices, kv_page_indptr, kv_page_lastlen, n_max=None):
+    """mylib::update_kv (Engine/utils.py:31-54).  In place on kv_cache."""
+    _gpu(k, v, kv_cache)
+    B = kv_page_indptr.numel() - 1
+    KH, D = kv_cache.shape[3], kv_cache.shape[4]
+    if n_max is None:
+        n_max = (k.shape[0] + B - 1) // B if B > 0 else 0
+        n_max = max(n_max, 1)
+    lib = _lib.load()
+    check(lib.md_append_paged_kv(_p(k), _p(v), _row_stride(k), _row_stride(v), _p(_i32(kv_append_indptr)),
+                                 _p(kv_cache), _p(_i32(kv_page_indices)), _p(_i32(kv_page_indptr)),
+                                 _p(_i32(kv_page_lastlen)), B, n_max, KH, D, kv_cache.shape[2], _stream()),
+          "md_append_paged_kv")
+
+
+# ----------------------------------------------------------------------------- K5
+class RopeTable:
+    """Host-precomputed cos/sin table on the device (float32 [max_pos, D/2, 2])."""
+
+    def __init__(self, max_pos, head_dim, rope_theta, rope_scale, low_freq_factor=None, high_freq_factor=None,
+                 old_context_len=None, device="cuda"):
+        lib = _lib.load()
+        host = torch.empty(max_pos, head_dim // 2, 2, dtype=torch.float32)
+        llama31 = low_freq_factor is not None and high_freq_factor is not None
+        check(lib.md_rope_fill_table_host(ctypes.c_void_p(host.data_ptr()), max_pos, head_dim, float(rope_theta),
+                                          float(rope_scale), float(low_freq_factor) if llama31 else 0.0,
+                                          float(high_freq_factor) if llama31 else 0.0,
+                                          float(old_context_len) if llama31 else 0.0),
+              "md_rope_fill_table_host")
+        self.table = host.to(device)
+        self.max_pos = max_pos
+        self.head_dim = head_dim
+
+
+def rope(q, k, indptr, offsets, table: RopeTable, n_max=None):
+    """mylib::rope / mylib::draft_rope (Engine/SnapKV/model.py:133-156): returns new (q, k)."""
+    _gpu(q, k)
+    B = indptr.numel() - 1
+    H, D = q.shape[1], q.shape[2]
+    KH = k.shape[1] if k is not None else 0
+    if n_max is None:
+        n_max = max((q.shape[0] + B - 1) // B, 1)
+    q_out = torch.empty((q.shape[0], H, D), dtype=q.dtype, device=q.device)
+    k_out = torch.empty((k.shape[0], KH, D), dtype=k.dtype, device=k.device) if k is not None else None
+    lib = _lib.load()
+    check(lib.md_rope(_p(q), _p(k), _row_stride(q), _row_stride(k) if k is not None else 0, _p(q_out), _p(k_out),
+                      _p(_i32(indptr)), _p(_i32(offsets)), B, n_max, H, KH, D, _p(table.table), table.max_pos,
+                      _stream()), "md_rope")
+    return q_out, k_out
+
+
+def rope_append(q, k, v, indptr, offsets, table: RopeTable, kv_cache, page_indices, page_indptr, last_page_len,
+                kv_cache2=None, page_indices2=None, page_indptr2=None, last_page_len2=None, n_max=None):
+    """Fused mylib::rope + mylib::update_kv (+ second cache for self-spec verify).  Returns rotated q."""
+    _gpu(q, k, v, kv_cache, kv_cache2)
+    B = indptr.numel() - 1
+    H, D = q.shape[1], q.shape[2]
+    KH = k.shape[1]
+    if n_max is None:
+        n_max = max((q.shape[0] + B - 1) // B, 1)
+    q_out = torch.empty((q.shape[0], H, D), dtype=q.dtype, device=q.device)
+    lib = _lib.load()
+    check(lib.md_rope_append(_p(q), _p(k), _p(v), _row_stride(q), _row_stride(k), _row_stride(v), _p(q_out),
+                             _p(_i32(indptr)), _p(_i32(offsets)), B, n_max, H, KH, D, _p(table.table), table.max_pos,
+                             _p(kv_cache), _p(_i32(page_indices)), _p(_i32(page_indptr)), _p(_i32(last_page_len)),
+                             _p(kv_cache2), _p(page_indices2), _p(page_indptr2), _p(last_page_len2),
+                             kv_cache.shape[2], _stream()), "md_rope_append")
+    return q_out
+
+
+# ----------------------------------------------------------------------------- K1/K2/K3
+class AttnWorkspace:
+    """Scratch for split-KV partials, grown on demand (never inside a captured graph)."""
+
+    def __init__(self, device="cuda"):
+        self.device = device
+        self.buf = torch.empty(1 << 20, dtype=torch.uint8, device=device)
+
+    def get(self, nbytes):
+        if self.buf.numel() < nbytes:
+            self.buf = torch.empty(int(nbytes * 1.25) + 256, dtype=torch.uint8, device=self.device)
+        return self.buf
+
+
+def paged_attention(q, kv_cache, qo_indptr, page_indices, page_indptr, last_page_len, n_max, max_pages_per_req,
+                    workspace: AttnWorkspace, causal=True, sm_scale=None, out=None):
+    """mylib::target_decode / target_prefill / draft_decode / draft_prefill
+    (Engine/SnapKV/backend.py:56-107): flashinfer BatchPrefillWithPagedKVCacheWrapper.run with the
+    plan() arguments passed explicitly."""
+    _gpu(q, kv_cache)
+    B = page_indptr.numel() - 1
+    H, D = q.shape[1], q.shape[2]
+    KH = kv_cache.shape[3]
+    page_size = kv_cache.shape[2]
+    if sm_scale is None:
+        sm_scale = 1.0 / math.sqrt(D)
+    if out is None:
+        out = torch.empty((q.shape[0], H, D), dtype=q.dtype, device=q.device)
+    lib = _lib.load()
+    nbytes = lib.md_paged_attn_workspace_bytes(B, n_max, H, KH, D, max_pages_per_req, page_size)
+    ws = workspace.get(nbytes)
+    check(lib.md_paged_attn(_p(q), _row_stride(q), _p(kv_cache), _p(out), _p(_i32(qo_indptr)), _p(_i32(page_indices)),
+                            _p(_i32(page_indptr)), _p(_i32(last_page_len)), B, n_max, H, KH, D, page_size,
+                            1 if causal else 0, float(sm_scale), max_pages_per_req, _p(ws), ws.numel(), _stream()),
+          "md_paged_attn")
+    return out
+
+
+# ----------------------------------------------------------------------------- K6
+def snapkv_select(q_win, kv_cache, page_indices, page_indptr, ctx_len, window, budget, pool_kernel, draft_cache,
+                  draft_page_indices, draft_page_indptr, draft_last_page_len, workspace: AttnWorkspace,
+                  return_scores=False):
+    """Attention.gen_draft_kv (Engine/SnapKV/model.py:389-439): writes budget rows per request and kv head
+    into draft_cache; returns the selected positions [B, KH, budget-window] int32 (reference order)."""
+    _gpu(q_win, kv_cache, draft_cache)
+    B = page_indptr.numel() - 1
+    H, D = q_win.shape[1], q_win.shape[2]
+    KH = kv_cache.shape[3]
+    if not q_win.is_contiguous():
+        q_win = q_win.contiguous()
+    idx = torch.empty((B, KH, budget - window), dtype=torch.int32, device=q_win.device)
+    lib = _lib.load()
+    nbytes = lib.md_snapkv_workspace_bytes(B, H, KH, ctx_len, window)
+    if nbytes == 0:
+        raise ValueError("md_snapkv_workspace_bytes: bad shape")
+    ws = workspace.get(nbytes + 512)
+    off = (-ws.data_ptr()) % 256
+    check(lib.md_snapkv_select(_p(q_win), _p(kv_cache), _p(_i32(page_indices)), _p(_i32(page_indptr)), B, H, KH, D,
+                               kv_cache.shape[2], ctx_len, window, budget, pool_kernel, _p(draft_cache),
+                               _p(_i32(draft_page_indices)), _p(_i32(draft_page_indptr)), _p(_i32(draft_last_page_len)),
+                               _p(idx), ctypes.c_void_p(ws.data_ptr() + off), nbytes, _stream()), "md_snapkv_select")
+    if return_scores:
+        soff = lib.md_snapkv_scores_offset(B, H, KH, ctx_len, window)
+        n = B * KH * (ctx_len - window)
+        sc = ws[off + soff: off + soff + 2 * n].view(torch.bfloat16).view(B, KH, ctx_len - window).clone()
+        return idx, sc
+    return idx
+
+
+# ----------------------------------------------------------------------------- K7
+def streaming_shift_append(k_new, v_new, kv_cache, n_new, kv_len, sink, pages_per_req):
+    """In-place equivalent of KVCache.prefill's eviction branch (Engine/StreamingLLM/model_draft.py:122-134)."""
+    _gpu(k_new, v_new, kv_cache)
+    B = k_new.shape[0] // n_new
+    KH, D = kv_cache.shape[3], kv_cache.shape[4]
+    lib = _lib.load()
+    check(lib.md_streaming_shift_append(_p(k_new), _p(v_new), _row_stride(k_new), _row_stride(v_new), _p(kv_cache), B,
+                                        n_new, kv_len, sink, pages_per_req, KH, D, kv_cache.shape[2], _stream()),
+          "md_streaming_shift_append")
+
+
+def streaming_rotate(kv_cache, rot_cache, B, valid_len, pages_per_req, table: RopeTable):
+    """Rotated clone of the draft cache (Engine/StreamingLLM/model_draft.py:112-118,135-143): K rotated by
+    slot position, V copied, rows [0, valid_len) of every request.  rot_cache may be kv_cache (in place)."""
+    _gpu(kv_cache, rot_cache)
+    KH, D = kv_cache.shape[3], kv_cache.shape[4]
+    lib = _lib.load()
+    check(lib.md_streaming_rotate(_p(kv_cache), _p(rot_cache), B, valid_len, pages_per_req, KH, D, kv_cache.shape[2],
+                                  _p(table.table), table.max_pos, _stream()), "md_streaming_rotate")
+
+
+# ----------------------------------------------------------------------------- K9
+def rmsnorm(x, weight, eps):
+    _gpu(x, weight)
+    dim = x.shape[-1]
+    x2 = x.reshape(-1, dim)
+    if not x2.is_contiguous():
+        x2 = x2.contiguous()
+    y = torch.empty_like(x2)
+    lib = _lib.load()
+    check(lib.md_rmsnorm(_p(x2), _p(weight), _p(y), x2.shape[0], dim, float(eps), _stream()), "md_rmsnorm")
+    return y.view(x.shape)
+
+
+def add_rmsnorm(x, r, weight, eps):
+    """h = x + r ; y = rmsnorm(h).  Returns (h, y)."""
+    _gpu(x, r, weight)
+    dim = x.shape[-1]
+    x2, r2 = x.reshape(-1, dim), r.reshape(-1, dim)
+    if not x2.is_contiguous():
+        x2 = x2.contiguous()
+    if not r2.is_contiguous():
+        r2 = r2.contiguous()
+    h = torch.empty_like(x2)
+    y = torch.empty_like(x2)
+    lib = _lib.load()
+    check(lib.md_add_rmsnorm(_p(x2), _p(r2), _p(weight), _p(h), _p(y), x2.shape[0], dim, float(eps), _stream()),
+          "md_add_rmsnorm")
+    return h.view(x.shape), y.view(x.shape)
+
+
+def silu_mul(a, b):
+    """bf16(silu(a)) * b for 2-D row-strided views (e.g. the two halves of a fused w1|w3 GEMM output)."""
+    _gpu(a, b)
+    if a.dim() != 2 or a.stride(1) != 1 or b.stride(1) != 1:
+        raise ValueError("silu_mul expects 2-D tensors with unit inner stride")
+    rows, dim = a.shape
+    y = torch.empty((rows, dim), dtype=a.dtype, device=a.device)
+    lib = _lib.load()
+    check(lib.md_silu_mul(_p(a), _p(b), a.stride(0), b.stride(0), _p(y), rows, dim, _stream()), "md_silu_mul")
+    return y
+
+
+# ----------------------------------------------------------------------------- K10
+def argmax(logits, index_offset=0, return_values=False):
+    """Row-wise argmax of bf16 logits [rows, vocab] (lowest index among equal maxima)."""
+    _gpu(logits)
+    if logits.dim() != 2 or logits.stride(1) != 1:
+        raise ValueError("argmax expects [rows, vocab] with unit inner stride")
+    rows, vocab = logits.shape
+    idx = torch.empty(rows, dtype=torch.int64, device=logits.device)
+    vals = torch.empty(rows, dtype=logits.dtype, device=logits.device) if return_values else None
+    lib = _lib.load()
+    check(lib.md_argmax(_p(logits), logits.stride(0), rows, vocab, int(index_offset), _p(vals), _p(idx), _stream()),
+          "md_argmax")
+    return (vals, idx) if return_values else idx
+
+
+def tp_argmax_merge(vals, idx):
+    """vals [rows, tp] bf16, idx [rows, tp] int64 -> winning global index per row (lowest rank on ties)."""
+    _gpu(vals, idx)
+    rows, tp = vals.shape
+    out = torch.empty(rows, dtype=torch.int64, device=vals.device)
+    lib = _lib.load()
+    check(lib.md_tp_argmax_merge(_p(vals.contiguous()), _p(idx.contiguous()), rows, tp, _p(out), _stream()),
+          "md_tp_argmax_merge")
+    return out
+
+
+# ----------------------------------------------------------------------------- a1
+def accept_rollback(tokens_buffer, target_tokens, output, num_nodes, cachelens, last_page_len, draft_cachelens,
+                    draft_last_page_len, gamma, draft_rollback, draft_cap, eot_1, eot_2, max_nodes, accept_nums,
+                    bonus, double_buffer, cachelens_update, flags):
+    """The verify-loop body (tests/SnapKV/longspec_benchmark.py:208-285) as one launch; all tensors are
+    updated in place, `flags` = int32[2] (terminal, next_double)."""
+    _gpu(tokens_buffer, target_tokens, output, num_nodes, cachelens, last_page_len)
+    B = tokens_buffer.shape[0]
+    lib = _lib.load()
+    check(lib.md_accept_rollback(_p(tokens_buffer), _p(target_tokens), _p(output), output.shape[1], _p(num_nodes),
+                                 _p(cachelens), _p(last_page_len), _p(draft_cachelens), _p(draft_last_page_len), B,
+                                 gamma, draft_rollback, draft_cap, int(eot_1), int(eot_2), int(max_nodes),
+                                 _p(accept_nums), _p(bonus), _p(double_buffer), _p(cachelens_update), _p(flags),
+                                 _stream()), "md_accept_rollback")

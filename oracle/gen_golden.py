@@ -1,0 +1,488 @@
+"""Generate the golden fixtures under tests/golden/ by running the REAL reference on CPU.
+
+Runs only in the build container (needs the read-only reference checkout, see
+oracle/ref_import.py); the fixtures it writes are committed, this script is the
+record of how they were made:
+
+    python -m oracle.gen_golden            # all scenarios (each in its own subprocess)
+    python -m oracle.gen_golden --scenario snapkv_select
+
+A fixture is data only: seeds/inputs and the reference's outputs (token ids, page
+table traces, selected indices, cache bytes as uint16 bf16 bit patterns).  The
+reference registers its custom ops inside setup_caches (a second call in the same
+process raises), hence one subprocess per scenario.
+
+Scenarios
+  snapkv_select     Attention.gen_draft_kv              Engine/SnapKV/model.py:389-439      g = 4, 5, 8
+  stream_prefill    KVCache.prefill                     Engine/StreamingLLM/model_draft.py:102-143
+  accept_loop       the verify-loop body, exec'd from   tests/SnapKV/longspec_benchmark.py:208-281
+  tp_shapes         _select_kv_heads / apply_tp         Engine/tp.py:36-52,184-207
+  run_*             the five benchmark scripts run unmodified under runpy with a stub tokenizer,
+                    a seeded synthetic dataset and call tracing of the Engine methods
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import runpy
+import subprocess
+import sys
+import tempfile
+import types
+from pathlib import Path
+
+import numpy as np
+import torch
+
+ROOT = Path(__file__).resolve().parents[1]
+GOLD = ROOT / "tests" / "golden"
+sys.path.insert(0, str(ROOT))
+
+from oracle import ref_import  # noqa: E402
+from oracle.magicdec_ref import RefConfig, init_state_dict  # noqa: E402
+
+BF16 = torch.bfloat16
+
+# tiny GQA configs shared with the tests (tests/golden_cfg.py mirrors these numbers)
+TINY = {
+    # name: (config kwargs in the REFERENCE's ModelArgs vocabulary, weight seed)
+    "tinytgt": (dict(block_size=4096, n_layer=2, n_head=8, n_local_heads=2, dim=512, intermediate_size=1024,
+                     vocab_size=2048, rope_base=500000.0, scaling_factor=8, high_freq_factor=4, low_freq_factor=1,
+                     original_max_position_embeddings=8192), 11, 0.1),
+    "tinydrf": (dict(block_size=4096, n_layer=1, n_head=8, n_local_heads=2, dim=512, intermediate_size=1024,
+                     vocab_size=2048, rope_base=10000.0), 12, 0.1),
+}
+
+
+def bits(t):
+    return t.contiguous().view(torch.int16).numpy().astype(np.uint16) if t.dtype == BF16 else t.numpy()
+
+
+def ref_cfg(name):
+    kw, seed, wo_scale = TINY[name]
+    kw = {k: v for k, v in kw.items() if k != "block_size"}
+    return RefConfig(n_layer=kw["n_layer"], n_head=kw["n_head"], n_local_heads=kw["n_local_heads"], dim=kw["dim"],
+                     intermediate_size=kw["intermediate_size"], vocab_size=kw["vocab_size"],
+                     rope_base=kw.get("rope_base", 10000.0), scaling_factor=kw.get("scaling_factor", 1.0),
+                     low_freq_factor=kw.get("low_freq_factor"), high_freq_factor=kw.get("high_freq_factor"),
+                     original_max_position_embeddings=kw.get("original_max_position_embeddings")), seed, wo_scale
+
+
+def write_checkpoints(tmp):
+    """<tmp>/<cfgname>/model.pth for every tiny config; the parent dir name selects the config
+    (Engine/SnapKV/model.py:45-57)."""
+    paths = {}
+    for name in TINY:
+        cfg, seed, wo_scale = ref_cfg(name)
+        d = Path(tmp) / name
+        d.mkdir(parents=True, exist_ok=True)
+        torch.save(init_state_dict(cfg, seed, wo_scale=wo_scale), d / "model.pth")
+        paths[name] = d / "model.pth"
+    return paths
+
+
+def inject_configs():
+    for mod in ("Engine.SnapKV.model", "Engine.SnapKV.model_draft", "Engine.StreamingLLM.model",
+                "Engine.StreamingLLM.model_draft"):
+        m = ref_import.module(mod)
+        for name, (kw, _, _) in TINY.items():
+            m.transformer_configs[name] = dict(kw)
+
+
+# ------------------------------------------------------------------------------------ snapkv_select
+def scen_snapkv_select():
+    M = ref_import.module("Engine.SnapKV.model")
+    out = {}
+    for tag, (g, KH, D, S, budget, B, seed) in {"g4": (4, 2, 64, 416, 129, 2, 0), "g5": (5, 2, 64, 288, 129, 2, 1),
+                                                "g8": (8, 1, 128, 416, 257, 2, 2),
+                                                "g4d128": (4, 1, 128, 544, 257, 1, 3)}.items():
+        W = 32
+        H = g * KH
+        torch.manual_seed(seed)
+        cfg = M.ModelArgs(block_size=2048, n_layer=1, n_head=H, n_local_heads=KH, dim=H * D, intermediate_size=256,
+                          vocab_size=128)
+        att = M.Attention(cfg)
+        att.is_spec, att.draft_budget, att.window_size, att.pooling, att.kernel_size = True, budget, W, "avgpool", 5
+        npg = (S + 127) // 128
+        kfull = torch.randn(B, S, KH, D).to(BF16)
+        vfull = torch.randn(B, S, KH, D).to(BF16)
+        cache = torch.zeros(B * npg, 2, 128, KH, D, dtype=BF16)
+        for b in range(B):
+            kk = torch.zeros(npg * 128, KH, D, dtype=BF16)
+            vv = torch.zeros(npg * 128, KH, D, dtype=BF16)
+            kk[:S], vv[:S] = kfull[b], vfull[b]
+            cache[b * npg:(b + 1) * npg, 0] = kk.view(npg, 128, KH, D)
+            cache[b * npg:(b + 1) * npg, 1] = vv.view(npg, 128, KH, D)
+        q = torch.randn(B * W, H, D).to(BF16)
+        cap = {}
+
+        class KC:
+            def update_draft(self, k, v, indptr, idx, ip, last):
+                cap["k"], cap["v"] = k.clone(), v.clone()
+        att.kv_cache = KC()
+        orig_topk = torch.Tensor.topk
+
+        def tk(self, k, dim=-1):
+            cap["scores"] = self.clone()
+            r = orig_topk(self, k, dim=dim)
+            cap["idx"] = r.indices.clone()
+            return r
+        torch.Tensor.topk = tk
+        try:
+            att.gen_draft_kv(q, cache[:, 0], cache[:, 1], B, W, torch.tensor(S), (torch.arange(B + 1) * budget).int(),
+                             None, None, None)
+        finally:
+            torch.Tensor.topk = orig_topk
+        out.update({f"{tag}_meta": np.array([g, KH, D, S, budget, B, W]), f"{tag}_q": bits(q), f"{tag}_k": bits(kfull),
+                    f"{tag}_v": bits(vfull), f"{tag}_scores": bits(cap["scores"]), f"{tag}_idx": cap["idx"].numpy(),
+                    f"{tag}_newk": bits(cap["k"]), f"{tag}_newv": bits(cap["v"])})
+    np.savez_compressed(GOLD / "snapkv_select.npz", **out)
+
+
+# ------------------------------------------------------------------------------------ stream_prefill
+def scen_stream_prefill():
+    ref_import.module("Engine.utils")       # defines mylib::update_kv
+    M = ref_import.module("Engine.StreamingLLM.model_draft")
+    fr = sys.modules["flashinfer"]
+    B, KH, D, budget = 2, 1, 64, 129
+    ppr = budget // 128 + 1
+    table = fr.rope_table(1024, D, 10000.0, 1.0)
+
+    def rope(q, k, indptr, offsets):
+        return fr.apply_rope(q, k, indptr, offsets, table)
+    kvc = M.KVCache(B * ppr, 128, KH, D, BF16, budget)
+    torch.manual_seed(5)
+    out = {"meta": np.array([B, KH, D, budget, ppr])}
+    ctx = 0
+    S = 128 * 4 + 37
+    npr = 0
+    step = 0
+    for st in range(0, S, 128):
+        n = min(128, S - st)
+        is_last = n != 128
+        k = torch.randn(B * n, KH, D).to(BF16)
+        v = torch.randn(B * n, KH, D).to(BF16)
+        if ctx + n <= budget:       # StreamingLLM/backend_draft.py:155-160
+            npr += 1
+            last = n
+        else:
+            npr = ppr
+            last = budget % 128
+        indices = torch.cat([torch.arange(i * ppr, i * ppr + npr, dtype=torch.int32) for i in range(B)])
+        indptr = (torch.arange(B + 1) * npr).to(torch.int32)
+        lastt = torch.full((B,), last, dtype=torch.int32)
+        append_indptr = (torch.arange(B + 1) * n).to(torch.int32)
+        rot = kvc.prefill(k, v, append_indptr, indices, indptr, lastt, B, torch.tensor(ctx), n, KH, D, rope, is_last)
+        out[f"k{step}"], out[f"v{step}"] = bits(k), bits(v)
+        out[f"cache{step}"] = bits(kvc.kv_cache.clone())
+        out[f"rot{step}"] = bits(rot.clone())
+        out[f"info{step}"] = np.array([ctx, n, int(is_last), npr, last])
+        ctx = min(ctx + n, budget)
+        step += 1
+    out["nsteps"] = np.array([step])
+    np.savez_compressed(GOLD / "stream_prefill.npz", **out)
+
+
+# ------------------------------------------------------------------------------------ accept_loop
+def _loop_body_source(script, first_marker, last_marker):
+    """The verify-loop body text, read from the reference at generation time (never stored in the repo)."""
+    lines = (Path(ref_import.REFERENCE_ROOT) / script).read_text().splitlines()
+    i0 = next(i for i, l in enumerate(lines) if first_marker in l)
+    i1 = next(i for i, l in enumerate(lines) if last_marker in l and i > i0)
+    body = lines[i0:i1]
+    ind = min(len(l) - len(l.lstrip()) for l in body if l.strip())
+    return "\n".join(l[ind:] for l in body)
+
+
+def scen_accept_loop():
+    """Executes the reference's own loop-body statements on crafted integer inputs (EOT in draft / bonus,
+    all-accept rows, mixed rows, length termination) and records inputs and resulting state."""
+    variants = {
+        "longspec": ("tests/SnapKV/longspec_benchmark.py", "draft_tokens = tokens_buffer[:, 1:args.gamma+1]",
+                     "if not terminal:\n"),
+        "selfspec_snapkv": ("tests/SnapKV/selfspec_benchmark.py", "draft_tokens = tokens_buffer[:, 1:args.gamma+1]",
+                            "if not terminal:\n"),
+        "selfspec_stream": ("tests/StreamingLLM/selfspec_benchmark.py",
+                            "draft_tokens = tokens_buffer[:, 1:args.gamma+1]", "if not terminal:\n"),
+    }
+    out = {}
+    rng = np.random.default_rng(7)
+    for vname, (script, m0, _) in variants.items():
+        lines = (Path(ref_import.REFERENCE_ROOT) / script).read_text().splitlines()
+        i0 = next(i for i, l in enumerate(lines) if m0 in l)
+        # body ends right before the benchmark-timing tail: the second top-level `if not terminal:` after i0
+        nt = [i for i, l in enumerate(lines) if i > i0 and l.strip() == "if not terminal:"]
+        i1 = nt[1] if len(nt) > 1 else nt[0]
+        body = lines[i0:i1]
+        ind = min(len(l) - len(l.lstrip()) for l in body if l.strip())
+        src = "\n".join(l[ind:] for l in body)
+        # the else-branch that writes the bonus token on termination follows; restate its effect from the
+        # script lines too: locate `for i in range(BATCH_SIZE):` after i1
+        j0 = next(i for i, l in enumerate(lines) if i > i1 and "for i in range(BATCH_SIZE):" in l)
+        tail = lines[j0:j0 + 3]
+        tind = min(len(l) - len(l.lstrip()) for l in tail if l.strip())
+        tail_src = "\n".join(l[tind:] for l in tail)
+        code, tail_code = compile(src, script, "exec"), compile(tail_src, script, "exec")
+        cases = []
+        for case in range(24):
+            gamma = int(rng.choice([1, 3, 4]))
+            B = int(rng.choice([1, 3, 8]))
+            prefix = 300
+            out_cols = prefix + 128 + 1
+            eot_1, eot_2 = 7, 9
+            tb = torch.from_numpy(rng.integers(10, 30, size=(B, gamma + 1))).long()
+            tt = tb.roll(-1, dims=1).clone()
+            tt[:, -1] = torch.from_numpy(rng.integers(10, 30, size=(B,)))
+            mode = case % 6
+            if mode == 0:       # all accepted somewhere
+                pass
+            elif mode == 1:     # random rejections
+                rej = torch.from_numpy(rng.integers(0, 2, size=(B, gamma + 1))).bool()
+                tt = torch.where(rej, tt + 100, tt)
+            elif mode == 2:     # EOT among drafts
+                tb[0, min(1, gamma)] = eot_1
+                tt[0, 0] = eot_1
+            elif mode == 3:     # EOT as bonus
+                tt[:, :] = tt + 100
+                tt[B - 1, 0] = eot_2
+            elif mode == 4:     # mixed full / partial
+                tt[::2] = tt[::2] + 100
+            base = torch.from_numpy(rng.integers(prefix, prefix + 40, size=(B,))).int()
+            if mode == 5:       # length termination
+                base[:] = prefix + 78
+            ns = types.SimpleNamespace
+            engine = ns(cachelens=(base + gamma + 1).clone(), paged_kv_last_page_len=(base % 128 + gamma + 1).clone(),
+                        draft_cachelens=(base + gamma + 2).clone(),
+                        draft_paged_kv_last_page_len=((base + 1) % 128 + gamma + 1).clone())
+            draft = ns(cachelens=(base % 129 + 129 + gamma).clone(), paged_kv_last_page_len=(base % 100 + gamma + 2).clone())
+            num_nodes = (base.long() + 1).clone()
+            output = torch.zeros(B, out_cols).long()
+            env = dict(torch=torch, args=ns(gamma=gamma, prefix_len=prefix), tokens_buffer=tb.clone(),
+                       target_tokens=tt.clone(), eot_1=eot_1, eot_2=eot_2, engine=engine, draft=draft, output=output,
+                       num_nodes=num_nodes, DEVICE="cpu", BATCH_SIZE=B, terminal=False, use_tp=False, rank=0,
+                       next_double=False, double_buffer=None, cachelens_update=None, benchmark=False)
+            rec = dict(gamma=gamma, B=B, prefix=prefix, out_cols=out_cols, eot_1=eot_1, eot_2=eot_2,
+                       tokens_buffer=tb.tolist(), target_tokens=tt.tolist(), cachelens=engine.cachelens.tolist(),
+                       last_page_len=engine.paged_kv_last_page_len.tolist(),
+                       engine_draft_cachelens=engine.draft_cachelens.tolist(),
+                       engine_draft_last_page_len=engine.draft_paged_kv_last_page_len.tolist(),
+                       draft_cachelens=draft.cachelens.tolist(), draft_last_page_len=draft.paged_kv_last_page_len.tolist(),
+                       num_nodes=num_nodes.tolist())
+            exec(code, env)
+            if env["terminal"]:
+                exec(tail_code, env)      # for i: output[i, num_nodes[i]] = bonus[i] ; num_nodes += 1
+            res = dict(terminal=bool(env["terminal"]), accept_nums=env["accept_nums"].flatten().tolist(),
+                       bonus=env["bonus_tokens"].flatten().tolist(), tokens_buffer=env["tokens_buffer"].tolist(),
+                       cachelens=env["engine"].cachelens.tolist(), last_page_len=env["engine"].paged_kv_last_page_len.tolist(),
+                       engine_draft_cachelens=env["engine"].draft_cachelens.tolist(),
+                       engine_draft_last_page_len=env["engine"].draft_paged_kv_last_page_len.tolist(),
+                       draft_cachelens=env["draft"].cachelens.tolist(),
+                       draft_last_page_len=env["draft"].paged_kv_last_page_len.tolist(),
+                       num_nodes=env["num_nodes"].tolist(), output_nz=[[int(c), int(v)] for c, v in
+                                                                       zip(*np.nonzero(env["output"].numpy()))],
+                       output_vals=env["output"].numpy()[np.nonzero(env["output"].numpy())].tolist(),
+                       next_double=bool(env.get("next_double", False)),
+                       double_buffer=env["double_buffer"].tolist() if env.get("next_double") else None,
+                       cachelens_update=env["cachelens_update"].tolist() if env.get("next_double") else None)
+            cases.append(dict(inp=rec, out=res))
+        out[vname] = cases
+    (GOLD / "accept_loop.json").write_text(json.dumps(out))
+
+
+# ------------------------------------------------------------------------------------ tp_shapes
+def scen_tp_shapes():
+    tp = ref_import.module("Engine.tp")
+    M = ref_import.module("Engine.SnapKV.model")
+    res = {"select": [], "shard": []}
+    for (H, KH, world) in [(32, 8, 8), (32, 8, 4), (64, 8, 8), (40, 8, 8), (28, 4, 8), (8, 2, 2), (32, 8, 3)]:
+        for r in range(world):
+            os.environ["LOCAL_RANK"] = str(r)
+            s, e = tp._select_kv_heads(KH, list(range(world)))
+            res["select"].append([H, KH, world, r, s, e])
+    inject_configs()
+    cfg, seed, wo_scale = ref_cfg("tinytgt")
+    sd = init_state_dict(cfg, seed, wo_scale=wo_scale)
+    for world in (2,):
+        for r in range(world):
+            os.environ["LOCAL_RANK"] = str(r)
+            model = M.Transformer.from_name("tinytgt")
+            model.load_state_dict(sd, assign=True)
+
+            class G:
+                pass
+            import torch.distributed as dist
+            # apply_tp needs dist.get_world_size/get_rank(process_group) only
+            orig_ws, orig_rk = dist.get_world_size, dist.get_rank
+            dist.get_world_size = lambda g=None: world
+            dist.get_rank = lambda g=None: r
+            try:
+                tp.apply_tp(model, list(range(world)), group="G")
+            finally:
+                dist.get_world_size, dist.get_rank = orig_ws, orig_rk
+            shapes = {k: list(v.shape) for k, v in model.state_dict().items()}
+            sums = {k: float(v.float().sum()) for k, v in model.state_dict().items()}
+            res["shard"].append(dict(world=world, rank=r, shapes=shapes, sums=sums,
+                                     cfg=[model.config.n_head, model.config.n_local_heads, model.config.dim]))
+    (GOLD / "tp_shapes.json").write_text(json.dumps(res))
+
+
+# ------------------------------------------------------------------------------------ run_* (whole scripts)
+class StubTokenizer:
+    eos_token = "</s>"
+    eos_token_id = 2
+    unk_token_id = 0
+    bos_token_id = 1
+    pad_token = None
+
+    @classmethod
+    def from_pretrained(cls, *a, **k):
+        return cls()
+
+    def decode(self, ids, **k):
+        return " ".join(str(int(i)) for i in ids)
+
+    def encode(self, s, **k):
+        return [3]
+
+
+def synthetic_dataset(prefix_len, n_seq, vocab, seed=123):
+    """PG-19-shaped batch: ids uniform in [4, vocab), column 0 = BOS (Data/data_converter.py:54)."""
+    from torch.utils.data import TensorDataset
+    g = torch.Generator().manual_seed(seed)
+    ids = torch.randint(4, vocab, (n_seq, prefix_len), generator=g)
+    ids[:, 0] = 1
+    return TensorDataset(ids)
+
+
+def run_script(script, argv, classes, vocab, prefix_len, n_seq, tag):
+    """Run a reference benchmark script unmodified under runpy, tracing Engine method calls."""
+    inject_configs()
+    import transformers
+    transformers.AutoTokenizer = StubTokenizer
+    dc = ref_import.module("Data.data_converter")
+    dc.convert_pg19_dataset = lambda tokenizer=None, seq_len=0, **k: synthetic_dataset(prefix_len, n_seq, vocab)
+    torch.cuda.synchronize = lambda *a, **k: None
+    trace = []
+
+    def wrap(cls, name, state_attrs):
+        orig = getattr(cls, name)
+
+        def f(self, input_ids, *a, **kw):
+            r = orig(self, input_ids, *a, **kw)
+            rec = dict(cls=cls.__module__.split(".")[-2] + "." + cls.__name__, fn=name,
+                       inp=input_ids.tolist() if input_ids.shape[1] <= 8 else [int(input_ids.shape[1])],
+                       out=r.tolist() if r.shape[1] <= 8 else r[:, -1:].tolist())
+            if "cachelen_update" in kw and kw["cachelen_update"] is not None:
+                rec["cachelen_update"] = kw["cachelen_update"].flatten().tolist()
+            for at in state_attrs:
+                if hasattr(self, at) and getattr(self, at) is not None:
+                    rec[at] = getattr(self, at).tolist()
+            trace.append(rec)
+            return r
+        setattr(cls, name, f)
+    attrs = ["cachelens", "paged_kv_last_page_len", "paged_kv_indptr", "draft_cachelens", "draft_paged_kv_last_page_len",
+             "draft_paged_kv_indptr"]
+    for modname, clsname, fns in classes:
+        cls = getattr(ref_import.module(modname), clsname)
+        for fn in fns:
+            if hasattr(cls, fn):
+                wrap(cls, fn, attrs)
+    topk_calls = []
+    orig_topk = torch.Tensor.topk
+
+    def tk(self, k, dim=-1, **kw):
+        r = orig_topk(self, k, dim=dim, **kw)
+        if self.dim() == 3:                      # SnapKV select: [B, KH, S-W]
+            topk_calls.append(r.indices.tolist())
+        return r
+    torch.Tensor.topk = tk
+    old = sys.argv
+    sys.argv = [script] + argv
+    outputs = []
+    # capture per-batch final `output`/`num_nodes`: the scripts print after each batch; hook print
+    import builtins
+    try:
+        g = runpy.run_path(str(Path(ref_import.REFERENCE_ROOT) / script), run_name="__main__")
+    finally:
+        sys.argv = old
+        torch.Tensor.topk = orig_topk
+    final = {}
+    for key in ("output", "num_nodes"):
+        if key in g and torch.is_tensor(g[key]):
+            final[key] = g[key].tolist()
+    (GOLD / f"{tag}.json").write_text(json.dumps(dict(argv=argv, trace=trace, final=final, snapkv_topk=topk_calls)))
+
+
+def scen_run(tag):
+    tmp = tempfile.mkdtemp(prefix="magicdec_ckpt_")
+    ck = write_checkpoints(tmp)
+    vocab = TINY["tinytgt"][0]["vocab_size"]
+    B, S, ML, G = 2, 416, 512, 3
+    common = ["--B", str(B), "--prefix_len", str(S), "--max_len", str(ML), "--gamma", str(G), "--rank_group", "0"]
+    if tag == "run_longspec_snapkv":          # draft = target weights (high acceptance, double-buffer path)
+        run_script("tests/SnapKV/longspec_benchmark.py",
+                   ["--target", str(ck["tinytgt"]), "--model", str(ck["tinytgt"]), "--draft_budget", "129",
+                    "--draft_rank_group", "0"] + common,
+                   [("Engine.SnapKV.backend", "LMBackend", ["encode", "inference"]),
+                    ("Engine.SnapKV.backend_draft", "LMBackend_Draft", ["encode", "inference"])], vocab, S, 6 * B, tag)
+    elif tag == "run_longspec_snapkv_rej":    # different draft model (frequent rejections); gamma=1 because the
+        # SnapKV draft table is never rolled back by the harness (it rebinds draft.paged_kv_last_page_len, the
+        # compressed path uses draft_paged_kv_last_page_len) and would overflow its spare page at gamma=3
+        common1 = [c if c != str(G) else "1" for c in common]
+        run_script("tests/SnapKV/longspec_benchmark.py",
+                   ["--target", str(ck["tinytgt"]), "--model", str(ck["tinydrf"]), "--draft_budget", "129",
+                    "--draft_rank_group", "0"] + common1,
+                   [("Engine.SnapKV.backend", "LMBackend", ["encode", "inference"]),
+                    ("Engine.SnapKV.backend_draft", "LMBackend_Draft", ["encode", "inference"])], vocab, S, 6 * B, tag)
+    elif tag == "run_longspec_stream":
+        run_script("tests/StreamingLLM/longspec_benchmark.py",
+                   ["--target", str(ck["tinytgt"]), "--model", str(ck["tinytgt"]), "--draft_budget", "129",
+                    "--draft_rank_group", "0"] + common,
+                   [("Engine.SnapKV.backend", "LMBackend", ["encode", "inference"]),
+                    ("Engine.StreamingLLM.backend_draft", "LMBackend_Draft", ["encode", "inference"])], vocab, S, 6 * B,
+                   tag)
+    elif tag == "run_selfspec_snapkv":
+        run_script("tests/SnapKV/selfspec_benchmark.py",
+                   ["--model", str(ck["tinytgt"]), "--draft_budget", "129"] + common,
+                   [("Engine.SnapKV.backend", "LMBackend", ["encode", "speculate", "verify"])], vocab, S, 6 * B, tag)
+    elif tag == "run_selfspec_stream":
+        run_script("tests/StreamingLLM/selfspec_benchmark.py",
+                   ["--model", str(ck["tinytgt"]), "--draft_budget", "129"] + common,
+                   [("Engine.StreamingLLM.backend", "LMBackend", ["encode", "draft_encode", "speculate", "verify"])],
+                   vocab, S, 6 * B, tag)
+    elif tag == "run_baseline":
+        run_script("tests/baseline_benchmark.py",
+                   ["--model", str(ck["tinytgt"]), "--B", str(B), "--prefix_len", str(S), "--max_len", str(ML),
+                    "--rank_group", "0"],
+                   [("Engine.SnapKV.backend", "LMBackend", ["encode", "inference"])], vocab, S, 6 * B, tag)
+    else:
+        raise SystemExit(f"unknown scenario {tag}")
+
+
+SCENARIOS = {"snapkv_select": scen_snapkv_select, "stream_prefill": scen_stream_prefill,
+             "accept_loop": scen_accept_loop, "tp_shapes": scen_tp_shapes}
+RUNS = ["run_longspec_snapkv", "run_longspec_snapkv_rej", "run_longspec_stream", "run_selfspec_snapkv",
+        "run_selfspec_stream", "run_baseline"]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--scenario", default=None)
+    a = ap.parse_args()
+    GOLD.mkdir(parents=True, exist_ok=True)
+    if a.scenario is None:
+        for s in list(SCENARIOS) + RUNS:
+            print("==", s, flush=True)
+            subprocess.run([sys.executable, "-m", "oracle.gen_golden", "--scenario", s], cwd=str(ROOT), check=True)
+        return
+    torch.manual_seed(0)
+    with torch.inference_mode():
+        if a.scenario in SCENARIOS:
+            SCENARIOS[a.scenario]()
+        else:
+            scen_run(a.scenario)
+
+
+if __name__ == "__main__":
+    main()
