@@ -1,0 +1,397 @@
+"""The transformer of the draft/verify decode path, MI355X-native.
+
+One implementation serves the four `Transformer` classes of the reference
+(Engine/SnapKV/model.py, Engine/SnapKV/model_draft.py, Engine/StreamingLLM/model.py,
+Engine/StreamingLLM/model_draft.py): same constructor, parameter names (so a
+reference `model.pth` loads unchanged), `config` object, `setup_caches` and the
+forward / verify / draft_forward / prefill / draft_prefill methods returning
+token ids [B, n].  What differs from the reference is everything underneath:
+
+* no flashinfer, no torch.library ops, no torch.compile: the attention, RoPE,
+  KV append, SnapKV select, StreamingLLM eviction, norms, SiLU*mul and argmax
+  are hand-written gfx950 kernels reached through the C ABI (magicdec_amd.ops);
+* per layer and step: 4 GEMMs (hipBLASLt via F.linear; w1|w3 fused into one) and
+  5 kernel launches (add+rmsnorm, rope+append, attention, add+rmsnorm, silu*mul);
+  RoPE and the paged append are one launch, the residual add is fused into the
+  following norm;
+* the page table is read on the device by the attention kernel -- there is no
+  host-side plan() and no host<->device sync anywhere in a step, so a step can be
+  captured into a hipGraph (Engine/graph.py);
+* KV pages live in one slab per layer sized for 288 GB HBM (no page migration).
+
+bf16 rounding points follow the reference (see oracle/magicdec_ref.py): linear
+outputs bf16, fp32 RMSNorm -> bf16 -> *weight in bf16, residual adds in bf16,
+SiLU in bf16 then the product in bf16, fp32 softmax, argmax on bf16 logits with
+lowest-index tie-break.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+from torch.nn import functional as F
+
+from .. import ops
+
+
+def find_multiple(n: int, k: int) -> int:
+    return n if n % k == 0 else n + k - (n % k)
+
+
+@dataclass
+class ModelArgs:
+    """Same fields and defaults as the reference's ModelArgs (Engine/SnapKV/model.py:17-43)."""
+    block_size: int = 2048
+    vocab_size: int = 32000
+    n_layer: int = 32
+    n_head: int = 32
+    dim: int = 4096
+    intermediate_size: int = None
+    n_local_heads: int = -1
+    head_dim: int = 64
+    rope_base: float = 10000
+    norm_eps: float = 1e-5
+    scaling_factor: float = 1.0
+    low_freq_factor: int = None
+    high_freq_factor: int = None
+    original_max_position_embeddings: int = None
+    qkv_bias: bool = False
+
+    def __post_init__(self):
+        if self.n_local_heads == -1:
+            self.n_local_heads = self.n_head
+        if self.intermediate_size is None:
+            self.intermediate_size = find_multiple(int(2 * 4 * self.dim / 3), 256)
+        self.head_dim = self.dim // self.n_head
+
+    @classmethod
+    def from_name(cls, name: str):
+        """Exact key, else the longest config key contained in `name` (checkpoint directory name),
+        as Engine/SnapKV/model.py:45-57."""
+        if name in transformer_configs:
+            return cls(**transformer_configs[name])
+        hits = [c for c in transformer_configs if c.lower() in str(name).lower()]
+        if not hits:
+            raise KeyError(f"no transformer config matches '{name}'")
+        hits.sort(key=len, reverse=True)
+        if len(hits) > 1:
+            assert len(hits[0]) != len(hits[1]), name
+        return cls(**transformer_configs[hits[0]])
+
+
+# model zoo of the reference (Engine/SnapKV/model.py:60-79)
+transformer_configs = {
+    "llama-2-7b": dict(block_size=4096, n_layer=32, n_head=32, dim=4096),
+    "llama-2-7b-32k": dict(block_size=32768, n_layer=32, dim=4096, vocab_size=32000, scaling_factor=8),
+    "llama-2-13b": dict(block_size=4096, n_layer=40, n_head=40, dim=5120),
+    "llama-2-70b": dict(block_size=4096, n_layer=80, n_head=64, dim=8192, n_local_heads=8, intermediate_size=28672),
+    "llama-3-8b": dict(block_size=8192, n_layer=32, n_head=32, n_local_heads=8, dim=4096, intermediate_size=14336,
+                       vocab_size=128256, rope_base=500000),
+    "llama-3-70b": dict(block_size=8192, n_layer=80, n_head=64, n_local_heads=8, dim=8192, intermediate_size=28672,
+                        vocab_size=128256, rope_base=500000),
+    "68m": dict(block_size=2048, n_layer=2, n_head=12, n_local_heads=12, dim=768, intermediate_size=3072,
+                vocab_size=32000),
+    "tinyllama": dict(block_size=2048, n_layer=22, n_head=32, n_local_heads=4, dim=2048, intermediate_size=5632,
+                      vocab_size=32000),
+    "llama-3.1-8b": dict(block_size=131072, n_layer=32, n_head=32, n_local_heads=8, dim=4096,
+                         intermediate_size=14336, vocab_size=128256, rope_base=500000.0, scaling_factor=8,
+                         high_freq_factor=4, low_freq_factor=1, original_max_position_embeddings=8192),
+    "llama-3.1-70b": dict(block_size=131072, n_layer=80, n_head=64, n_local_heads=8, dim=8192,
+                          intermediate_size=28672, vocab_size=128256, rope_base=500000.0, scaling_factor=8,
+                          high_freq_factor=4, low_freq_factor=1, original_max_position_embeddings=8192),
+    "llama-3.2-1b": dict(block_size=131072, n_layer=16, n_head=32, n_local_heads=8, dim=2048, intermediate_size=8192,
+                         vocab_size=128256, rope_base=500000.0, scaling_factor=32, high_freq_factor=4,
+                         low_freq_factor=1, original_max_position_embeddings=8192),
+    "Qwen2.5-7b": dict(block_size=131072, n_layer=28, n_head=28, n_local_heads=4, dim=3584, intermediate_size=18944,
+                       vocab_size=152064, rope_base=1000000.0, qkv_bias=True, norm_eps=1e-6),
+    "Qwen2.5-14b": dict(block_size=131072, n_layer=48, n_head=40, n_local_heads=8, dim=5120, intermediate_size=13824,
+                        vocab_size=152064, rope_base=1000000.0, qkv_bias=True, norm_eps=1e-6),
+    "Qwen2.5-32b": dict(block_size=131072, n_layer=64, n_head=40, n_local_heads=8, dim=5120, intermediate_size=27648,
+                        vocab_size=152064, rope_base=1000000.0, qkv_bias=True, norm_eps=1e-6),
+    "Yi-1.5-6b": dict(block_size=4096, n_layer=32, n_head=32, n_local_heads=4, dim=4096, intermediate_size=11008,
+                      vocab_size=64000, rope_base=500000.0),
+    "Yi-1.5-34b-32k": dict(block_size=32768, n_layer=60, n_head=56, n_local_heads=8, dim=7168,
+                           intermediate_size=20480, vocab_size=64000, rope_base=500000.0),
+    "Mistral-7B-v0.1": dict(n_layer=32, n_head=32, n_local_heads=8, dim=4096, intermediate_size=14336,
+                            vocab_size=32000),
+    "Mistral-7B-v0.3": dict(n_layer=32, n_head=32, n_local_heads=8, dim=4096, intermediate_size=14336,
+                            vocab_size=32768, rope_base=1000000.0),
+}
+
+SINK = 16          # StreamingLLM sink tokens (Engine/StreamingLLM/model_draft.py:124)
+POOL_KERNEL = 5    # SnapKV avg-pool width (Engine/SnapKV/model.py:169)
+
+
+class RMSNorm(nn.Module):
+    def __init__(self, dim: int, eps: float = 1e-5):
+        super().__init__()
+        self.eps = eps
+        self.weight = nn.Parameter(torch.ones(dim))
+
+    def forward(self, x):
+        return ops.rmsnorm(x, self.weight, self.eps)
+
+
+class KVCache(nn.Module):
+    """Paged caches of one layer: `kv_cache` [pages, 2, 128, KH, D] and, for speculation, `draft_cache`."""
+
+    def __init__(self, max_num_pages, page_size, n_heads, head_dim, dtype=torch.bfloat16, draft_max_num_pages=0,
+                 kv_len=0):
+        super().__init__()
+        if max_num_pages > 0:
+            self.register_buffer("kv_cache", torch.zeros((max_num_pages, 2, page_size, n_heads, head_dim), dtype=dtype),
+                                 persistent=False)
+        if draft_max_num_pages > 0:
+            self.register_buffer("draft_cache",
+                                 torch.zeros((draft_max_num_pages, 2, page_size, n_heads, head_dim), dtype=dtype),
+                                 persistent=False)
+        self.kv_len = kv_len
+        self.page_size = page_size
+
+
+class Attention(nn.Module):
+    def __init__(self, config: ModelArgs):
+        super().__init__()
+        assert config.dim % config.n_head == 0
+        total_head_dim = (config.n_head + 2 * config.n_local_heads) * config.head_dim
+        self.wqkv = nn.Linear(config.dim, total_head_dim, bias=config.qkv_bias)
+        self.wo = nn.Linear(config.dim, config.dim, bias=False)
+        self.kv_cache: Optional[KVCache] = None
+        self.process_group = None
+        self.n_head, self.head_dim = config.n_head, config.head_dim
+        self.n_local_heads, self.dim = config.n_local_heads, config.dim
+        self._register_load_state_dict_pre_hook(self.load_hook)
+
+    def load_hook(self, state_dict, prefix, *args):
+        """Accept un-fused wq/wk/wv checkpoints (Engine/SnapKV/model.py:309-320)."""
+        if prefix + "wq.weight" in state_dict:
+            state_dict[prefix + "wqkv.weight"] = torch.cat([state_dict.pop(prefix + "wq.weight"),
+                                                            state_dict.pop(prefix + "wk.weight"),
+                                                            state_dict.pop(prefix + "wv.weight")])
+        if prefix + "wq.bias" in state_dict:
+            state_dict[prefix + "wqkv.bias"] = torch.cat([state_dict.pop(prefix + "wq.bias"),
+                                                          state_dict.pop(prefix + "wk.bias"),
+                                                          state_dict.pop(prefix + "wv.bias")])
+
+
+class FeedForward(nn.Module):
+    def __init__(self, config: ModelArgs):
+        super().__init__()
+        self.w1 = nn.Linear(config.dim, config.intermediate_size, bias=False)
+        self.w3 = nn.Linear(config.dim, config.intermediate_size, bias=False)
+        self.w2 = nn.Linear(config.intermediate_size, config.dim, bias=False)
+        self.process_group = None
+
+
+class TransformerBlock(nn.Module):
+    def __init__(self, config: ModelArgs):
+        super().__init__()
+        self.attention = Attention(config)
+        self.feed_forward = FeedForward(config)
+        self.ffn_norm = RMSNorm(config.dim, config.norm_eps)
+        self.attention_norm = RMSNorm(config.dim, config.norm_eps)
+
+
+@dataclass
+class PageTable:
+    """(indices, indptr, last_page_len) of one paged cache + host-known bounds for the kernels."""
+    indices: torch.Tensor
+    indptr: torch.Tensor
+    last_page_len: torch.Tensor
+    max_pages: int  # host upper bound of pages per request
+
+
+class Transformer(nn.Module):
+    def __init__(self, config: ModelArgs):
+        super().__init__()
+        self.config = config
+        self.tok_embeddings = nn.Embedding(config.vocab_size, config.dim)
+        self.layers = nn.ModuleList(TransformerBlock(config) for _ in range(config.n_layer))
+        self.norm = RMSNorm(config.dim, eps=config.norm_eps)
+        self.output = nn.Linear(config.dim, config.vocab_size, bias=False)
+        self.world_size = None
+        self.rank = None
+        self.process_group = None
+        self._ready = False
+        self.skip_head = False
+
+    @classmethod
+    def from_name(cls, name: str):
+        return cls(ModelArgs.from_name(name))
+
+    # ------------------------------------------------------------------ setup
+    def setup_caches(self, num_pages, page_size=128, spec=False, draft_num_pages=0, draft_budget=0, window_size=32,
+                     max_positions=None, streaming=False):
+        """Allocates the per-layer KV slabs and the device-side constants of the step
+        (Engine/SnapKV/model.py:127-169 / StreamingLLM/model_draft.py:157-189 without the op registration)."""
+        c = self.config
+        dev = self.output.weight.device
+        dtype = self.output.weight.dtype if self.output.weight.dtype == torch.float16 else torch.bfloat16
+        if dtype != torch.bfloat16:
+            raise NotImplementedError("the gfx950 kernels are bf16")
+        head_dim = c.dim // c.n_head
+        self.page_size = page_size
+        self.spec, self.streaming = spec, streaming
+        self.draft_budget, self.window_size = draft_budget, window_size
+        for b in self.layers:
+            b.attention.kv_cache = KVCache(num_pages, page_size, c.n_local_heads, head_dim, dtype,
+                                           draft_num_pages if spec else 0, kv_len=draft_budget).to(dev)
+        if max_positions is None:
+            max_positions = max(num_pages, draft_num_pages, 1) * page_size + 256
+        llama31 = c.high_freq_factor is not None and c.low_freq_factor is not None
+        self.rope_table = ops.RopeTable(int(max_positions), head_dim, c.rope_base, c.scaling_factor,
+                                        c.low_freq_factor if llama31 else None, c.high_freq_factor if llama31 else None,
+                                        c.original_max_position_embeddings if llama31 else None, device=dev)
+        self.workspace = ops.AttnWorkspace(dev)
+        self._rot_scratch = None
+        self._fuse_weights()
+        self._ready = True
+
+    def _fuse_weights(self):
+        """w1|w3 -> one [2I, dim] GEMM operand; the original parameters become views of it (no extra HBM)."""
+        self._w13 = []
+        for b in self.layers:
+            ff = b.feed_forward
+            w13 = torch.cat([ff.w1.weight.data, ff.w3.weight.data], dim=0).contiguous()
+            inter = ff.w1.weight.shape[0]
+            ff.w1.weight = nn.Parameter(w13[:inter], requires_grad=False)
+            ff.w3.weight = nn.Parameter(w13[inter:], requires_grad=False)
+            self._w13.append(w13)
+
+    # ------------------------------------------------------------------ building blocks
+    def _reduce(self, y, group):
+        if group is not None:
+            dist.all_reduce(y, group=group)
+        return y
+
+    def _qkv(self, layer, y2d):
+        c = self.config
+        att = layer.attention
+        qkv = F.linear(y2d, att.wqkv.weight, att.wqkv.bias)          # [rows, (H+2KH)*D]
+        H, KH, D = c.n_head, c.n_local_heads, c.head_dim
+        rows = qkv.shape[0]
+        q = qkv[:, :H * D].unflatten(1, (H, D))
+        k = qkv[:, H * D:(H + KH) * D].unflatten(1, (KH, D))
+        v = qkv[:, (H + KH) * D:].unflatten(1, (KH, D))
+        return q, k, v, rows
+
+    def _mlp(self, i, layer, y2d):
+        inter = layer.feed_forward.w2.weight.shape[1]
+        h13 = F.linear(y2d, self._w13[i])
+        act = ops.silu_mul(h13[:, :inter], h13[:, inter:])
+        return self._reduce(F.linear(act, layer.feed_forward.w2.weight), layer.feed_forward.process_group)
+
+    def _run(self, idx, attn_fn):
+        """embed -> L x (norm, attention, +res, norm, mlp, +res) -> norm -> head -> argmax.
+        attn_fn(i, layer, q, k, v, n) -> attention output [rows, H, D].
+        With self.skip_head set (non-final prefill chunks, whose tokens the reference computes and discards,
+        Engine/SnapKV/backend.py:239-263) the lm head is skipped and None is returned."""
+        assert self._ready, "call setup_caches first"
+        B, n = idx.shape
+        x = self.tok_embeddings(idx).view(B * n, -1)
+        layers = self.layers
+        y = ops.rmsnorm(x, layers[0].attention_norm.weight, layers[0].attention_norm.eps)
+        for i, layer in enumerate(layers):
+            q, k, v, rows = self._qkv(layer, y)
+            o = attn_fn(i, layer, q, k, v, n)
+            a = self._reduce(F.linear(o.view(rows, -1), layer.attention.wo.weight), layer.attention.process_group)
+            x, y = ops.add_rmsnorm(x, a, layer.ffn_norm.weight, layer.ffn_norm.eps)
+            f = self._mlp(i, layer, y)
+            nxt = layers[i + 1].attention_norm if i + 1 < len(layers) else self.norm
+            x, y = ops.add_rmsnorm(x, f, nxt.weight, nxt.eps)
+        if self.skip_head:
+            return None
+        logits = F.linear(y, self.output.weight)                      # [rows, vocab / tp]
+        self._last_logits = logits
+        return self._argmax(logits).view(B, n)
+
+    def _argmax(self, logits):
+        """argmax, or the TP merge of per-rank maxima (Engine/SnapKV/model.py:178-188): two sum-all-reduces of
+        one-hot-slot tensors, then the lowest rank among equal maxima."""
+        if self.process_group is None:
+            return ops.argmax(logits)
+        rows = logits.shape[0]
+        vals, idx = ops.argmax(logits, index_offset=self.rank * logits.shape[1], return_values=True)
+        all_v = torch.zeros((rows, self.world_size), dtype=logits.dtype, device=logits.device)
+        all_i = torch.zeros((rows, self.world_size), dtype=torch.long, device=logits.device)
+        all_v[:, self.rank] = vals
+        all_i[:, self.rank] = idx
+        dist.all_reduce(all_v, group=self.process_group)
+        dist.all_reduce(all_i, group=self.process_group)
+        return ops.tp_argmax_merge(all_v, all_i)
+
+    def _attend(self, q_rot, cache, qo_indptr, tab: PageTable, n):
+        return ops.paged_attention(q_rot, cache, qo_indptr, tab.indices, tab.indptr, tab.last_page_len, n,
+                                   tab.max_pages, self.workspace, causal=True)
+
+    # ------------------------------------------------------------------ step variants
+    def _std_step(self, idx, offsets, qo_indptr, tab: PageTable, which="kv_cache", tab2: PageTable = None,
+                  snap_tab: PageTable = None):
+        """rope(offsets) -> append (-> 2nd cache) -> attention (-> SnapKV select): Attention.forward / verify /
+        draft_forward / prefill of Engine/SnapKV/model.py:322-387."""
+        c = self.config
+
+        def fn(i, layer, q, k, v, n):
+            kvc = layer.attention.kv_cache
+            cache = getattr(kvc, which)
+            cache2 = kvc.draft_cache if tab2 is not None else None
+            q_rot = ops.rope_append(q, k, v, qo_indptr, offsets, self.rope_table, cache, tab.indices, tab.indptr,
+                                    tab.last_page_len, cache2, tab2.indices if tab2 else None,
+                                    tab2.indptr if tab2 else None, tab2.last_page_len if tab2 else None, n_max=n)
+            o = self._attend(q_rot, cache, qo_indptr, tab, n)
+            if snap_tab is not None:
+                ops.snapkv_select(q_rot, cache, tab.indices, tab.indptr, self._snap_ctx_len, self.window_size,
+                                  self.draft_budget, POOL_KERNEL, kvc.draft_cache, snap_tab.indices, snap_tab.indptr,
+                                  snap_tab.last_page_len, self.workspace)
+            return o
+        return self._run(idx, fn)
+
+    def forward(self, idx, input_pos, kv_append_indptr, tab: PageTable):
+        return self._std_step(idx, input_pos, kv_append_indptr, tab)
+
+    def verify(self, idx, input_pos, kv_append_indptr, tab: PageTable, draft_tab: PageTable = None):
+        """Self-spec SnapKV verify also appends the gamma+1 rows to the draft cache (model.py:338-353)."""
+        return self._std_step(idx, input_pos, kv_append_indptr, tab, tab2=draft_tab)
+
+    def draft_forward(self, idx, input_pos, kv_append_indptr, draft_tab: PageTable):
+        return self._std_step(idx, input_pos, kv_append_indptr, draft_tab, which="draft_cache")
+
+    def prefill(self, idx, input_pos, kv_append_indptr, tab: PageTable, is_last=False, draft_tab: PageTable = None,
+                ctx_len=None):
+        """Chunked prefill; on the last chunk of a SnapKV engine also runs the select (model.py:371-387).
+        ctx_len = offsets[0]+seqlen is passed by the back-end (host-known, no device read)."""
+        snap = draft_tab if (is_last and self.spec and not self.streaming and draft_tab is not None) else None
+        self._snap_ctx_len = ctx_len
+        return self._std_step(idx, input_pos, kv_append_indptr, tab, snap_tab=snap)
+
+    def stream_prefill(self, idx, ctx, kv_append_indptr, tab: PageTable, is_last, which, B):
+        """StreamingLLM draft prefill of one chunk (Attention.prefill + KVCache.prefill,
+        Engine/StreamingLLM/model_draft.py:102-143,309-326; draft_prefill / prefill_draft of StreamingLLM/model.py).
+        ctx = tokens already in the (capped) cache, host int."""
+        kv_len = self.draft_budget
+        dev = idx.device
+
+        def fn(i, layer, q, k, v, n):
+            cache = getattr(layer.attention.kv_cache, which)
+            ppr = cache.shape[0] // B
+            overflow = ctx + n > kv_len
+            off = torch.full((B,), (kv_len - n) if overflow else ctx, dtype=torch.int32, device=dev)
+            q_rot, _ = ops.rope(q, None, kv_append_indptr, off, self.rope_table, n_max=n)
+            if not overflow:
+                ops.update_kv(k, v, kv_append_indptr, cache, tab.indices, tab.indptr, tab.last_page_len, n_max=n)
+                valid = ctx + n
+            else:
+                ops.streaming_shift_append(k, v, cache, n, kv_len, SINK, ppr)
+                valid = kv_len
+            if overflow and is_last:
+                rot = cache                           # persistent cache becomes rotated (model_draft.py:141-142)
+            else:
+                if self._rot_scratch is None or self._rot_scratch.shape != cache.shape:
+                    self._rot_scratch = torch.empty_like(cache)
+                rot = self._rot_scratch
+            ops.streaming_rotate(cache, rot, B, valid, ppr, self.rope_table)
+            return self._attend(q_rot, rot, kv_append_indptr, tab, n)
+        return self._run(idx, fn)

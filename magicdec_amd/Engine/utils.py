@@ -1,0 +1,79 @@
+"""Loaders and seeding of the decode path (Engine/utils.py:189-277 of the reference, same names).
+
+`model.pth` files written by the reference's convert_hf_checkpoint.py load unchanged (same parameter names,
+fused wqkv = [q;k;v], interleaved-RoPE row order).  When the checkpoint file does not exist the model is
+initialised with seeded normal(0, 0.02) bf16 weights of the architecture named by the checkpoint's parent
+directory -- benchmarks on a box without network access use this (throughput is weight-value independent).
+"""
+import random
+from pathlib import Path
+
+import numpy as np
+import torch
+
+
+def setup_seed(seed):
+    torch.manual_seed(seed)
+    if torch.cuda.is_available():
+        torch.cuda.manual_seed_all(seed)
+    np.random.seed(seed)
+    random.seed(seed)
+
+
+def _random_init_(model, seed, device, dtype, std=0.02):
+    """Deterministic per-parameter init (each tensor from its own generator stream: identical on every rank)."""
+    for j, (name, p) in enumerate(sorted(model.named_parameters())):
+        g = torch.Generator(device="cpu").manual_seed(seed * 100003 + j)
+        if p.dim() == 1 and "norm" in name:
+            t = torch.ones(p.shape, dtype=dtype)
+        elif p.numel() > (1 << 24) and torch.device(device).type == "cuda":
+            gg = torch.Generator(device=device).manual_seed(seed * 100003 + j)
+            t = (torch.randn(p.shape, generator=gg, device=device, dtype=torch.float32) * std).to(dtype)
+        else:
+            t = (torch.randn(p.shape, generator=g) * std).to(dtype)
+        parent, leaf = model, name.split(".")
+        for part in leaf[:-1]:
+            parent = getattr(parent, part)
+        setattr(parent, leaf[-1], torch.nn.Parameter(t, requires_grad=False))
+
+
+def _load(transformer_cls, checkpoint_path, device, precision, use_tp, rank_group, group, seed=1234):
+    checkpoint_path = Path(checkpoint_path)
+    with torch.device("meta"):
+        model = transformer_cls.from_name(checkpoint_path.parent.name)
+    if "int8" in str(checkpoint_path):
+        raise NotImplementedError("weight-only int8 checkpoints are outside the hot path (SURVEY.md section 2, #9)")
+    if checkpoint_path.exists():
+        checkpoint = torch.load(str(checkpoint_path), mmap=True, weights_only=True)
+        if "model" in checkpoint and "stories" in str(checkpoint_path):
+            checkpoint = checkpoint["model"]
+        model.load_state_dict(checkpoint, assign=True)
+    else:
+        print(f"[magicdec_amd] {checkpoint_path} not found: seeded random weights for '{checkpoint_path.parent.name}'")
+        _random_init_(model, seed, device, precision)
+    if use_tp:
+        from .tp import apply_tp
+        print("Applying tensor parallel to model ...")
+        apply_tp(model, rank_group, group=group)
+    model = model.to(device=device, dtype=precision)
+    return model.eval()
+
+
+def load_model_snapKV(checkpoint_path, device, precision, use_tp, rank_group=None, group=None):
+    from .SnapKV.model import Transformer
+    return _load(Transformer, checkpoint_path, device, precision, use_tp, rank_group, group)
+
+
+def load_model_draft_snapKV(checkpoint_path, device, precision, use_tp, rank_group=None, group=None):
+    from .SnapKV.model_draft import Transformer
+    return _load(Transformer, checkpoint_path, device, precision, use_tp, rank_group, group)
+
+
+def load_model_streamingLLM(checkpoint_path, device, precision, use_tp, rank_group=None, group=None):
+    from .StreamingLLM.model import Transformer
+    return _load(Transformer, checkpoint_path, device, precision, use_tp, rank_group, group)
+
+
+def load_model_draft_streamingLLM(checkpoint_path, device, precision, use_tp, rank_group=None, group=None):
+    from .StreamingLLM.model_draft import Transformer
+    return _load(Transformer, checkpoint_path, device, precision, use_tp, rank_group, group)

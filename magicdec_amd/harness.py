@@ -1,0 +1,181 @@
+"""The speculative draft/verify decode loops (L5 of SURVEY.md section 1) on the GPU.
+
+These are the loop bodies of the reference's benchmark scripts
+(tests/SnapKV/longspec_benchmark.py:131-295 and its StreamingLLM twin,
+tests/*/selfspec_benchmark.py, tests/baseline_benchmark.py:72-90) with the ~15
+per-iteration ATen launches and 4 host syncs of the verify loop replaced by ONE
+integer kernel (ops.accept_rollback) and ONE 8-byte flag read per iteration.
+The Engine attributes are updated in place exactly as the reference harness
+updates them, including its quirks (e.g. the SnapKV longspec harness rolls back
+`draft.paged_kv_last_page_len`, which the compressed draft does not use).
+
+Used by the CLI scripts under tests/, by bench.py and by the parity tests.
+"""
+from __future__ import annotations
+
+import time
+from dataclasses import dataclass, field
+
+import torch
+
+from . import ops
+
+
+@dataclass
+class LoopState:
+    """Per-batch device state of the spec-decode loop."""
+    tokens_buffer: torch.Tensor
+    output: torch.Tensor
+    num_nodes: torch.Tensor
+    accept_nums: torch.Tensor
+    bonus: torch.Tensor
+    double_buffer: torch.Tensor
+    cachelens_update: torch.Tensor
+    flags: torch.Tensor
+    flags_host: torch.Tensor
+    iters: int = 0
+    accept_trace: list = field(default_factory=list)
+
+
+def new_state(B, gamma, out_cols, device, input_ids=None):
+    st = LoopState(tokens_buffer=torch.zeros((B, gamma + 1), dtype=torch.long, device=device),
+                   output=torch.zeros((B, out_cols), dtype=torch.long, device=device),
+                   num_nodes=torch.zeros(B, dtype=torch.long, device=device),
+                   accept_nums=torch.zeros(B, dtype=torch.long, device=device),
+                   bonus=torch.zeros(B, dtype=torch.long, device=device),
+                   double_buffer=torch.zeros((B, 2), dtype=torch.long, device=device),
+                   cachelens_update=torch.ones(B, dtype=torch.long, device=device),
+                   flags=torch.zeros(2, dtype=torch.int32, device=device),
+                   flags_host=torch.zeros(2, dtype=torch.int32).pin_memory())
+    if input_ids is not None:
+        st.output[:, :input_ids.shape[1]] = input_ids
+        st.num_nodes += input_ids.shape[1]
+    return st
+
+
+def _read_flags(st: LoopState):
+    st.flags_host.copy_(st.flags, non_blocking=True)
+    torch.cuda.current_stream().synchronize()
+    return bool(st.flags_host[0]), bool(st.flags_host[1])
+
+
+def _draft_round(step_fn, st: LoopState, gamma, next_double):
+    """gamma draft steps; after an all-accept iteration the first step consumes two tokens
+    (tests/SnapKV/longspec_benchmark.py:165-188)."""
+    for i in range(gamma):
+        if i == 0 and next_double:
+            nt = step_fn(st.double_buffer, st.cachelens_update)
+            st.tokens_buffer[:, 1:2] = nt.gather(1, st.cachelens_update.view(-1, 1) - 1)
+        else:
+            st.tokens_buffer[:, i + 1:i + 2] = step_fn(st.tokens_buffer[:, i].view(-1, 1), None)
+
+
+def longspec_iteration(engine, draft, st: LoopState, gamma, eot_1, eot_2, max_nodes, next_double,
+                       forced_accept=None):
+    """One iteration of the longspec loop: gamma draft steps, one verify, the fused accept/rollback.
+    Returns (terminal, next_double)."""
+    _draft_round(lambda ids, cu: draft.inference(ids, cachelen_update=cu), st, gamma, next_double)
+    target_tokens = engine.inference(st.tokens_buffer)
+    if forced_accept is not None:
+        target_tokens = _force_accept(st.tokens_buffer, target_tokens, forced_accept, gamma)
+    ops.accept_rollback(st.tokens_buffer, target_tokens, st.output, st.num_nodes, engine.cachelens,
+                        engine.paged_kv_last_page_len, draft.cachelens, draft.paged_kv_last_page_len, gamma,
+                        gamma, gamma, eot_1, eot_2, max_nodes, st.accept_nums, st.bonus, st.double_buffer,
+                        st.cachelens_update, st.flags)
+    st.iters += 1
+    return _read_flags(st)
+
+
+def selfspec_iteration(engine, st: LoopState, gamma, eot_1, eot_2, max_nodes, next_double, streaming,
+                       forced_accept=None):
+    """One iteration of tests/SnapKV/selfspec_benchmark.py:121-211 (streaming=False: draft rolled back by
+    gamma+1 and advanced by accept_nums, no two-token step) or tests/StreamingLLM/selfspec_benchmark.py:121-238."""
+    if streaming:
+        _draft_round(lambda ids, cu: engine.speculate(ids, cachelen_update=cu), st, gamma, next_double)
+    else:
+        _draft_round(lambda ids, cu: engine.speculate(ids), st, gamma, False)
+    target_tokens = engine.verify(st.tokens_buffer)
+    if forced_accept is not None:
+        target_tokens = _force_accept(st.tokens_buffer, target_tokens, forced_accept, gamma)
+    if streaming:
+        ops.accept_rollback(st.tokens_buffer, target_tokens, st.output, st.num_nodes, engine.cachelens,
+                            engine.paged_kv_last_page_len, engine.draft_cachelens,
+                            engine.draft_paged_kv_last_page_len, gamma, gamma, gamma, eot_1, eot_2, max_nodes,
+                            st.accept_nums, st.bonus, st.double_buffer, st.cachelens_update, st.flags)
+    else:
+        ops.accept_rollback(st.tokens_buffer, target_tokens, st.output, st.num_nodes, engine.cachelens,
+                            engine.paged_kv_last_page_len, engine.draft_cachelens,
+                            engine.draft_paged_kv_last_page_len, gamma, gamma + 1, gamma + 1, eot_1, eot_2, max_nodes,
+                            st.accept_nums, st.bonus, None, None, st.flags)
+    st.iters += 1
+    return _read_flags(st)
+
+
+def _force_accept(tokens_buffer, target_tokens, forced_accept, gamma):
+    """Fixed-acceptance replay: with random-init weights the measured acceptance is
+    meaningless, so benchmarks may replace the target's tokens by ones that accept exactly
+    forced_accept[b]-1 draft tokens of row b (all the draft/verify/accept work still runs)."""
+    tt = target_tokens.clone()
+    j = torch.arange(gamma, device=tt.device).view(1, -1)
+    keep = j < (forced_accept.view(-1, 1) - 1)
+    draft = tokens_buffer[:, 1:gamma + 1]
+    tt[:, :gamma] = torch.where(keep, draft, draft + 1)
+    return tt
+
+
+def run_longspec_batch(engine, draft, input_ids, gamma, max_len, eot_1, eot_2, forced_accept_fn=None,
+                       trace_fn=None):
+    """A whole batch: prefill both models, loop until termination.  Returns (state, seconds in the loop)."""
+    B, S = input_ids.shape
+    st = new_state(B, gamma, max_len + 1, input_ids.device, input_ids)
+    st.tokens_buffer[:, :1] = engine.encode(input_ids=input_ids)[:, -1:]
+    draft.encode(input_ids=input_ids)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    terminal, nd = False, False
+    while not terminal:
+        fa = forced_accept_fn(st) if forced_accept_fn is not None else None
+        terminal, nd = longspec_iteration(engine, draft, st, gamma, eot_1, eot_2, S + 80, nd, fa)
+        if trace_fn is not None:
+            trace_fn(st)
+    torch.cuda.synchronize()
+    return st, time.perf_counter() - t0
+
+
+def run_selfspec_batch(engine, input_ids, gamma, max_len, eot_1, eot_2, streaming, forced_accept_fn=None,
+                       trace_fn=None):
+    B, S = input_ids.shape
+    st = new_state(B, gamma, max_len + 1, input_ids.device, input_ids)
+    st.tokens_buffer[:, :1] = engine.encode(input_ids=input_ids)[:, -1:]
+    if streaming:
+        engine.draft_encode(input_ids=input_ids)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    terminal, nd = False, False
+    while not terminal:
+        fa = forced_accept_fn(st) if forced_accept_fn is not None else None
+        terminal, nd = selfspec_iteration(engine, st, gamma, eot_1, eot_2, S + 80, nd, streaming, fa)
+        if trace_fn is not None:
+            trace_fn(st)
+    torch.cuda.synchronize()
+    return st, time.perf_counter() - t0
+
+
+def run_baseline_batch(engine, input_ids, max_len, eot_1, eot_2, check_eot_every=1):
+    """tests/baseline_benchmark.py:72-90: greedy autoregressive decode until max_len or EOT."""
+    output = input_ids.clone()
+    next_tokens = engine.encode(input_ids=input_ids)[:, -1:]
+    output = torch.cat((output, next_tokens), dim=-1)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    steps = 0
+    terminate = False
+    while output.size(1) < max_len and not terminate:
+        next_tokens = engine.inference(input_ids=next_tokens.clone())
+        output = torch.cat((output, next_tokens), dim=-1)
+        steps += 1
+        if steps % check_eot_every == 0:
+            last = next_tokens[:, -1]
+            terminate = bool(((last == eot_1) | (last == eot_2)).any())
+    torch.cuda.synchronize()
+    return output, steps, time.perf_counter() - t0

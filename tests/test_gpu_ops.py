@@ -1,0 +1,372 @@
+"""GPU parity tests of every C-ABI entry point against the oracle / golden vectors (run with -m gpu).
+
+Bars (stated per test): bit-exact for integer / byte / index work (KV append, RoPE, StreamingLLM eviction,
+accept loop, argmax, top-k given equal scores); bf16-rounding-level tolerance for floating-point kernels
+(attention, norms, SiLU)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import flashinfer_ref as fr
+from oracle import magicdec_ref as mr
+from tests import golden_cfg as gc
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+BF = torch.bfloat16
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from magicdec_amd import ops as _ops
+    _ops._lib.load()      # fail loudly if the HIP library is missing
+    return _ops
+
+
+def bits(t):
+    return t.contiguous().view(torch.int16)
+
+
+def make_paged(B, lens, KH, D, seed, page_size=128, scatter=False, extra_pages=2):
+    g = torch.Generator().manual_seed(seed)
+    max_pages = max(1, max((l + page_size - 1) // page_size for l in lens))
+    tot = B * max_pages + extra_pages
+    cache = torch.randn(tot, 2, page_size, KH, D, generator=g).to(BF)
+    perm = torch.randperm(tot, generator=g) if scatter else torch.arange(tot)
+    indices, indptr, last = [], [0], []
+    for b in range(B):
+        npg = (lens[b] + page_size - 1) // page_size
+        indices += [int(perm[b * max_pages + i]) for i in range(npg)]
+        indptr.append(indptr[-1] + npg)
+        last.append(lens[b] - (npg - 1) * page_size if npg else 0)
+    return (cache, torch.tensor(indices + [0], dtype=torch.int32), torch.tensor(indptr, dtype=torch.int32),
+            torch.tensor(last, dtype=torch.int32), max_pages)
+
+
+# ----------------------------------------------------------------------------------------- attention
+ATTN_CASES = [
+    ("verify-8b-shape", 2, 4, 8, 2, 128, [300, 257], True, False),
+    ("verify-tile-edge-32", 1, 4, 4, 1, 128, [32], True, False),
+    ("verify-tile-edge-33", 1, 4, 4, 1, 128, [33], True, False),
+    ("verify-short", 1, 4, 4, 1, 128, [20], True, False),
+    ("verify-ragged-scattered-pages", 3, 4, 32, 8, 128, [1000, 129, 640], True, True),
+    ("verify-split-kv", 2, 4, 8, 2, 128, [8069, 7000], True, False),
+    ("draft-1row-d64", 4, 1, 32, 8, 64, [260, 258, 300, 257], True, False),
+    ("draft-2row-d64", 4, 2, 8, 2, 64, [260, 258, 300, 257], True, False),
+    ("g8-two-mtiles", 2, 4, 16, 2, 128, [500, 300], True, False),
+    ("g5-padded-mtile", 2, 4, 10, 2, 128, [500, 300], True, False),
+    ("mha-g1", 2, 1, 12, 12, 64, [129, 200], True, False),
+    ("prefill-chunk-128", 2, 128, 8, 2, 128, [384, 384], True, False),
+    ("prefill-last-chunk-32", 2, 32, 8, 2, 128, [160, 160], True, False),
+    ("prefill-d64", 2, 128, 8, 2, 64, [256, 256], True, False),
+    ("non-causal", 2, 4, 8, 2, 128, [300, 257], False, False),
+    ("empty-request", 2, 4, 8, 2, 128, [0, 200], True, False),
+]
+
+
+@pytest.mark.parametrize("name,B,n,H,KH,D,lens,causal,scatter", ATTN_CASES, ids=[c[0] for c in ATTN_CASES])
+def test_paged_attention_vs_oracle(ops, name, B, n, H, KH, D, lens, causal, scatter):
+    """fp32-softmax attention, bf16 in/out: |err| <= 2e-2 * max(1, |ref|max)  (bf16 P and output rounding;
+    flashinfer itself is unpinned, see oracle/flashinfer_ref.py)."""
+    cache, indices, indptr, last, max_pages = make_paged(B, lens, KH, D, seed=hash(name) % 1000, scatter=scatter)
+    g = torch.Generator().manual_seed(1)
+    q = torch.randn(B * n, H, D, generator=g).to(BF)
+    qo = torch.arange(B + 1, dtype=torch.int32) * n
+    ref = fr.batch_prefill_paged(q, cache, qo, indices, indptr, last, H, KH, D, causal=causal).float()
+    ws = ops.AttnWorkspace(DEV)
+    out = ops.paged_attention(q.to(DEV), cache.to(DEV), qo.to(DEV), indices.to(DEV), indptr.to(DEV), last.to(DEV), n,
+                              max_pages, ws, causal=causal)
+    o = out.float().cpu()
+    assert not torch.isnan(o).any()
+    tol = 2e-2 * max(1.0, ref.abs().max().item())
+    assert (o - ref).abs().max().item() <= tol
+
+
+def test_paged_attention_ignores_garbage_beyond_length(ops):
+    """Rows past a request's length may hold NaN/Inf (stale pages): they must not leak into the output."""
+    B, n, H, KH, D = 2, 4, 8, 2, 128
+    cache, indices, indptr, last, max_pages = make_paged(B, [200, 130], KH, D, seed=3)
+    dirty = cache.clone()
+    for b, ln in enumerate([200, 130]):
+        pg = int(indices[int(indptr[b]) + ln // 128])
+        dirty[pg, :, ln % 128:] = float("nan")
+    q = torch.randn(B * n, H, D).to(BF)
+    qo = torch.arange(B + 1, dtype=torch.int32) * n
+    ws = ops.AttnWorkspace(DEV)
+    a = ops.paged_attention(q.to(DEV), cache.to(DEV), qo.to(DEV), indices.to(DEV), indptr.to(DEV), last.to(DEV), n,
+                            max_pages, ws)
+    b_ = ops.paged_attention(q.to(DEV), dirty.to(DEV), qo.to(DEV), indices.to(DEV), indptr.to(DEV), last.to(DEV), n,
+                             max_pages, ws)
+    assert torch.equal(bits(a.cpu()), bits(b_.cpu()))
+
+
+def test_verify_attention_full_size_properties(ops):
+    """BASELINE size (one layer of Llama-3.1-8B, B=64, S=16K): size-independent properties --
+    (1) softmax weights sum to one: with V == 1 everywhere the output is exactly 1;
+    (2) linearity in V: attn(V1+V2) == attn(V1)+attn(V2) up to bf16 rounding;
+    (3) split-KV invariance: the same rows computed with a short page table prefix match the oracle."""
+    B, n, H, KH, D, S = 64, 4, 32, 8, 128, 16032 + 4
+    mp = (S + 127) // 128
+    g = torch.Generator(device=DEV).manual_seed(0)
+    cache = torch.randn(B * mp, 2, 128, KH, D, device=DEV, generator=g, dtype=torch.float32).to(BF)
+    q = torch.randn(B * n, H, D, device=DEV, generator=g, dtype=torch.float32).to(BF)
+    indices = torch.arange(B * mp, dtype=torch.int32, device=DEV)
+    indptr = torch.arange(B + 1, dtype=torch.int32, device=DEV) * mp
+    last = torch.full((B,), S - (mp - 1) * 128, dtype=torch.int32, device=DEV)
+    qo = torch.arange(B + 1, dtype=torch.int32, device=DEV) * n
+    ws = ops.AttnWorkspace(DEV)
+    ones = cache.clone()
+    ones[:, 1] = 1.0
+    o1 = ops.paged_attention(q, ones, qo, indices, indptr, last, n, mp, ws)
+    assert (o1.float() - 1.0).abs().max().item() <= 1e-2
+    v2 = cache.clone()
+    v2[:, 1] = (cache[:, 1].float() * 0.5).to(BF)
+    oa = ops.paged_attention(q, cache, qo, indices, indptr, last, n, mp, ws).float()
+    ob = ops.paged_attention(q, v2, qo, indices, indptr, last, n, mp, ws).float()
+    assert (oa * 0.5 - ob).abs().max().item() <= 4e-3 * max(1.0, oa.abs().max().item())
+    # request 5 alone against the CPU oracle
+    b = 5
+    sub = cache[b * mp:(b + 1) * mp].cpu()
+    ref = fr.batch_prefill_paged(q[b * n:(b + 1) * n].cpu(), sub, torch.tensor([0, n], dtype=torch.int32),
+                                 torch.arange(mp, dtype=torch.int32), torch.tensor([0, mp], dtype=torch.int32),
+                                 last[b:b + 1].cpu(), H, KH, D).float()
+    assert (oa[b * n:(b + 1) * n].cpu() - ref).abs().max().item() <= 2e-2 * max(1.0, ref.abs().max().item())
+
+
+# ----------------------------------------------------------------------------------------- rope / append
+@pytest.mark.parametrize("llama31", [False, True])
+def test_rope_bit_exact(ops, llama31):
+    B, n, H, KH, D = 3, 4, 8, 2, 128
+    kw = dict(low_freq_factor=1.0, high_freq_factor=4.0, old_context_len=8192) if llama31 else {}
+    tab_ref = fr.rope_table(4096, D, 500000.0, 8.0, **kw)
+    tab = ops.RopeTable(4096, D, 500000.0, 8.0, kw.get("low_freq_factor"), kw.get("high_freq_factor"),
+                        kw.get("old_context_len"), device=DEV)
+    assert torch.equal(tab.table.cpu(), tab_ref), "host table must equal the oracle's float64->float32 table"
+    g = torch.Generator().manual_seed(2)
+    qkv = torch.randn(B * n, (H + 2 * KH) * D, generator=g).to(BF)       # strided views like the wqkv output
+    q = qkv[:, :H * D].unflatten(1, (H, D))
+    k = qkv[:, H * D:(H + KH) * D].unflatten(1, (KH, D))
+    indptr = torch.arange(B + 1, dtype=torch.int32) * n
+    offsets = torch.tensor([0, 1000, 4000], dtype=torch.int32)
+    rq, rk = fr.apply_rope(q, k, indptr, offsets, tab_ref)
+    dqkv = qkv.to(DEV)
+    dq = dqkv[:, :H * D].unflatten(1, (H, D))
+    dk = dqkv[:, H * D:(H + KH) * D].unflatten(1, (KH, D))
+    oq, ok = ops.rope(dq, dk, indptr.to(DEV), offsets.to(DEV), tab)
+    assert torch.equal(bits(oq.cpu()), bits(rq)) and torch.equal(bits(ok.cpu()), bits(rk))
+
+
+def test_append_and_fused_rope_append_bit_exact(ops):
+    B, n, H, KH, D = 3, 4, 8, 2, 64
+    lens = [200, 131, 4]        # lengths AFTER the append (page table already includes the new rows)
+    cache, indices, indptr, last, _ = make_paged(B, lens, KH, D, seed=9, scatter=True)
+    tab_ref = fr.rope_table(2048, D, 10000.0, 1.0)
+    tab = ops.RopeTable(2048, D, 10000.0, 1.0, device=DEV)
+    g = torch.Generator().manual_seed(4)
+    qkv = torch.randn(B * n, (H + 2 * KH) * D, generator=g).to(BF)
+    q = qkv[:, :H * D].unflatten(1, (H, D))
+    k = qkv[:, H * D:(H + KH) * D].unflatten(1, (KH, D))
+    v = qkv[:, (H + KH) * D:].unflatten(1, (KH, D))
+    ip = torch.arange(B + 1, dtype=torch.int32) * n
+    offsets = torch.tensor([l - n for l in lens], dtype=torch.int32)
+    # oracle: rope then append
+    rq, rk = fr.apply_rope(q, k, ip, offsets, tab_ref)
+    ref_cache = cache.clone()
+    fr.append_paged_kv_cache(rk, v, ip, ref_cache, indices, indptr, last)
+    d = lambda t: t.to(DEV)
+    dqkv = d(qkv)
+    dq = dqkv[:, :H * D].unflatten(1, (H, D))
+    dk = dqkv[:, H * D:(H + KH) * D].unflatten(1, (KH, D))
+    dv = dqkv[:, (H + KH) * D:].unflatten(1, (KH, D))
+    # (a) separate ops
+    c1 = d(cache)
+    oq, ok = ops.rope(dq, dk, d(ip), d(offsets), tab)
+    ops.update_kv(ok, dv, d(ip), c1, d(indices), d(indptr), d(last))
+    assert torch.equal(bits(c1.cpu()), bits(ref_cache))
+    # (b) fused, writing two caches
+    c2, c3 = d(cache), d(cache)
+    oq2 = ops.rope_append(dq, dk, dv, d(ip), d(offsets), tab, c2, d(indices), d(indptr), d(last), c3, d(indices),
+                          d(indptr), d(last))
+    assert torch.equal(bits(oq2.cpu()), bits(rq))
+    assert torch.equal(bits(c2.cpu()), bits(ref_cache)) and torch.equal(bits(c3.cpu()), bits(ref_cache))
+
+
+# ----------------------------------------------------------------------------------------- small fused ops
+def _ulp_close(a, b, ulps=1):
+    """bf16 tensors equal up to `ulps` units in the last place."""
+    ia, ib = bits(a).int(), bits(b).int()
+    # map sign-magnitude to a monotonic integer line
+    ia = torch.where(ia < 0, -(ia & 0x7fff), ia)
+    ib = torch.where(ib < 0, -(ib & 0x7fff), ib)
+    return (ia - ib).abs().max().item() <= ulps
+
+
+@pytest.mark.parametrize("dim", [512, 2048, 4096, 8192])
+def test_rmsnorm_and_add_rmsnorm(ops, dim):
+    """<= 1 bf16 ulp vs the oracle (fp32 reduction order differs); the residual sum h is bit-exact."""
+    g = torch.Generator().manual_seed(dim)
+    x = torch.randn(37, dim, generator=g).to(BF)
+    r = torch.randn(37, dim, generator=g).to(BF)
+    w = (1 + 0.1 * torch.randn(dim, generator=g)).to(BF)
+    ref = mr.rmsnorm(x, w, 1e-5)
+    y = ops.rmsnorm(x.to(DEV), w.to(DEV), 1e-5).cpu()
+    assert _ulp_close(y, ref)
+    h_ref = x + r
+    h, y2 = ops.add_rmsnorm(x.to(DEV), r.to(DEV), w.to(DEV), 1e-5)
+    assert torch.equal(bits(h.cpu()), bits(h_ref))
+    assert _ulp_close(y2.cpu(), mr.rmsnorm(h_ref, w, 1e-5))
+
+
+def test_silu_mul(ops):
+    g = torch.Generator().manual_seed(5)
+    ab = (torch.randn(33, 2 * 1024, generator=g) * 3).to(BF)
+    a, b = ab[:, :1024], ab[:, 1024:]
+    ref = torch.nn.functional.silu(a) * b
+    dab = ab.to(DEV)
+    y = ops.silu_mul(dab[:, :1024], dab[:, 1024:]).cpu()
+    assert _ulp_close(y, ref)
+
+
+def test_argmax_lowest_index_and_tp_merge(ops):
+    g = torch.Generator().manual_seed(6)
+    logits = torch.randn(9, 16032, generator=g).to(BF)
+    logits[3, 100] = logits[3].max()
+    logits[3, 7000] = logits[3, 100]                   # exact tie -> lowest index
+    logits[5] = 0                                      # all equal -> index 0
+    ref = torch.tensor([int(torch.nonzero(row == row.max())[0]) for row in logits.float()])
+    vals, idx = ops.argmax(logits.to(DEV), index_offset=16032 * 2, return_values=True)
+    assert torch.equal(idx.cpu(), ref + 16032 * 2)
+    assert torch.equal(bits(vals.cpu()), bits(logits.float().max(dim=-1).values.to(BF)))
+    tpv = torch.randn(9, 8, generator=g).to(BF)
+    tpv[2, 1] = tpv[2].max()
+    tpv[2, 6] = tpv[2, 1]
+    tpi = torch.randint(0, 100000, (9, 8), generator=g)
+    out = ops.tp_argmax_merge(tpv.to(DEV), tpi.to(DEV)).cpu()
+    assert torch.equal(out, mr.tp_argmax_merge(tpv, tpi))
+
+
+# ----------------------------------------------------------------------------------------- accept loop
+VARIANTS = {"longspec": (lambda g: g, lambda g: g, True, "draft_"),
+            "selfspec_snapkv": (lambda g: g + 1, lambda g: g + 1, False, "engine_draft_"),
+            "selfspec_stream": (lambda g: g, lambda g: g, True, "engine_draft_")}
+
+
+@pytest.mark.parametrize("variant", list(VARIANTS))
+def test_accept_rollback_kernel_matches_reference_loop_body(ops, variant):
+    """Bit-exact against vectors produced by exec'ing the reference's own loop body (gen_golden.py:accept_loop)."""
+    dr, cap, dbl, pre = VARIANTS[variant]
+    for c in gc.load_json("accept_loop.json")[variant]:
+        i, o = c["inp"], c["out"]
+        G, B = i["gamma"], i["B"]
+        d = lambda x, dt: torch.tensor(x, dtype=dt, device=DEV)
+        tb, tt = d(i["tokens_buffer"], torch.long), d(i["target_tokens"], torch.long)
+        output = torch.zeros(B, i["out_cols"], dtype=torch.long, device=DEV)
+        nn_ = d(i["num_nodes"], torch.long)
+        cl, lp = d(i["cachelens"], torch.int32), d(i["last_page_len"], torch.int32)
+        dcl, dlp = d(i[pre + "cachelens"], torch.int32), d(i[pre + "last_page_len"], torch.int32)
+        an, bo = torch.zeros(B, dtype=torch.long, device=DEV), torch.zeros(B, dtype=torch.long, device=DEV)
+        db, cu = torch.zeros(B, 2, dtype=torch.long, device=DEV), torch.zeros(B, dtype=torch.long, device=DEV)
+        fl = torch.zeros(2, dtype=torch.int32, device=DEV)
+        ops.accept_rollback(tb, tt, output, nn_, cl, lp, dcl, dlp, G, dr(G), cap(G), i["eot_1"], i["eot_2"],
+                            i["prefix"] + 80, an, bo, db if dbl else None, cu if dbl else None, fl)
+        assert bool(fl[0]) == o["terminal"]
+        assert an.tolist() == o["accept_nums"] and bo.tolist() == o["bonus"]
+        assert tb.tolist() == o["tokens_buffer"]
+        assert cl.tolist() == o["cachelens"] and lp.tolist() == o["last_page_len"]
+        assert dcl.tolist() == o[pre + "cachelens"] and dlp.tolist() == o[pre + "last_page_len"]
+        assert nn_.tolist() == o["num_nodes"]
+        out_np = output.cpu().numpy()
+        nz = np.nonzero(out_np)
+        assert [[int(a), int(b)] for a, b in zip(*nz)] == o["output_nz"] and out_np[nz].tolist() == o["output_vals"]
+        assert bool(fl[1]) == o["next_double"]
+        if o["next_double"]:
+            assert db.tolist() == o["double_buffer"] and cu.tolist() == o["cachelens_update"]
+
+
+# ----------------------------------------------------------------------------------------- StreamingLLM eviction
+def test_streaming_shift_and_rotate_match_reference_cache_bytes(ops, golden_dir):
+    """The in-place shift + rotate reproduces the reference KVCache.prefill's cache bytes chunk by chunk."""
+    z = np.load(f"{golden_dir}/stream_prefill.npz")
+    B, KH, D, budget, ppr = [int(x) for x in z["meta"]]
+    tab = ops.RopeTable(1024, D, 10000.0, 1.0, device=DEV)
+    cache = torch.zeros(B * ppr, 2, 128, KH, D, dtype=BF, device=DEV)
+    rot = torch.empty_like(cache)
+    for step in range(int(z["nsteps"][0])):
+        ctx, n, is_last, npr, last = [int(x) for x in z[f"info{step}"]]
+        k = gc.from_bits(z[f"k{step}"]).to(DEV)
+        v = gc.from_bits(z[f"v{step}"]).to(DEV)
+        if ctx + n <= budget:
+            indices = torch.cat([torch.arange(i * ppr, i * ppr + npr, dtype=torch.int32) for i in range(B)]).to(DEV)
+            indptr = (torch.arange(B + 1) * npr).to(torch.int32).to(DEV)
+            ops.update_kv(k, v, (torch.arange(B + 1) * n).to(torch.int32).to(DEV), cache, indices, indptr,
+                          torch.full((B,), last, dtype=torch.int32, device=DEV))
+            valid = ctx + n
+        else:
+            ops.streaming_shift_append(k, v, cache, n, budget, 16, ppr)
+            valid = budget
+        overflow_last = (ctx + n > budget) and is_last
+        dst = cache if overflow_last else rot
+        if not overflow_last:
+            rot.copy_(cache)     # rows >= valid of the clone are the cache's (the reference clones everything)
+        ops.streaming_rotate(cache, dst, B, valid, ppr, tab)
+        assert torch.equal(bits(cache.cpu()), bits(gc.from_bits(z[f"cache{step}"]))), f"cache step {step}"
+        assert torch.equal(bits(dst.cpu()), bits(gc.from_bits(z[f"rot{step}"]))), f"rot step {step}"
+
+
+# ----------------------------------------------------------------------------------------- SnapKV select
+@pytest.mark.parametrize("tag", ["g4", "g5", "g8", "g4d128"])
+def test_snapkv_select_vs_reference_fixture(ops, tag, golden_dir):
+    """Scores: equal to the reference's bf16 scores except isolated 1-ulp flips (MFMA vs CPU fp32 summation order
+    and exp implementation) -- asserted <= 2 ulp and >= 99% exactly equal.  Indices: descending-score order with
+    lowest-index tie-break; the selected set equals the reference's except positions whose score is within
+    2 ulp of the threshold (score ties are implementation-defined in torch.topk)."""
+    z = np.load(f"{golden_dir}/snapkv_select.npz")
+    g, KH, D, S, budget, B, W = [int(x) for x in z[f"{tag}_meta"]]
+    H = g * KH
+    q = gc.from_bits(z[f"{tag}_q"])
+    k = gc.from_bits(z[f"{tag}_k"])
+    v = gc.from_bits(z[f"{tag}_v"])
+    ref_scores = gc.from_bits(z[f"{tag}_scores"])
+    ref_idx = torch.from_numpy(z[f"{tag}_idx"])
+    npg = (S + 127) // 128
+    cache = torch.zeros(B * npg, 2, 128, KH, D, dtype=BF)
+    for b in range(B):
+        kk = torch.zeros(npg * 128, KH, D, dtype=BF)
+        vv = torch.zeros(npg * 128, KH, D, dtype=BF)
+        kk[:S], vv[:S] = k[b], v[b]
+        cache[b * npg:(b + 1) * npg, 0] = kk.view(npg, 128, KH, D)
+        cache[b * npg:(b + 1) * npg, 1] = vv.view(npg, 128, KH, D)
+    dppr = budget // 128 + 1
+    dcache = torch.zeros(B * dppr, 2, 128, KH, D, dtype=BF, device=DEV)
+    ws = ops.AttnWorkspace(DEV)
+    idx, sc = ops.snapkv_select(q.to(DEV), cache.to(DEV), torch.arange(B * npg, dtype=torch.int32, device=DEV),
+                                (torch.arange(B + 1, dtype=torch.int32) * npg).to(DEV), S, W, budget, 5, dcache,
+                                torch.arange(B * dppr, dtype=torch.int32, device=DEV),
+                                (torch.arange(B + 1, dtype=torch.int32) * dppr).to(DEV),
+                                torch.ones(B, dtype=torch.int32, device=DEV), ws, return_scores=True)
+    idx, sc = idx.cpu().long(), sc.cpu()
+    topk = budget - W
+    exact = (bits(sc) == bits(ref_scores)).float().mean().item()
+    assert exact >= 0.99, exact
+    assert _ulp_close(sc, ref_scores, ulps=2)
+    dk = dcache.cpu()
+    for b in range(B):
+        for h in range(KH):
+            s = sc[b, h].float()
+            mine = idx[b, h]
+            assert torch.equal(mine, torch.sort(s, descending=True, stable=True).indices[:topk]), "order / tie-break"
+            theirs = set(ref_idx[b, h].tolist())
+            diff = set(mine.tolist()) ^ theirs
+            thr = ref_scores[b, h].float()[ref_idx[b, h]].min()
+            for p in diff:
+                assert abs(ref_scores[b, h, p].float() - thr) <= 2 * thr * 2 ** -8 + 1e-30, (b, h, p)
+            # gathered rows: draft slots [0,topk) = K/V at our indices, then the last W positions
+            rows_k = dk[b * dppr:(b + 1) * dppr, 0].reshape(-1, KH, D)[:budget, h]
+            rows_v = dk[b * dppr:(b + 1) * dppr, 1].reshape(-1, KH, D)[:budget, h]
+            assert torch.equal(bits(rows_k[:topk]), bits(k[b][mine, h]))
+            assert torch.equal(bits(rows_v[:topk]), bits(v[b][mine, h]))
+            assert torch.equal(bits(rows_k[topk:]), bits(k[b][S - W:, h]))
+            assert torch.equal(bits(rows_v[topk:]), bits(v[b][S - W:, h]))
