@@ -17,11 +17,21 @@ import torch
 from .magicdec_ref import accept_step
 
 
+RICH = False   # tests set this to also record full inputs and the oracle's top-2 logits per position
+
+
 def _rec(trace, name, eng, inp, out, cachelen_update=None):
     if trace is None:
         return
     r = dict(fn=name, inp=inp.tolist() if inp.shape[1] <= 8 else [int(inp.shape[1])],
              out=out.tolist() if out.shape[1] <= 8 else out[:, -1:].tolist())
+    if RICH:
+        import torch as _t
+        r["inp_full"] = inp.clone()
+        r["out_full"] = out.clone()
+        lg = eng.model.last_logits.float()
+        r["top2"] = _t.topk(lg, 2, dim=-1)
+        r["logits"] = lg.clone() if lg.numel() <= (1 << 18) else None
     if cachelen_update is not None:
         r["cachelen_update"] = cachelen_update.flatten().tolist()
     for at in ("cachelens", "paged_kv_last_page_len", "paged_kv_indptr", "draft_cachelens",

@@ -340,6 +340,7 @@ class RefModel:
         """:175-188 final norm -> lm head -> argmax (TP: merge of per-rank maxima)."""
         x = rmsnorm(x, self.sd["norm.weight"], self.cfg.norm_eps)
         logits = F.linear(x, self.sd["output.weight"])
+        self.last_logits = logits          # kept for tie-aware token comparisons in tests
         if return_logits:
             return logits
         if self.group is not None:
