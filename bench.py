@@ -1,0 +1,363 @@
+"""Benchmark of the MagicDec draft/verify decode loop on MI355X.
+
+    python bench.py [--gpus N --steps K --warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json metric "decode tokens/s/node + speedup vs autoregressive, Llama-3.1-8B B=64
+prefix=16K" == configs[2], the tests/SnapKV/longspec_benchmark.py command of the reference's README.md:69):
+Llama-3.1-8B target (TP = N) + Llama-3.2-1B SnapKV draft (budget 257, TP = min(N,4)), gamma=3, B=64,
+prefix_len 16032, max_len 16128, bf16, seeded random-init weights of those architectures (no checkpoints on
+the box), synthetic PG-19-shaped token batch.  It fits one MI355X (126 GiB target KV + 32 GiB draft KV +
+17 GiB weights), so the N=1 line is this exact configuration at TP=1.
+
+A "step" is one speculative iteration: gamma draft steps, one (gamma+1)-token verify over the full KV, the
+fused accept/rollback.  Prefill (outside the reference's timed region too) runs once before the clock starts;
+when a batch reaches prefix+80 generated tokens the length counters are restored to their post-prefill values
+(the KV rows beyond the prefix are overwritten), exactly what the next batch would see.
+
+Acceptance: random-init weights make measured acceptance meaningless (~0), so `value` uses the fixed-acceptance
+replay of SURVEY.md section 8d -- per-row accept counts drawn from a seeded truncated geometric with alpha=0.8
+(the reference's measured rate, index.html:595-601), E[tokens/iter]=2.952 at gamma=3; every kernel of the
+iteration still runs.  The same line also reports the run with the models' own (random-weight) acceptance and
+the autoregressive baseline (tests/baseline_benchmark.py loop) that defines "speedup".
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0     # MI355X spec (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 TB/s achievable)
+
+WORKLOADS = {
+    # name: (target cfg dir, draft cfg dir, B, prefix, max_len, budget, gamma)
+    "cfg3": ("Meta-Llama-3.1-8B", "Llama-3.2-1B", 64, 16032, 16128, 257, 3),
+    "cfg3-small": ("Meta-Llama-3.1-8B", "Llama-3.2-1B", 8, 2080, 2176, 257, 3),
+    "tiny": ("llama-68m-gqa", "llama-68m-gqa", 4, 416, 512, 129, 3),
+}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--workload", default="cfg3", choices=list(WORKLOADS))
+    ap.add_argument("--alpha", type=float, default=0.8, help="acceptance rate of the fixed-acceptance replay")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--graphs", action="store_true", help="capture decode steps into hipGraphs (engine.compile())")
+    ap.add_argument("--checkpoints", type=Path, default=Path("checkpoints"))
+    return ap.parse_args()
+
+
+class AttnTimer:
+    """HIP events around every md_paged_attn launch of the verify pass, recorded on the launching stream."""
+
+    def __init__(self):
+        self.pairs = []
+        self.enabled = False
+
+    def wrap(self, model):
+        timer = self
+        orig = model._attend
+
+        def timed(q_rot, cache, qo_indptr, tab, n):
+            if not timer.enabled:
+                return orig(q_rot, cache, qo_indptr, tab, n)
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            o = orig(q_rot, cache, qo_indptr, tab, n)
+            e.record()
+            timer.pairs.append((s, e))
+            return o
+        model._attend = timed
+
+    def mean_ms(self):
+        return sum(s.elapsed_time(e) for s, e in self.pairs) / max(len(self.pairs), 1)
+
+
+def truncated_geometric(alpha, gamma, shape, gen, device):
+    """accept_nums in [1, gamma+1]: P(j accepted drafts) = alpha^j (1-alpha) for j<gamma, alpha^gamma for j=gamma."""
+    u = torch.rand(shape, generator=gen, device=device)
+    a = torch.ones(shape, dtype=torch.long, device=device)
+    for j in range(1, gamma + 1):
+        a += (u < alpha ** j).long()
+    return a
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)"
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    dev = f"cuda:{local_rank}"
+    os.environ.setdefault("LOCAL_WORLD_SIZE", str(world))
+
+    from magicdec_amd import harness, _lib
+    from magicdec_amd.Engine import model_core
+    from magicdec_amd.Engine.SnapKV.backend import LMBackend
+    from magicdec_amd.Engine.SnapKV.backend_draft import LMBackend_Draft
+    from magicdec_amd.Engine.utils import setup_seed
+    _lib.load()
+    model_core.transformer_configs.setdefault(
+        "llama-68m-gqa", dict(block_size=2048, n_layer=2, n_head=12, n_local_heads=4, dim=768, intermediate_size=3072,
+                              vocab_size=32000))
+
+    tgt_name, drf_name, B, S, ML, BUDGET, G = WORKLOADS[args.workload]
+    use_tp = world > 1
+    group = draft_group = None
+    rank_group = list(range(world))
+    draft_ranks = list(range(min(world, 4)))
+    if use_tp:
+        from magicdec_amd.Engine.tp import init_dist
+        _, group, draft_group = init_dist(draft_ranks)
+    in_draft = rank in draft_ranks
+    setup_seed(123)
+
+    t_load = time.time()
+    engine = LMBackend(dtype=torch.bfloat16, device=dev, dec_len=G + 1)
+    engine.load_model(args.checkpoints / tgt_name / "model.pth", use_tp=use_tp, rank_group=rank_group, group=group)
+    engine.setup_caches(max_batch_size=B, max_seq_length=ML)
+    draft = None
+    if in_draft:
+        draft = LMBackend_Draft(dtype=torch.bfloat16, device=dev, draft_budget=BUDGET)
+        draft.load_model(args.checkpoints / drf_name / "model.pth", use_tp=len(draft_ranks) > 1,
+                         rank_group=draft_ranks, group=draft_group)
+        draft.setup_caches(max_batch_size=B, max_seq_length=ML, draft_budget=BUDGET)
+    if args.graphs:
+        engine.compile()
+        if draft is not None:
+            draft.compile()
+    timer = AttnTimer()
+    timer.wrap(engine.model)
+    t_load = time.time() - t_load
+
+    # synthetic PG-19-shaped batch: uniform token ids, BOS in column 0 (Data/data_converter.py:54), seed 123
+    vocab = engine.model.tok_embeddings.weight.shape[0]
+    g = torch.Generator().manual_seed(123)
+    input_ids = torch.randint(0, vocab, (B, S), generator=g)
+    input_ids[:, 0] = 1
+    input_ids = input_ids.to(dev)
+    eot_1, eot_2 = -1, -2      # synthetic ids carry no EOT semantics
+
+    # ---- prefill (untimed, as in the reference)
+    torch.cuda.synchronize()
+    t_pf = time.time()
+    st = harness.new_state(B, G, ML + 1, dev, input_ids)
+    st.tokens_buffer[:, :1] = engine.encode(input_ids=input_ids)[:, -1:]
+    if draft is not None:
+        draft.encode(input_ids=input_ids)
+    torch.cuda.synchronize()
+    t_pf = time.time() - t_pf
+    snap = {"e": (engine.cachelens.clone(), engine.paged_kv_last_page_len.clone())}
+    if draft is not None:
+        snap["d"] = (draft.cachelens.clone(), draft.paged_kv_last_page_len.clone(),
+                     draft.draft_paged_kv_last_page_len.clone())
+    first_tok = st.tokens_buffer[:, :1].clone()
+
+    def restore():
+        engine.cachelens.copy_(snap["e"][0])
+        engine.paged_kv_last_page_len.copy_(snap["e"][1])
+        if draft is not None:
+            draft.cachelens.copy_(snap["d"][0])
+            draft.paged_kv_last_page_len.copy_(snap["d"][1])
+            draft.draft_paged_kv_last_page_len.copy_(snap["d"][2])
+        st.num_nodes.fill_(S)
+        st.tokens_buffer.zero_()
+        st.tokens_buffer[:, :1] = first_tok
+
+    def barrier():
+        if use_tp:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def iteration(next_double, forced):
+        """One speculative iteration across the TP group (draft sub-group drafts, tokens broadcast, all verify)."""
+        if draft is not None:
+            harness._draft_round(lambda ids, cu: draft.inference(ids, cachelen_update=cu), st, G, next_double)
+        if use_tp and len(draft_ranks) != world:
+            dist.broadcast(st.tokens_buffer, src=draft_ranks[0], group=group)
+        target_tokens = engine.inference(st.tokens_buffer)
+        if forced is not None:
+            target_tokens = harness._force_accept(st.tokens_buffer, target_tokens, forced, G)
+        from magicdec_amd import ops
+        dcl = draft.cachelens if draft is not None else None
+        dlp = draft.paged_kv_last_page_len if draft is not None else None
+        ops.accept_rollback(st.tokens_buffer, target_tokens, st.output, st.num_nodes, engine.cachelens,
+                            engine.paged_kv_last_page_len, dcl, dlp, G, G, G, eot_1, eot_2, S + 80, st.accept_nums,
+                            st.bonus, st.double_buffer, st.cachelens_update, st.flags)
+        st.iters += 1
+        return harness._read_flags(st)
+
+    def run_spec(n_warm, n_steps, forced_table):
+        restore()
+        nd = False
+        tokens = torch.zeros((), dtype=torch.long, device=dev)
+        timer.enabled = False
+        for i in range(n_warm):
+            term, nd = iteration(nd, forced_table[i] if forced_table is not None else None)
+            if term:
+                restore()
+                nd = False
+        timer.pairs.clear()
+        timer.enabled = True
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(n_steps):
+            term, nd = iteration(nd, forced_table[n_warm + i] if forced_table is not None else None)
+            tokens += st.accept_nums.sum()
+            if term:
+                restore()
+                nd = False
+        barrier()
+        dt = time.perf_counter() - t0
+        timer.enabled = False
+        return dt, int(tokens.item())
+
+    gen = torch.Generator(device=dev).manual_seed(2024)
+    forced = truncated_geometric(args.alpha, G, (args.warmup + args.steps, B), gen, dev)
+    dt_replay, tok_replay = run_spec(args.warmup, args.steps, forced)
+    attn_ms = timer.mean_ms()
+    n_attn = len(timer.pairs)
+    dt_meas, tok_meas = run_spec(min(args.warmup, 2), max(args.steps // 4, 4), None)
+    meas_steps = max(args.steps // 4, 4)
+
+    # ---- autoregressive baseline (tests/baseline_benchmark.py loop: one token per target step)
+    restore()
+    nt = first_tok.clone()
+    for _ in range(min(args.warmup, 3)):
+        nt = engine.inference(nt)
+    restore()
+    base_steps = max(args.steps // 2, 8)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(base_steps):
+        nt = engine.inference(nt)
+    barrier()
+    dt_base = time.perf_counter() - t0
+
+    def allmax(x):
+        if not use_tp:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+    dt_replay, dt_meas, dt_base = allmax(dt_replay), allmax(dt_meas), allmax(dt_base)
+
+    value = tok_replay / dt_replay
+    base_tps = B * base_steps / dt_base
+    cfg = engine.model.config
+    H_loc, KH_loc, D = cfg.n_head, cfg.n_local_heads, cfg.head_dim
+    L_kv = S + 40 + G + 1                                 # mean kv length over a batch's 80 generated tokens
+    attn_bytes = B * L_kv * KH_loc * D * 2 * 2 + 2 * B * (G + 1) * H_loc * D * 2
+    achieved = attn_bytes / (attn_ms * 1e-3) / 1e9 if attn_ms > 0 else 0.0
+
+    line = {
+        "metric": "decode tokens/s/node + speedup vs autoregressive, Llama-3.1-8B B=64 prefix=16K",
+        "value": round(value, 2), "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(dt_replay / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong",
+        "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": f"{args.workload}: {tgt_name} target TP{world} + {drf_name} SnapKV draft "
+                               f"TP{len(draft_ranks)} budget {BUDGET} gamma {G}, B={B} prefix={S} max_len={ML}",
+                   "acceptance": f"fixed replay alpha={args.alpha} (E[tokens/iter]={tok_replay / args.steps / B:.3f})",
+                   "weights": "seeded random init (no checkpoints on the box)",
+                   "hip_graphs": bool(args.graphs)},
+        "speedup_vs_autoregressive": round(value / base_tps, 4),
+        "autoregressive_tokens_per_s": round(base_tps, 2),
+        "autoregressive_ms_per_step": round(dt_base / base_steps * 1e3, 4),
+        "measured_acceptance_run": {"tokens_per_s": round(tok_meas / dt_meas, 2),
+                                    "tokens_per_iter_per_seq": round(tok_meas / meas_steps / B, 3),
+                                    "ms_per_step": round(dt_meas / meas_steps * 1e3, 4)},
+        "prefill_s": round(t_pf, 2), "load_s": round(t_load, 2),
+        "roofline": {"kernel": "paged_attn_kernel<128,1,false> (verify attention, md_paged_attn)", "bound": "hbm",
+                     "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                     "bytes_per_launch": attn_bytes, "avg_launch_ms": round(attn_ms, 4), "launches_timed": n_attn},
+    }
+    if rank == 0 and not args.no_cpu_baseline and world == 1:
+        line["cpu_baseline"] = cpu_baseline(tgt_name, drf_name, S, BUDGET, G, args.alpha)
+    if rank == 0:
+        print(json.dumps(line), flush=True)
+    if use_tp:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(tgt_name, drf_name, S, budget, gamma, alpha):
+    """The oracle (oracle/magicdec_ref.py, a CPU port of the reference path) timed on this host's cores on a
+    bounded sample: ONE decoder layer of each model at the real shapes, B=1, the real prefix length with the KV
+    pre-filled with random values; one speculative iteration = gamma draft steps + one verify.  The per-layer
+    times are scaled to the full depth (32 / 16 layers) -- layer cost is depth-independent -- and to tokens/s
+    with the same replayed acceptance.  A reported baseline, not an optimisation target."""
+    import torch
+    from magicdec_amd.Engine.model_core import ModelArgs
+    from oracle import magicdec_ref as mr
+    ncores = os.cpu_count() or 1
+    torch.set_num_threads(ncores)
+
+    def one_layer(name, mode, max_len, bud):
+        a = ModelArgs.from_name(name)
+        cfg = mr.RefConfig(n_layer=1, n_head=a.n_head, n_local_heads=a.n_local_heads, dim=a.dim,
+                           intermediate_size=a.intermediate_size, vocab_size=a.vocab_size, rope_base=a.rope_base,
+                           scaling_factor=a.scaling_factor, low_freq_factor=a.low_freq_factor,
+                           high_freq_factor=a.high_freq_factor,
+                           original_max_position_embeddings=a.original_max_position_embeddings)
+        sd = mr.init_state_dict(cfg, 1)
+        e = mr.RefEngine(mode, cfg, sd, 1, max_len, bud, max_pos=max_len + 256)
+        return e, a.n_layer
+
+    t_all = time.perf_counter()
+    tgt, n_t = one_layer(tgt_name, "target", S + 96, 0)
+    npg = S // 128 + 1
+    tgt.caches[0][:npg].normal_()
+    tgt.cachelens.fill_(S)
+    tgt.paged_kv_indptr = torch.tensor([0, npg], dtype=torch.int32)
+    tgt.paged_kv_indices = torch.arange(npg, dtype=torch.int32)
+    tgt.paged_kv_last_page_len = torch.tensor([S - (npg - 1) * 128], dtype=torch.int32)
+    drf, n_d = one_layer(drf_name, "snapkv_draft", S + 96, budget)
+    drf.draft_caches[0].normal_()
+    drf.cachelens.fill_(S)
+    tb = torch.randint(0, 1000, (1, gamma + 1))
+    reps = 2
+    t_d = t_v = 0.0
+    for r in range(reps + 1):
+        t0 = time.perf_counter()
+        for i in range(gamma):
+            drf.inference(tb[:, i:i + 1])
+        t1 = time.perf_counter()
+        tgt.inference(tb)
+        t2 = time.perf_counter()
+        tgt.cachelens -= gamma + 1
+        tgt.paged_kv_last_page_len -= gamma + 1
+        drf.cachelens -= gamma
+        drf.draft_paged_kv_last_page_len -= gamma
+        if r > 0:
+            t_d += t1 - t0
+            t_v += t2 - t1
+    t_d, t_v = t_d / reps, t_v / reps
+    # a 1-layer pass = 1 layer + embedding + lm head; scaling by depth over-counts the head slightly (stated)
+    iter_s = t_d * n_d + t_v * n_t
+    e_tok = sum(alpha ** j for j in range(gamma + 1))
+    return {"value": round(e_tok / iter_s, 4), "unit": "tokens/s", "cores": ncores, "kind": "port",
+            "sample": f"oracle (CPU port), 1 of {n_t} target layers + 1 of {n_d} draft layers at real shapes, B=1, "
+                      f"prefix {S}, random KV; iteration = {gamma} draft steps ({t_d * 1e3:.1f} ms/layer-pass) + 1 "
+                      f"verify ({t_v * 1e3:.1f} ms/layer-pass), scaled to full depth, replay alpha={alpha}; "
+                      f"CPU throughput is per-sequence (x1 batch)",
+            "wall_s": round(time.perf_counter() - t_all, 1)}
+
+
+if __name__ == "__main__":
+    main()

@@ -117,7 +117,7 @@ class SnapKVTargetBackend(_BackendBase):
         self.is_spec = draft_dec_len is not None
         self.draft_cachelens = None
 
-    @torch.inference_mode()
+    @torch.no_grad()
     def setup_caches(self, max_batch_size: int = 1, max_seq_length: int = 2048, draft_budget=0, window_size=32):
         self.max_length, self.batch_size = max_seq_length, max_batch_size
         dev = self.device
@@ -141,7 +141,7 @@ class SnapKVTargetBackend(_BackendBase):
             self.model.setup_caches(num_pages=self.max_num_pages, page_size=PAGE_SIZE,
                                     max_positions=max_seq_length + 256)
 
-    @torch.inference_mode()
+    @torch.no_grad()
     def clear_kv(self):
         for b in self.model.layers:
             b.attention.kv_cache.kv_cache.zero_()
@@ -154,7 +154,7 @@ class SnapKVTargetBackend(_BackendBase):
             self.draft_cachelens.zero_()
             self._d.reset(last_page_len_init=1, full_table=True)
 
-    @torch.inference_mode()
+    @torch.no_grad()
     def encode(self, input_ids: torch.LongTensor, benchmark=False):
         """Chunked prefill (backend.py:232-268)."""
         self.clear_kv()
@@ -180,7 +180,7 @@ class SnapKVTargetBackend(_BackendBase):
             self.draft_cachelens.copy_(self.cachelens)
         return tokens
 
-    @torch.inference_mode()
+    @torch.no_grad()
     def inference(self, input_ids: torch.LongTensor, benchmark=False):
         """Autoregressive step / longspec verification (backend.py:129-159)."""
         n = input_ids.shape[1]
@@ -193,7 +193,7 @@ class SnapKVTargetBackend(_BackendBase):
             self.paged_kv_last_page_len -= n
         return out
 
-    @torch.inference_mode()
+    @torch.no_grad()
     def verify(self, input_ids: torch.LongTensor, benchmark=False):
         """Self-spec verification: also appends the gamma+1 rows to the draft cache (backend.py:163-197)."""
         n = input_ids.shape[1]
@@ -209,7 +209,7 @@ class SnapKVTargetBackend(_BackendBase):
             self.paged_kv_last_page_len -= n
         return out
 
-    @torch.inference_mode()
+    @torch.no_grad()
     def speculate(self, input_ids: torch.LongTensor, benchmark=False):
         """Self-spec draft step over the SnapKV draft cache (backend.py:200-229)."""
         n = input_ids.shape[1]
@@ -233,7 +233,7 @@ class SnapKVDraftBackend(_BackendBase):
         self.dec_len = dec_len
         self.is_compress = draft_budget != -1
 
-    @torch.inference_mode()
+    @torch.no_grad()
     def setup_caches(self, max_batch_size: int = 1, max_seq_length: int = 2048, draft_budget=0, window_size=32):
         self.batch_size = max_batch_size
         dev = self.device
@@ -256,7 +256,7 @@ class SnapKVDraftBackend(_BackendBase):
             self.model.setup_caches(num_pages=self.max_num_pages, page_size=PAGE_SIZE,
                                     max_positions=max_seq_length + 256)
 
-    @torch.inference_mode()
+    @torch.no_grad()
     def clear_kv(self):
         for b in self.model.layers:
             b.attention.kv_cache.kv_cache.zero_()
@@ -268,7 +268,7 @@ class SnapKVDraftBackend(_BackendBase):
         if self.is_compress:
             self._d.reset(last_page_len_init=1, full_table=True)
 
-    @torch.inference_mode()
+    @torch.no_grad()
     def encode(self, input_ids: torch.LongTensor, benchmark=False):
         """backend_draft.py:176-209."""
         self.clear_kv()
@@ -292,7 +292,7 @@ class SnapKVDraftBackend(_BackendBase):
         self.model.skip_head = False
         return tokens
 
-    @torch.inference_mode()
+    @torch.no_grad()
     def inference(self, input_ids: torch.LongTensor, benchmark=False, cachelen_update=None):
         """One (or, after an all-accept iteration, a two-token) draft step (backend_draft.py:113-173)."""
         n = input_ids.shape[1]
@@ -357,7 +357,7 @@ class StreamingDraftBackend(_BackendBase, _StreamingMixin):
     def __init__(self, dtype=torch.bfloat16, device: str = "cuda:0"):
         super().__init__(dtype, device)
 
-    @torch.inference_mode()
+    @torch.no_grad()
     def setup_caches(self, max_batch_size: int = 1, draft_budget=0):
         self.draft_budget, self.batch_size = draft_budget, max_batch_size
         dev = self.device
@@ -371,7 +371,7 @@ class StreamingDraftBackend(_BackendBase, _StreamingMixin):
         self.model.setup_caches(num_pages=self.max_num_pages, page_size=PAGE_SIZE, draft_budget=draft_budget,
                                 streaming=True, max_positions=self.max_num_pages_per_request * PAGE_SIZE + 256)
 
-    @torch.inference_mode()
+    @torch.no_grad()
     def clear_kv(self):
         for b in self.model.layers:
             b.attention.kv_cache.kv_cache.zero_()
@@ -379,12 +379,12 @@ class StreamingDraftBackend(_BackendBase, _StreamingMixin):
         self.qo_indptr = torch.arange(self.batch_size + 1, dtype=torch.int32, device=self.device)
         self._t.reset()
 
-    @torch.inference_mode()
+    @torch.no_grad()
     def encode(self, input_ids: torch.LongTensor, benchmark=False):
         self.clear_kv()
         return self._stream_encode(input_ids, self._t, "cachelens", "kv_cache")
 
-    @torch.inference_mode()
+    @torch.no_grad()
     def inference(self, input_ids: torch.LongTensor, benchmark=False, cachelen_update=None):
         """StreamingLLM/backend_draft.py:89-124."""
         n = input_ids.shape[1]
@@ -412,7 +412,7 @@ class StreamingSelfSpecBackend(_BackendBase, _StreamingMixin):
         self.dec_len = dec_len
         self.draft_cachelens = None
 
-    @torch.inference_mode()
+    @torch.no_grad()
     def setup_caches(self, max_batch_size: int = 1, max_seq_length: int = 2048, draft_budget=0):
         self.draft_budget, self.batch_size = draft_budget, max_batch_size
         dev = self.device
@@ -431,7 +431,7 @@ class StreamingSelfSpecBackend(_BackendBase, _StreamingMixin):
                                 draft_num_pages=self.draft_max_num_pages, draft_budget=draft_budget, streaming=True,
                                 max_positions=max_seq_length + 256)
 
-    @torch.inference_mode()
+    @torch.no_grad()
     def clear_kv(self):
         for b in self.model.layers:
             b.attention.kv_cache.kv_cache.zero_()
@@ -442,7 +442,7 @@ class StreamingSelfSpecBackend(_BackendBase, _StreamingMixin):
         self._t.reset()
         self._d.reset(indptr_stride=self.draft_max_num_pages_per_request)   # StreamingLLM/backend.py:316
 
-    @torch.inference_mode()
+    @torch.no_grad()
     def encode(self, input_ids: torch.LongTensor, benchmark=False):
         """Target prefill (StreamingLLM/backend.py:190-211)."""
         self.clear_kv()
@@ -459,12 +459,12 @@ class StreamingSelfSpecBackend(_BackendBase, _StreamingMixin):
         self.model.skip_head = False
         return tokens
 
-    @torch.inference_mode()
+    @torch.no_grad()
     def draft_encode(self, input_ids: torch.LongTensor, benchmark=False):
         """Second pass filling the streaming draft cache (StreamingLLM/backend.py:234-258)."""
         return self._stream_encode(input_ids, self._d, "draft_cachelens", "draft_cache")
 
-    @torch.inference_mode()
+    @torch.no_grad()
     def verify(self, input_ids: torch.LongTensor, benchmark=False):
         n = input_ids.shape[1]
         self.paged_kv_last_page_len += n
@@ -476,7 +476,7 @@ class StreamingSelfSpecBackend(_BackendBase, _StreamingMixin):
             self.paged_kv_last_page_len -= n
         return out
 
-    @torch.inference_mode()
+    @torch.no_grad()
     def speculate(self, input_ids: torch.LongTensor, benchmark=False, cachelen_update=None):
         n = input_ids.shape[1]
         self.draft_paged_kv_last_page_len += n

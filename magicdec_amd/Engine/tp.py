@@ -52,6 +52,7 @@ def init_dist(draft_ranks=None):
 
 
 def _slice_param(linear: nn.Linear, weight, size_attr):
+    weight = weight.clone()      # own storage: the full tensor is released, GEMM operands stay contiguous
     linear.weight = nn.Parameter(weight, requires_grad=False)
     setattr(linear, size_attr, weight.shape[0 if size_attr == "out_features" else 1])
 
