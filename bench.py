@@ -55,7 +55,9 @@ def parse():
     ap.add_argument("--workload", default="cfg3", choices=list(WORKLOADS))
     ap.add_argument("--alpha", type=float, default=0.8, help="acceptance rate of the fixed-acceptance replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--graphs", action="store_true", help="capture decode steps into hipGraphs (engine.compile())")
+    ap.add_argument("--graphs", dest="graphs", action="store_true", default=None,
+                    help="capture decode steps into hipGraphs (engine.compile()); default: on for 1 GPU")
+    ap.add_argument("--no-graphs", dest="graphs", action="store_false")
     ap.add_argument("--checkpoints", type=Path, default=Path("checkpoints"))
     return ap.parse_args()
 
@@ -137,6 +139,9 @@ def main():
         draft.load_model(args.checkpoints / drf_name / "model.pth", use_tp=len(draft_ranks) > 1,
                          rank_group=draft_ranks, group=draft_group)
         draft.setup_caches(max_batch_size=B, max_seq_length=ML, draft_budget=BUDGET)
+    if args.graphs is None:
+        # TP>1: RCCL collectives inside a captured graph could not be validated on the 1-GPU development box
+        args.graphs = (world == 1) and os.environ.get("MAGICDEC_NO_GRAPHS", "0") != "1"
     if args.graphs:
         engine.compile()
         if draft is not None:
@@ -230,6 +235,12 @@ def main():
     gen = torch.Generator(device=dev).manual_seed(2024)
     forced = truncated_geometric(args.alpha, G, (args.warmup + args.steps, B), gen, dev)
     dt_replay, tok_replay = run_spec(args.warmup, args.steps, forced)
+    if args.graphs:
+        # HIP events cannot be recorded inside a replayed graph: time the verify-attention launches in an eager
+        # pass of the same iterations (same kernels, same shapes, same stream) right after the timed region
+        engine._use_graphs = False
+        run_spec(1, min(args.steps, 8), forced)
+        engine._use_graphs = True
     attn_ms = timer.mean_ms()
     n_attn = len(timer.pairs)
     dt_meas, tok_meas = run_spec(min(args.warmup, 2), max(args.steps // 4, 4), None)

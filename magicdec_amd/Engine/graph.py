@@ -1,0 +1,106 @@
+"""hipGraph capture of the decode steps (the MI355X counterpart of the reference's `compile()`:
+torch.compile(mode="max-autotune") + CUDA graphs, Engine/SnapKV/backend.py:116-125).
+
+A draft step of a 1B model is ~150 kernel launches for ~0.6 ms of HBM time: eager launching is host-bound
+(MI355X_MICROARCH.md "graph-replay-floor").  Every kernel of a step reads its lengths / page table from device
+memory at execution time and nothing in a step touches the host, so a step is captured once per
+(kind, n_tokens) and replayed.
+
+The harness may REBIND the length tensors between calls (tests/SnapKV/longspec_benchmark.py:228-256).  Graphs
+bake addresses, so each captured step owns static copies of the state tensors it reads; before a replay any
+attribute that is no longer the static tensor is copied into it and re-bound to it (same values, so the
+reference's semantics are unchanged); in the steady state of our own loop (in-place updates) nothing is copied.
+"""
+from __future__ import annotations
+
+import torch
+
+_STATE_BY_KIND = {
+    "fwd": ("cachelens", "qo_indptr", "paged_kv_indices", "paged_kv_indptr", "paged_kv_last_page_len"),
+    "draft": ("cachelens", "qo_indptr", "draft_paged_kv_indices", "draft_paged_kv_indptr",
+              "draft_paged_kv_last_page_len"),
+    "spec": ("draft_cachelens", "qo_indptr", "draft_paged_kv_indices", "draft_paged_kv_indptr",
+             "draft_paged_kv_last_page_len"),
+    "verify": ("cachelens", "qo_indptr", "paged_kv_indices", "paged_kv_indptr", "paged_kv_last_page_len",
+               "draft_paged_kv_indices", "draft_paged_kv_indptr", "draft_paged_kv_last_page_len"),
+}
+
+
+class _Captured:
+    def __init__(self):
+        self.graph = None
+        self.static_in = None
+        self.static_out = None
+        self.names = ()       # state attributes this step reads
+
+
+def _statics(backend):
+    """attr name -> static tensor, shared by all captured steps of one back-end."""
+    if not hasattr(backend, "_gstate"):
+        backend._gstate = {}
+    return backend._gstate
+
+
+def _bind_state(backend, ent: _Captured):
+    """Make every state attribute the static tensor (copying the current values if it was rebound)."""
+    src, dst = [], []
+    gs = _statics(backend)
+    for name in ent.names:
+        st = gs[name]
+        cur = getattr(backend, name)
+        if cur is not st:
+            if cur.shape != st.shape:
+                raise RuntimeError(f"captured step: '{name}' changed shape {tuple(st.shape)} -> {tuple(cur.shape)}; "
+                                   "call clear_graphs() after setup_caches/encode with a new batch geometry")
+            src.append(cur)
+            dst.append(st)
+            setattr(backend, name, st)
+    if src:
+        torch._foreach_copy_(dst, src)
+
+
+def run_captured(backend, key, fn, input_ids):
+    kind = key[0]
+    full_key = (key, tuple(input_ids.shape), tuple(getattr(backend, "paged_kv_indices").shape),
+                tuple(getattr(backend, "draft_paged_kv_indices").shape) if hasattr(backend, "draft_paged_kv_indices")
+                else None)
+    ent = backend._graphs.get(full_key)
+    if ent is None:
+        ent = _Captured()
+        gs = _statics(backend)
+        names = []
+        for name in _STATE_BY_KIND[kind]:
+            cur = getattr(backend, name, None)
+            if cur is None:
+                continue
+            if name not in gs or gs[name].shape != cur.shape:
+                gs[name] = cur.clone()
+            names.append(name)
+        ent.names = tuple(names)
+        _bind_state(backend, ent)
+        ent.static_in = input_ids.clone()
+        # warm up on a side stream (hipBLASLt workspaces, lazy module loads, LDS attributes); a step never
+        # changes the lengths it reads, and re-running it rewrites the same KV rows with the same values
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            for _ in range(2):
+                fn(ent.static_in)
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            ent.static_out = fn(ent.static_in)
+        ent.graph = g
+        backend._graphs[full_key] = ent
+    _bind_state(backend, ent)
+    if input_ids.data_ptr() != ent.static_in.data_ptr():
+        ent.static_in.copy_(input_ids)
+    ent.graph.replay()
+    return ent.static_out.clone()
+
+
+def clear_graphs(backend):
+    backend._graphs.clear()
+    if hasattr(backend, "_gstate"):
+        backend._gstate.clear()

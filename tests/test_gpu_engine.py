@@ -198,3 +198,26 @@ def test_hip_loop_equals_hip_autoregressive(ckpt_dir):
     print(f"[spec == autoregressive] agreeing prefix {agree}/{total} generated tokens, iterations={st.iters}")
     assert st.iters > 0 and total > 0
     assert agree >= 0.5 * total
+
+
+def test_hipgraph_steps_equal_eager_steps(ckpt_dir):
+    """engine.compile() (hipGraph capture of the decode steps) must not change a single token or length:
+    the free-running longspec loop with graphs == without graphs, bit for bit (same kernels, deterministic)."""
+    from magicdec_amd import harness
+    ids = gc.synthetic_batches()[1].to(DEV)
+    outs = []
+    for use_graphs in (False, True):
+        tgt, drf = _hip("target", ckpt_dir), _hip("snapkv_draft", ckpt_dir)
+        if use_graphs:
+            tgt.compile()
+            drf.compile()
+        trace = []
+        st, _ = harness.run_longspec_batch(tgt, drf, ids, gc.GAMMA, gc.MAX_LEN, gc.EOT_1, gc.EOT_2,
+                                           trace_fn=lambda s: trace.append(s.accept_nums.tolist()))
+        outs.append((st.output.cpu(), st.num_nodes.cpu(), trace, tgt.cachelens.cpu(), drf.cachelens.cpu(),
+                     drf.draft_paged_kv_last_page_len.cpu()))
+    a, b = outs
+    assert a[2] == b[2] and len(a[2]) > 3, "accept traces differ"
+    for x, y in zip(a, b):
+        if torch.is_tensor(x):
+            assert torch.equal(x, y)
