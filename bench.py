@@ -189,23 +189,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    bcast = (draft_ranks[0], group) if (use_tp and len(draft_ranks) != world) else None
+
     def iteration(next_double, forced):
         """One speculative iteration across the TP group (draft sub-group drafts, tokens broadcast, all verify)."""
-        if draft is not None:
-            harness._draft_round(lambda ids, cu: draft.inference(ids, cachelen_update=cu), st, G, next_double)
-        if use_tp and len(draft_ranks) != world:
-            dist.broadcast(st.tokens_buffer, src=draft_ranks[0], group=group)
-        target_tokens = engine.inference(st.tokens_buffer)
-        if forced is not None:
-            target_tokens = harness._force_accept(st.tokens_buffer, target_tokens, forced, G)
-        from magicdec_amd import ops
-        dcl = draft.cachelens if draft is not None else None
-        dlp = draft.paged_kv_last_page_len if draft is not None else None
-        ops.accept_rollback(st.tokens_buffer, target_tokens, st.output, st.num_nodes, engine.cachelens,
-                            engine.paged_kv_last_page_len, dcl, dlp, G, G, G, eot_1, eot_2, S + 80, st.accept_nums,
-                            st.bonus, st.double_buffer, st.cachelens_update, st.flags)
-        st.iters += 1
-        return harness._read_flags(st)
+        return harness.longspec_iteration(engine, draft, st, G, eot_1, eot_2, S + 80, next_double, forced, bcast)
 
     def run_spec(n_warm, n_steps, forced_table):
         restore()

@@ -1,0 +1,268 @@
+"""Command lines of the reference's benchmark scripts (same flags, asserts and printed lines):
+tests/SnapKV/longspec_benchmark.py:16-46, tests/StreamingLLM/longspec_benchmark.py, tests/*/selfspec_benchmark.py,
+tests/baseline_benchmark.py.  The loops themselves live in magicdec_amd/harness.py."""
+from __future__ import annotations
+
+import argparse
+import builtins
+import time
+from pathlib import Path
+
+import torch
+import torch.distributed as dist
+from torch.utils.data.dataloader import DataLoader
+
+from . import harness
+from .data import convert_pg19_dataset, load_tokenizer
+from .Engine.utils import setup_seed
+
+
+def _common(parser, spec=True):
+    parser.add_argument('--model', type=Path, default=Path("checkpoints/meta-llama/Llama-3.2-1B/model.pth"), help='model')
+    parser.add_argument('--model_name', type=str, default="meta-llama/Meta-Llama-3.1-8B", help='model name')
+    parser.add_argument('--dataset', type=str, default="pg19", help='Dataset name.')
+    parser.add_argument('--rank_group', nargs='+', type=int, help='Target group of ranks')
+    parser.add_argument('--compile', action='store_true', help='Capture the decode steps into hipGraphs.')
+    parser.add_argument('--B', type=int, default=1, help='Batch size.')
+    parser.add_argument('--prefix_len', type=int, default=4000, help='Prefix length')
+    parser.add_argument('--max_len', type=int, default=64, help='Generate length')
+    parser.add_argument('--seed', type=int, default=123, help='Random seed.')
+    parser.add_argument('--printoutput', action='store_true', help='Whether to print the generated text.')
+    parser.add_argument('--benchmark', action='store_true', help='Per-phase timing (adds synchronisations).')
+    if spec:
+        parser.add_argument('--draft_budget', type=int, default=-1, help='Draft KV budget.')
+        parser.add_argument('--gamma', type=int, default=5, help='speculation length')
+        parser.add_argument('--window_size', type=int, default=32, help='SnapKV observation window')
+
+
+def _eot(tokenizer):
+    eot_1 = tokenizer.eos_token_id
+    eot_2 = tokenizer.unk_token_id if tokenizer.unk_token_id is not None else tokenizer.encode("<|eot_id|>")[-1]
+    return eot_1, eot_2
+
+
+def _device():
+    return 'cuda' if torch.cuda.is_available() else 'cpu'
+
+
+def _dataset(args, tokenizer, vocab):
+    if args.dataset != "pg19":
+        raise ValueError(f"Unknown dataset {args.dataset}")
+    return convert_pg19_dataset(tokenizer=tokenizer, seq_len=args.prefix_len, vocab_size=vocab,
+                                num_sequences=10 * args.B)
+
+
+def longspec_main(kind: str, argv=None):
+    """kind: 'SnapKV' | 'StreamingLLM' -- tests/<kind>/longspec_benchmark.py."""
+    parser = argparse.ArgumentParser(description='Process model configuration and partitions.')
+    _common(parser)
+    parser.add_argument('--target', type=Path, default=Path("checkpoints/meta-llama/Meta-Llama-3.1-8B/model.pth"), help='target model')
+    parser.add_argument('--draft_rank_group', nargs='+', type=int, help='Draft group of ranks')
+    args = parser.parse_args(argv)
+    assert args.prefix_len < args.max_len
+    assert (args.max_len + 127) // 128 == args.prefix_len // 128 + 1
+    if kind == "SnapKV":
+        if args.draft_budget != -1:
+            assert (args.prefix_len - args.window_size) % 128 == 0
+            assert (args.draft_budget - 1) % 128 == 0
+    else:
+        assert (args.draft_budget - 1) % 128 == 0
+
+    draft_tp = len(args.draft_rank_group) > 1
+    DEVICE = _device()
+    from .Engine.tp import init_dist
+    use_tp = len(args.draft_rank_group) > 1
+    global_group = draft_group = None
+    rank = 0
+    print_ = builtins.print
+    if use_tp:
+        rank, global_group, draft_group = init_dist(args.draft_rank_group)
+        if rank != args.rank_group[0]:
+            print_ = lambda *a, **k: None
+        DEVICE = f"cuda:{rank}" if torch.cuda.is_available() else "cpu"
+    setup_seed(args.seed)
+    print_(f"Using device={DEVICE}")
+    draft_target_equal = len(args.draft_rank_group) == len(args.rank_group)
+    MAX_LEN_TARGET, BATCH_SIZE, DTYPE = args.max_len, args.B, torch.bfloat16
+
+    from .Engine.SnapKV.backend import LMBackend
+    if kind == "SnapKV":
+        from .Engine.SnapKV.backend_draft import LMBackend_Draft
+    else:
+        from .Engine.StreamingLLM.backend_draft import LMBackend_Draft
+    engine = LMBackend(dtype=DTYPE, device=DEVICE, dec_len=args.gamma + 1)
+    engine.load_model(args.target, use_tp=use_tp, rank_group=args.rank_group, group=global_group)
+    if args.compile:
+        engine.compile()
+    engine.setup_caches(max_batch_size=BATCH_SIZE, max_seq_length=MAX_LEN_TARGET)
+
+    draft = None
+    if (not use_tp) or rank in args.draft_rank_group:
+        if kind == "SnapKV":
+            draft = LMBackend_Draft(dtype=DTYPE, device=DEVICE, draft_budget=args.draft_budget)
+        else:
+            draft = LMBackend_Draft(dtype=DTYPE, device=DEVICE)
+        draft.load_model(args.model, use_tp=use_tp and draft_tp, rank_group=args.draft_rank_group, group=draft_group)
+        if args.compile:
+            draft.compile()
+        if kind == "SnapKV":
+            draft.setup_caches(max_batch_size=BATCH_SIZE, max_seq_length=MAX_LEN_TARGET, draft_budget=args.draft_budget)
+        else:
+            draft.setup_caches(max_batch_size=BATCH_SIZE, draft_budget=args.draft_budget)
+    if use_tp:
+        dist.barrier()
+
+    tokenizer = load_tokenizer(args.model_name)
+    eot_1, eot_2 = _eot(tokenizer)
+    print_(f"eot_1: {eot_1}, eot_2: {eot_2}")
+    dataset = _dataset(args, tokenizer, engine.model.tok_embeddings.weight.shape[0])
+    dataloader = DataLoader(dataset, batch_size=BATCH_SIZE, shuffle=False, drop_last=True)
+    num_eval_steps = min(10, len(dataloader))
+    bcast = (args.draft_rank_group[0], global_group) if (use_tp and not draft_target_equal) else None
+    barrier = dist.barrier if use_tp else None
+
+    total_time, num_gen_tokens, target_steps = 0.0, 0, 0
+    for step, batch in enumerate(dataloader):
+        if step >= num_eval_steps:
+            break
+        input_ids = batch[0].to(DEVICE)
+        st, dt = harness.run_longspec_batch(engine, draft, input_ids, args.gamma, MAX_LEN_TARGET, eot_1, eot_2,
+                                            bcast=bcast, barrier=barrier)
+        total_time += dt
+        target_steps += st.iters
+        num_gen_tokens += int(st.num_nodes.sum() - (input_ids.shape[1] + 1) * BATCH_SIZE)
+        if args.printoutput:
+            for i in range(BATCH_SIZE):
+                print_("Sequence ", i)
+                print_(tokenizer.decode(st.output[i, args.prefix_len:st.num_nodes[i]]))
+        print_("total time :{:.5f}s, time per iter :{:.5f}s, decoding step: {}, large model step: {}, avg latency: {}".format(
+            total_time, total_time / target_steps, num_gen_tokens, target_steps, total_time / num_gen_tokens * BATCH_SIZE))
+        if args.benchmark:
+            print_("avg generate len per sentence: {}".format(num_gen_tokens / target_steps / BATCH_SIZE))
+        if step < 5:
+            total_time, num_gen_tokens, target_steps = 0.0, 0, 0
+        if use_tp:
+            dist.barrier()
+    print_(f"Final tokens per second :{num_gen_tokens / total_time}")
+    return num_gen_tokens / total_time
+
+
+def selfspec_main(kind: str, argv=None):
+    """kind: 'SnapKV' | 'StreamingLLM' -- tests/<kind>/selfspec_benchmark.py."""
+    parser = argparse.ArgumentParser(description='Process model configuration and partitions.')
+    _common(parser)
+    args = parser.parse_args(argv)
+    assert args.prefix_len < args.max_len
+    assert (args.max_len + 127) // 128 == args.prefix_len // 128 + 1
+    assert (args.draft_budget - 1) % 128 == 0
+    if kind == "SnapKV":
+        assert (args.prefix_len - args.window_size) % 128 == 0
+    DEVICE = _device()
+    use_tp = len(args.rank_group) > 1
+    global_group = None
+    rank = 0
+    print_ = builtins.print
+    if use_tp:
+        from .Engine.tp import init_dist
+        rank, global_group = init_dist()
+        if rank != args.rank_group[0]:
+            print_ = lambda *a, **k: None
+        DEVICE = f"cuda:{rank}" if torch.cuda.is_available() else "cpu"
+    setup_seed(args.seed)
+    print_(f"Using device={DEVICE}")
+    MAX_LEN_TARGET, BATCH_SIZE, DTYPE = args.max_len, args.B, torch.bfloat16
+    streaming = kind == "StreamingLLM"
+    if streaming:
+        from .Engine.StreamingLLM.backend import LMBackend
+        engine = LMBackend(dtype=DTYPE, device=DEVICE, dec_len=args.gamma + 1)
+    else:
+        from .Engine.SnapKV.backend import LMBackend
+        engine = LMBackend(dtype=DTYPE, device=DEVICE, dec_len=args.gamma + 1, draft_dec_len=1)
+    engine.load_model(args.model, use_tp=use_tp, rank_group=args.rank_group, group=global_group)
+    if args.compile:
+        engine.compile()
+    if streaming:
+        engine.setup_caches(max_batch_size=BATCH_SIZE, max_seq_length=MAX_LEN_TARGET, draft_budget=args.draft_budget)
+    else:
+        engine.setup_caches(max_batch_size=BATCH_SIZE, max_seq_length=MAX_LEN_TARGET, draft_budget=args.draft_budget,
+                            window_size=args.window_size)
+    tokenizer = load_tokenizer(args.model_name)
+    eot_1, eot_2 = _eot(tokenizer)
+    print_(f"eot_1: {eot_1}, eot_2: {eot_2}")
+    dataset = _dataset(args, tokenizer, engine.model.tok_embeddings.weight.shape[0])
+    dataloader = DataLoader(dataset, batch_size=BATCH_SIZE, shuffle=False, drop_last=True)
+    num_eval_steps = min(10, len(dataloader))
+    total_time, num_gen_tokens, target_steps = 0.0, 0, 0
+    for step, batch in enumerate(dataloader):
+        if step >= num_eval_steps:
+            break
+        input_ids = batch[0].to(DEVICE)
+        st, dt = harness.run_selfspec_batch(engine, input_ids, args.gamma, MAX_LEN_TARGET, eot_1, eot_2, streaming)
+        total_time += dt
+        target_steps += st.iters
+        num_gen_tokens += int(st.num_nodes.sum() - (input_ids.shape[1] + 1) * BATCH_SIZE)
+        if args.printoutput:
+            for i in range(BATCH_SIZE):
+                print_("Sequence ", i)
+                print_(tokenizer.decode(st.output[i, args.prefix_len:st.num_nodes[i]]))
+        print_("total time :{:.5f}s, time per iter :{:.5f}s, decoding step: {}, large model step: {}".format(
+            total_time, total_time / target_steps, num_gen_tokens, target_steps))
+        if args.benchmark:
+            print_("avg generate len per sentence: {}".format(num_gen_tokens / target_steps / BATCH_SIZE))
+        if step < 5:
+            total_time, num_gen_tokens, target_steps = 0.0, 0, 0
+        if use_tp:
+            dist.barrier()
+    print_(f"Final tokens per second :{num_gen_tokens / total_time}")
+    return num_gen_tokens / total_time
+
+
+def baseline_main(argv=None):
+    """tests/baseline_benchmark.py: the autoregressive denominator of every speedup figure."""
+    parser = argparse.ArgumentParser(description='Process model configuration and partitions.')
+    _common(parser, spec=False)
+    args = parser.parse_args(argv)
+    assert args.max_len % 128 == 0
+    DEVICE = _device()
+    use_tp = len(args.rank_group) > 1
+    global_group = None
+    rank = 0
+    print_ = builtins.print
+    if use_tp:
+        from .Engine.tp import init_dist
+        rank, global_group = init_dist()
+        if rank != args.rank_group[0]:
+            print_ = lambda *a, **k: None
+        DEVICE = f"cuda:{rank}" if torch.cuda.is_available() else "cpu"
+    setup_seed(args.seed)
+    print_(f"Using device={DEVICE}")
+    from .Engine.SnapKV.backend import LMBackend
+    engine = LMBackend(dtype=torch.bfloat16, device=DEVICE)
+    engine.load_model(args.model, use_tp=use_tp, rank_group=args.rank_group, group=global_group)
+    if args.compile:
+        engine.compile()
+    engine.setup_caches(max_batch_size=args.B, max_seq_length=args.max_len)
+    tokenizer = load_tokenizer(args.model_name)
+    eot_1, eot_2 = _eot(tokenizer)
+    print_(f"eot_1: {eot_1}, eot_2: {eot_2}")
+    dataset = _dataset(args, tokenizer, engine.model.tok_embeddings.weight.shape[0])
+    dataloader = DataLoader(dataset, batch_size=args.B, shuffle=False, drop_last=True)
+    num_eval_steps = min(10, len(dataloader))
+    total_time, model_steps = 0.0, 0
+    for step, batch in enumerate(dataloader):
+        if step >= num_eval_steps:
+            break
+        input_ids = batch[0].to(DEVICE)
+        output, steps, dt = harness.run_baseline_batch(engine, input_ids, args.max_len, eot_1, eot_2)
+        total_time += dt
+        model_steps += steps
+        if args.printoutput:
+            for i in range(args.B):
+                print_(tokenizer.decode(output[i, args.prefix_len:]))
+        print_(f"Tokens per second :{args.B * (model_steps / total_time)}")
+        if step < 5:
+            total_time, model_steps = 0.0, 0
+        if use_tp:
+            dist.barrier()
+    print_(f"Final tokens per second :{args.B * (model_steps / total_time)}")
+    return args.B * (model_steps / total_time)

@@ -46,16 +46,26 @@ def new_state(B, gamma, out_cols, device, input_ids=None):
                    double_buffer=torch.zeros((B, 2), dtype=torch.long, device=device),
                    cachelens_update=torch.ones(B, dtype=torch.long, device=device),
                    flags=torch.zeros(2, dtype=torch.int32, device=device),
-                   flags_host=torch.zeros(2, dtype=torch.int32).pin_memory())
+                   flags_host=(torch.zeros(2, dtype=torch.int32).pin_memory() if torch.device(device).type == "cuda"
+                               else torch.zeros(2, dtype=torch.int32)))
     if input_ids is not None:
         st.output[:, :input_ids.shape[1]] = input_ids
         st.num_nodes += input_ids.shape[1]
     return st
 
 
+def _sync(t):
+    if t.is_cuda:
+        torch.cuda.synchronize(t.device)
+
+
 def _read_flags(st: LoopState):
-    st.flags_host.copy_(st.flags, non_blocking=True)
-    torch.cuda.current_stream().synchronize()
+    """The one host read of an iteration: (terminal, next_double)."""
+    if st.flags.is_cuda:
+        st.flags_host.copy_(st.flags, non_blocking=True)
+        torch.cuda.current_stream().synchronize()
+    else:
+        st.flags_host.copy_(st.flags)
     return bool(st.flags_host[0]), bool(st.flags_host[1])
 
 
@@ -71,15 +81,24 @@ def _draft_round(step_fn, st: LoopState, gamma, next_double):
 
 
 def longspec_iteration(engine, draft, st: LoopState, gamma, eot_1, eot_2, max_nodes, next_double,
-                       forced_accept=None):
+                       forced_accept=None, bcast=None):
     """One iteration of the longspec loop: gamma draft steps, one verify, the fused accept/rollback.
-    Returns (terminal, next_double)."""
-    _draft_round(lambda ids, cu: draft.inference(ids, cachelen_update=cu), st, gamma, next_double)
+    Returns (terminal, next_double).
+
+    Tensor parallel (tests/SnapKV/longspec_benchmark.py:163-189): `draft` is None on ranks outside the draft
+    sub-group; when the draft group is smaller than the target group the gamma draft tokens are broadcast from
+    `bcast = (src_rank, group)` before the verify.  Every rank runs the (replicated, all-integer) accept kernel."""
+    if draft is not None:
+        _draft_round(lambda ids, cu: draft.inference(ids, cachelen_update=cu), st, gamma, next_double)
+    if bcast is not None:
+        import torch.distributed as dist
+        dist.broadcast(st.tokens_buffer, src=bcast[0], group=bcast[1])
     target_tokens = engine.inference(st.tokens_buffer)
     if forced_accept is not None:
         target_tokens = _force_accept(st.tokens_buffer, target_tokens, forced_accept, gamma)
     ops.accept_rollback(st.tokens_buffer, target_tokens, st.output, st.num_nodes, engine.cachelens,
-                        engine.paged_kv_last_page_len, draft.cachelens, draft.paged_kv_last_page_len, gamma,
+                        engine.paged_kv_last_page_len, draft.cachelens if draft is not None else None,
+                        draft.paged_kv_last_page_len if draft is not None else None, gamma,
                         gamma, gamma, eot_1, eot_2, max_nodes, st.accept_nums, st.bonus, st.double_buffer,
                         st.cachelens_update, st.flags)
     st.iters += 1
@@ -124,21 +143,24 @@ def _force_accept(tokens_buffer, target_tokens, forced_accept, gamma):
 
 
 def run_longspec_batch(engine, draft, input_ids, gamma, max_len, eot_1, eot_2, forced_accept_fn=None,
-                       trace_fn=None):
+                       trace_fn=None, bcast=None, barrier=None):
     """A whole batch: prefill both models, loop until termination.  Returns (state, seconds in the loop)."""
     B, S = input_ids.shape
     st = new_state(B, gamma, max_len + 1, input_ids.device, input_ids)
     st.tokens_buffer[:, :1] = engine.encode(input_ids=input_ids)[:, -1:]
-    draft.encode(input_ids=input_ids)
-    torch.cuda.synchronize()
+    if draft is not None:
+        draft.encode(input_ids=input_ids)
+    if barrier is not None:
+        barrier()
+    _sync(input_ids)
     t0 = time.perf_counter()
     terminal, nd = False, False
     while not terminal:
         fa = forced_accept_fn(st) if forced_accept_fn is not None else None
-        terminal, nd = longspec_iteration(engine, draft, st, gamma, eot_1, eot_2, S + 80, nd, fa)
+        terminal, nd = longspec_iteration(engine, draft, st, gamma, eot_1, eot_2, S + 80, nd, fa, bcast)
         if trace_fn is not None:
             trace_fn(st)
-    torch.cuda.synchronize()
+    _sync(input_ids)
     return st, time.perf_counter() - t0
 
 
@@ -149,7 +171,7 @@ def run_selfspec_batch(engine, input_ids, gamma, max_len, eot_1, eot_2, streamin
     st.tokens_buffer[:, :1] = engine.encode(input_ids=input_ids)[:, -1:]
     if streaming:
         engine.draft_encode(input_ids=input_ids)
-    torch.cuda.synchronize()
+    _sync(input_ids)
     t0 = time.perf_counter()
     terminal, nd = False, False
     while not terminal:
@@ -157,7 +179,7 @@ def run_selfspec_batch(engine, input_ids, gamma, max_len, eot_1, eot_2, streamin
         terminal, nd = selfspec_iteration(engine, st, gamma, eot_1, eot_2, S + 80, nd, streaming, fa)
         if trace_fn is not None:
             trace_fn(st)
-    torch.cuda.synchronize()
+    _sync(input_ids)
     return st, time.perf_counter() - t0
 
 
@@ -166,7 +188,7 @@ def run_baseline_batch(engine, input_ids, max_len, eot_1, eot_2, check_eot_every
     output = input_ids.clone()
     next_tokens = engine.encode(input_ids=input_ids)[:, -1:]
     output = torch.cat((output, next_tokens), dim=-1)
-    torch.cuda.synchronize()
+    _sync(input_ids)
     t0 = time.perf_counter()
     steps = 0
     terminate = False
@@ -177,5 +199,5 @@ def run_baseline_batch(engine, input_ids, max_len, eot_1, eot_2, check_eot_every
         if steps % check_eot_every == 0:
             last = next_tokens[:, -1]
             terminate = bool(((last == eot_1) | (last == eot_2)).any())
-    torch.cuda.synchronize()
+    _sync(input_ids)
     return output, steps, time.perf_counter() - t0

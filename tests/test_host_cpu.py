@@ -1,0 +1,298 @@
+"""CPU tests (no GPU): the C-ABI surface, and the product's HOST logic -- back-end page-table state machines,
+model wiring, decode loops, CLI entry points, TP sharding over gloo (world_size 2) -- run with the device ops
+replaced by oracle stand-ins (tests/cpu_ops.py) and compared bit-exactly with the traces recorded from the real
+reference scripts (tests/golden/run_*.json)."""
+import os
+import re
+import subprocess
+import sys
+import tempfile
+from pathlib import Path
+
+import pytest
+import torch
+
+from tests import cpu_ops
+from tests import golden_cfg as gc
+
+ROOT = Path(__file__).resolve().parents[1]
+
+
+# ------------------------------------------------------------------ C ABI
+def test_library_exports_every_declared_symbol():
+    """include/magicdec_hip.h <-> libmagicdec_hip.so <-> magicdec_amd/_lib.py agree (no compute calls)."""
+    header = (ROOT / "include" / "magicdec_hip.h").read_text()
+    declared = set(re.findall(r"\b(md_[a-z0-9_]+)\s*\(", header))
+    from magicdec_amd import _lib
+    assert declared == set(_lib.EXPORTED_SYMBOLS), declared ^ set(_lib.EXPORTED_SYMBOLS)
+    lib = _lib.load()
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.md_abi_version() == _lib.ABI_VERSION
+    assert lib.md_last_error_string() is not None
+
+
+def test_host_side_rope_table_matches_oracle():
+    import ctypes
+    from magicdec_amd import _lib
+    from oracle import flashinfer_ref as fr
+    lib = _lib.load()
+    for (mp, D, theta, scale, lo, hi, old) in [(512, 64, 10000.0, 1.0, None, None, None),
+                                               (2048, 128, 500000.0, 8.0, 1.0, 4.0, 8192)]:
+        host = torch.empty(mp, D // 2, 2)
+        rc = lib.md_rope_fill_table_host(ctypes.c_void_p(host.data_ptr()), mp, D, theta, scale, lo or 0.0, hi or 0.0,
+                                         float(old or 0))
+        assert rc == 0
+        assert torch.equal(host, fr.rope_table(mp, D, theta, scale, lo, hi, old))
+
+
+def test_ops_refuse_cpu_tensors_and_bad_arguments():
+    """No CPU fallback: device ops raise on CPU tensors; the C side validates shapes and reports a message."""
+    import ctypes
+    from magicdec_amd import _lib, ops
+    x = torch.zeros(4, 64, dtype=torch.bfloat16)
+    with pytest.raises(ValueError):
+        ops.rmsnorm(x, torch.ones(64, dtype=torch.bfloat16), 1e-5)
+    lib = _lib.load()
+    rc = lib.md_paged_attn(None, 0, None, None, None, None, None, None, 1, 1, 8, 2, 128, 128, 1, 1.0, 1, None, 0, None)
+    assert rc == -1 and b"null pointer" in lib.md_last_error_string()
+    p = ctypes.c_void_p(256)
+    rc = lib.md_paged_attn(p, 1024, p, p, p, p, p, p, 1, 1, 8, 2, 96, 128, 1, 1.0, 1, None, 0, None)
+    assert rc == -2 and b"head_dim" in lib.md_last_error_string()
+
+
+# ------------------------------------------------------------------ host logic vs the reference's own traces
+@pytest.fixture()
+def cpu_ops_patched(monkeypatch):
+    cpu_ops.install(monkeypatch)
+    cpu_ops.TOPK_REPLAY.update(table=None, pos=0)
+    yield
+    cpu_ops.TOPK_REPLAY.update(table=None, pos=0)
+
+
+@pytest.fixture(scope="module")
+def ckpt_dir():
+    from magicdec_amd.Engine import model_core
+    d = tempfile.mkdtemp(prefix="md_ckpt_")
+    for name in gc.TINY:
+        cfg, sd = gc.tiny(name)
+        os.makedirs(os.path.join(d, name), exist_ok=True)
+        torch.save(sd, os.path.join(d, name, "model.pth"))
+        model_core.transformer_configs[name] = dict(
+            block_size=4096, n_layer=cfg.n_layer, n_head=cfg.n_head, n_local_heads=cfg.n_local_heads, dim=cfg.dim,
+            intermediate_size=cfg.intermediate_size, vocab_size=cfg.vocab_size, rope_base=cfg.rope_base,
+            scaling_factor=cfg.scaling_factor, high_freq_factor=cfg.high_freq_factor,
+            low_freq_factor=cfg.low_freq_factor, original_max_position_embeddings=cfg.original_max_position_embeddings)
+    return Path(d)
+
+
+class Tracer:
+    """Records the product back-end calls in the same format as oracle/gen_golden.py's tracer."""
+    ATTRS = ["cachelens", "paged_kv_last_page_len", "paged_kv_indptr", "draft_cachelens", "draft_paged_kv_last_page_len",
+             "draft_paged_kv_indptr"]
+
+    def __init__(self, eng, cls, log, fns):
+        self.__dict__.update(eng=eng, cls=cls, log=log, fns=fns)
+
+    def __getattr__(self, name):
+        attr = getattr(self.eng, name)
+        if name not in self.fns:
+            return attr
+
+        def call(*a, **kw):
+            ids = a[0] if a else kw["input_ids"]
+            out = attr(*a, **kw)
+            rec = dict(cls=self.cls, fn=name, inp=ids.tolist() if ids.shape[1] <= 8 else [int(ids.shape[1])],
+                       out=out.tolist() if out.shape[1] <= 8 else out[:, -1:].tolist())
+            if kw.get("cachelen_update") is not None:
+                rec["cachelen_update"] = kw["cachelen_update"].flatten().tolist()
+            for at in self.ATTRS:
+                if getattr(self.eng, at, None) is not None:
+                    rec[at] = getattr(self.eng, at).tolist()
+            self.log.append(rec)
+            return out
+        return call
+
+    def __setattr__(self, k, v):
+        setattr(self.eng, k, v)
+
+
+def _compare(trace, ref):
+    assert len(trace) == len(ref), (len(trace), len(ref))
+    for a, b in zip(trace, ref):
+        assert (a["cls"], a["fn"]) == (b["cls"], b["fn"])
+        for key in ("inp", "out", "cachelen_update", *Tracer.ATTRS):
+            if key in b:
+                assert a.get(key) == b[key], (a["cls"], a["fn"], key, a.get(key), b[key])
+
+
+@pytest.mark.parametrize("kind,gamma", [("longspec_snapkv", 3), ("longspec_snapkv_rej", 1), ("longspec_stream", 3)])
+def test_product_longspec_host_logic_matches_reference_trace(kind, gamma, cpu_ops_patched, ckpt_dir):
+    from magicdec_amd import harness
+    from magicdec_amd.Engine.SnapKV.backend import LMBackend
+    j = gc.load_json(f"run_{kind}.json")
+    eng = LMBackend(dtype=torch.bfloat16, device="cpu", dec_len=gamma + 1)
+    eng.load_model(ckpt_dir / "tinytgt" / "model.pth", use_tp=False)
+    eng.setup_caches(max_batch_size=gc.B, max_seq_length=gc.MAX_LEN)
+    if "snapkv" in kind:
+        from magicdec_amd.Engine.SnapKV.backend_draft import LMBackend_Draft
+        drf = LMBackend_Draft(dtype=torch.bfloat16, device="cpu", draft_budget=gc.BUDGET)
+        drf.load_model(ckpt_dir / ("tinydrf" if kind.endswith("rej") else "tinytgt") / "model.pth", use_tp=False)
+        drf.setup_caches(max_batch_size=gc.B, max_seq_length=gc.MAX_LEN, draft_budget=gc.BUDGET)
+        cpu_ops.TOPK_REPLAY.update(table=j["snapkv_topk"], pos=0)
+        dcls = "SnapKV.LMBackend_Draft"
+    else:
+        from magicdec_amd.Engine.StreamingLLM.backend_draft import LMBackend_Draft
+        drf = LMBackend_Draft(dtype=torch.bfloat16, device="cpu")
+        drf.load_model(ckpt_dir / "tinytgt" / "model.pth", use_tp=False)
+        drf.setup_caches(max_batch_size=gc.B, draft_budget=gc.BUDGET)
+        dcls = "StreamingLLM.LMBackend_Draft"
+    log = []
+    te = Tracer(eng, "SnapKV.LMBackend", log, ("encode", "inference"))
+    td = Tracer(drf, dcls, log, ("encode", "inference"))
+    last = None
+    for ids in gc.synthetic_batches():
+        last, _ = harness.run_longspec_batch(te, td, ids, gamma, gc.MAX_LEN, gc.EOT_1, gc.EOT_2)
+    _compare(log, j["trace"])
+    assert last.output.tolist() == j["final"]["output"]
+    assert last.num_nodes.tolist() == j["final"]["num_nodes"]
+
+
+@pytest.mark.parametrize("kind", ["selfspec_snapkv", "selfspec_stream"])
+def test_product_selfspec_host_logic_matches_reference_trace(kind, cpu_ops_patched, ckpt_dir):
+    from magicdec_amd import harness
+    j = gc.load_json(f"run_{kind}.json")
+    streaming = kind.endswith("stream")
+    if streaming:
+        from magicdec_amd.Engine.StreamingLLM.backend import LMBackend
+        eng = LMBackend(dtype=torch.bfloat16, device="cpu", dec_len=gc.GAMMA + 1)
+        cls = "StreamingLLM.LMBackend"
+    else:
+        from magicdec_amd.Engine.SnapKV.backend import LMBackend
+        eng = LMBackend(dtype=torch.bfloat16, device="cpu", dec_len=gc.GAMMA + 1, draft_dec_len=1)
+        cls = "SnapKV.LMBackend"
+        cpu_ops.TOPK_REPLAY.update(table=j["snapkv_topk"], pos=0)
+    eng.load_model(ckpt_dir / "tinytgt" / "model.pth", use_tp=False)
+    eng.setup_caches(max_batch_size=gc.B, max_seq_length=gc.MAX_LEN, draft_budget=gc.BUDGET)
+    log = []
+    te = Tracer(eng, cls, log, ("encode", "draft_encode", "speculate", "verify"))
+    last = None
+    for ids in gc.synthetic_batches():
+        last, _ = harness.run_selfspec_batch(te, ids, gc.GAMMA, gc.MAX_LEN, gc.EOT_1, gc.EOT_2, streaming)
+    _compare(log, j["trace"])
+    assert last.output.tolist() == j["final"]["output"]
+    assert last.num_nodes.tolist() == j["final"]["num_nodes"]
+
+
+def test_product_baseline_host_logic_matches_reference_trace(cpu_ops_patched, ckpt_dir):
+    from magicdec_amd import harness
+    from magicdec_amd.Engine.SnapKV.backend import LMBackend
+    j = gc.load_json("run_baseline.json")
+    eng = LMBackend(dtype=torch.bfloat16, device="cpu")
+    eng.load_model(ckpt_dir / "tinytgt" / "model.pth", use_tp=False)
+    eng.setup_caches(max_batch_size=gc.B, max_seq_length=gc.MAX_LEN)
+    log = []
+    te = Tracer(eng, "SnapKV.LMBackend", log, ("encode", "inference"))
+    out = None
+    for ids in gc.synthetic_batches():
+        out, _, _ = harness.run_baseline_batch(te, ids, gc.MAX_LEN, gc.EOT_1, gc.EOT_2)
+    _compare(log, j["trace"])
+    assert out.tolist() == j["final"]["output"]
+
+
+def test_model_config_lookup_and_cli_asserts():
+    from magicdec_amd.Engine.model_core import ModelArgs
+    a = ModelArgs.from_name("Meta-Llama-3.1-8B")
+    assert (a.n_layer, a.n_head, a.n_local_heads, a.dim, a.head_dim, a.scaling_factor) == (32, 32, 8, 4096, 128, 8)
+    b = ModelArgs.from_name("Llama-3.2-1B")
+    assert (b.n_layer, b.n_local_heads, b.head_dim, b.scaling_factor) == (16, 8, 64, 32)
+    assert ModelArgs.from_name("llama-68m").dim == 768
+    from magicdec_amd.cli import longspec_main
+    with pytest.raises(AssertionError):     # prefix that is not window + k*128 (tests/SnapKV/longspec_benchmark.py:45)
+        longspec_main("SnapKV", ["--B", "1", "--prefix_len", "400", "--max_len", "512", "--draft_budget", "129",
+                                 "--rank_group", "0", "--draft_rank_group", "0"])
+
+
+# ------------------------------------------------------------------ tensor parallel over gloo, world_size 2
+TP_WORKER = r'''
+import os, sys, json, torch
+sys.path.insert(0, os.environ["MD_ROOT"])
+import torch.distributed as dist
+from pathlib import Path
+from tests import cpu_ops, golden_cfg as gc
+from oracle import magicdec_ref as mr, harness_ref as hr
+cpu_ops.install()
+from magicdec_amd import harness
+from magicdec_amd.Engine import model_core
+from magicdec_amd.Engine.tp import init_dist
+from magicdec_amd.Engine.SnapKV.backend import LMBackend
+from magicdec_amd.Engine.StreamingLLM.backend_draft import LMBackend_Draft
+ck = Path(os.environ["MD_CKPT"])
+for name in gc.TINY:
+    cfg, _ = gc.tiny(name)
+    model_core.transformer_configs[name] = dict(block_size=4096, n_layer=cfg.n_layer, n_head=cfg.n_head,
+        n_local_heads=cfg.n_local_heads, dim=cfg.dim, intermediate_size=cfg.intermediate_size, vocab_size=cfg.vocab_size,
+        rope_base=cfg.rope_base, scaling_factor=cfg.scaling_factor, high_freq_factor=cfg.high_freq_factor,
+        low_freq_factor=cfg.low_freq_factor, original_max_position_embeddings=cfg.original_max_position_embeddings)
+draft_ranks = [int(x) for x in os.environ["MD_DRAFT_RANKS"].split(",")]
+rank, group, dgroup = init_dist(draft_ranks)
+world = dist.get_world_size()
+eng = LMBackend(dtype=torch.bfloat16, device="cpu", dec_len=gc.GAMMA + 1)
+eng.load_model(ck / "tinytgt" / "model.pth", use_tp=True, rank_group=list(range(world)), group=group)
+eng.setup_caches(max_batch_size=gc.B, max_seq_length=gc.MAX_LEN)
+drf = None
+if rank in draft_ranks:
+    drf = LMBackend_Draft(dtype=torch.bfloat16, device="cpu")
+    drf.load_model(ck / "tinytgt" / "model.pth", use_tp=len(draft_ranks) > 1, rank_group=draft_ranks, group=dgroup)
+    drf.setup_caches(max_batch_size=gc.B, draft_budget=gc.BUDGET)
+bcast = (draft_ranks[0], group) if len(draft_ranks) != world else None
+ids = gc.synthetic_batches()[0]
+st, _ = harness.run_longspec_batch(eng, drf, ids, gc.GAMMA, gc.MAX_LEN, gc.EOT_1, gc.EOT_2, bcast=bcast, barrier=dist.barrier)
+# oracle with the same sharding and the same gloo all-reduce
+cfg, sd = gc.tiny("tinytgt")
+ssd, lcfg = mr.shard_state_dict(sd, cfg, rank, world)
+o_t = mr.RefEngine("target", lcfg, ssd, gc.B, gc.MAX_LEN, group=group, rank=rank, world=world)
+if rank in draft_ranks:
+    if len(draft_ranks) > 1:
+        dsd, dcfg = mr.shard_state_dict(sd, cfg, draft_ranks.index(rank), len(draft_ranks))
+        o_d = mr.RefEngine("stream_draft", dcfg, dsd, gc.B, 0, gc.BUDGET, group=dgroup, rank=draft_ranks.index(rank), world=len(draft_ranks))
+    else:
+        o_d = mr.RefEngine("stream_draft", cfg, sd, gc.B, 0, gc.BUDGET)
+else:
+    o_d = None
+res = dict(rank=rank, output=st.output.tolist(), num_nodes=st.num_nodes.tolist(), iters=st.iters,
+           cachelens=eng.cachelens.tolist(), local_heads=[eng.model.config.n_head, eng.model.config.n_local_heads])
+if o_d is not None and len(draft_ranks) == world:
+    ref = hr.longspec_batch(o_t, o_d, ids, gc.GAMMA, gc.MAX_LEN, gc.EOT_1, gc.EOT_2)
+    res["oracle_output"] = ref["output"].tolist()
+    res["oracle_num_nodes"] = ref["num_nodes"].tolist()
+json.dump(res, open(os.path.join(os.environ["MD_OUT"], f"rank{rank}.json"), "w"))
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+@pytest.mark.parametrize("draft_ranks", ["0,1", "0"])
+def test_tensor_parallel_gloo_world2(draft_ranks, ckpt_dir):
+    """TP=2 over gloo: both ranks end with identical replicated state; with draft TP == target TP the run equals the
+    oracle sharded the same way (same gloo bf16 sum all-reduce) bit for bit; with a 1-rank draft sub-group the
+    gamma tokens are broadcast (tests/SnapKV/longspec_benchmark.py:189)."""
+    import json
+    out = tempfile.mkdtemp(prefix="md_tp_")
+    script = os.path.join(out, "worker.py")
+    Path(script).write_text(TP_WORKER)
+    port = 29500 + (os.getpid() % 2000) + (7 if draft_ranks == "0" else 0)
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, LOCAL_RANK=str(r), LOCAL_WORLD_SIZE="2", RANK=str(r), WORLD_SIZE="2",
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), MD_ROOT=str(ROOT), MD_CKPT=str(ckpt_dir), MD_OUT=out,
+                   MD_DRAFT_RANKS=draft_ranks, OMP_NUM_THREADS="2")
+        procs.append(subprocess.Popen([sys.executable, script], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    logs = [p.communicate(timeout=900)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(logs)
+    r0, r1 = (json.load(open(os.path.join(out, f"rank{r}.json"))) for r in range(2))
+    assert r0["local_heads"] == [4, 1] and r1["local_heads"] == [4, 1]
+    assert r0["output"] == r1["output"] and r0["num_nodes"] == r1["num_nodes"] and r0["cachelens"] == r1["cachelens"]
+    assert r0["iters"] == r1["iters"] and r0["iters"] > 3
+    if draft_ranks == "0,1":
+        assert r0["output"] == r0["oracle_output"] and r0["num_nodes"] == r0["oracle_num_nodes"]
