@@ -264,6 +264,13 @@ def main():
     attn_bytes = B * L_kv * KH_loc * D * 2 * 2 + 2 * B * (G + 1) * H_loc * D * 2
     achieved = attn_bytes / (attn_ms * 1e-3) / 1e9 if attn_ms > 0 else 0.0
 
+    traffic = None
+    pmc_path = os.path.join(ROOT, "profiles", "r01_verify_attn_pmc.json")
+    if args.workload == "cfg3" and world == 1 and os.path.exists(pmc_path):
+        # HBM bytes per launch from the committed rocprofv3 PMC passes of this kernel at this layer shape
+        # (FETCH_SIZE x2 + WRITE_SIZE, see the file); PMC collection cannot run inside bench.py itself
+        with open(pmc_path) as f:
+            traffic = json.load(f)["traffic_bytes_per_launch"]
     line = {
         "metric": "decode tokens/s/node + speedup vs autoregressive, Llama-3.1-8B B=64 prefix=16K",
         "value": round(value, 2), "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -283,7 +290,7 @@ def main():
         "prefill_s": round(t_pf, 2), "load_s": round(t_load, 2),
         "roofline": {"kernel": "paged_attn_kernel<128,1,false> (verify attention, md_paged_attn)", "bound": "hbm",
                      "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                      "bytes_per_launch": attn_bytes, "avg_launch_ms": round(attn_ms, 4), "launches_timed": n_attn},
     }
     if rank == 0 and not args.no_cpu_baseline and world == 1:
