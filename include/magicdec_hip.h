@@ -115,6 +115,9 @@ int md_rope_append(const void* q, const void* k, const void* v, int64_t q_row_st
  * ---------------------------------------------------------------------- */
 size_t md_paged_attn_workspace_bytes(int B, int n_max, int H, int KH, int D,
                                      int max_pages_per_req, int page_size);
+/* development knob (kernel tuning sweeps only): target number of workgroups of the split-KV decomposition;
+ * n <= 0 restores the default (256 = one per CU). Host, not thread-safe. */
+void md_debug_set_attn_target_wgs(int n);
 int md_paged_attn(const void* q, int64_t q_row_stride, const void* cache, void* out,
                   const int32_t* qo_indptr, const int32_t* page_indices,
                   const int32_t* page_indptr, const int32_t* last_page_len, int B, int n_max,

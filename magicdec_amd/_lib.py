@@ -28,6 +28,7 @@ _SIGNATURES = {
     "md_rope_fill_table_host": (c_int, [P, I, I, c_double, c_double, c_double, c_double, c_double]),
     "md_rope_append": (c_int, [P, P, P, L, L, L, P, P, P, I, I, I, I, I, P, I, P, P, P, P, P, P, P, P, I, P]),
     "md_paged_attn_workspace_bytes": (c_size_t, [I, I, I, I, I, I, I]),
+    "md_debug_set_attn_target_wgs": (None, [I]),
     "md_paged_attn": (c_int, [P, L, P, P, P, P, P, P, I, I, I, I, I, I, I, c_float, I, P, c_size_t, P]),
     "md_snapkv_workspace_bytes": (c_size_t, [I, I, I, I, I]),
     "md_snapkv_scores_offset": (c_size_t, [I, I, I, I, I]),

@@ -67,6 +67,16 @@ __device__ __forceinline__ bf16x4 lds_read_tr(const unsigned char* p) {
         (__attribute__((address_space(3))) bf16x4*)(p));
 }
 
+// decode/verify reads every K/V byte exactly once: non-temporal loads (+5 % of HBM peak measured); the prefill
+// variant re-reads a (request, kv head) stream from L2 by several workgroups, where nt costs bandwidth
+template <bool NT>
+__device__ __forceinline__ u32x4 ldg_stream(const u32x4* p) {
+    if constexpr (NT)
+        return __builtin_nontemporal_load(p);
+    else
+        return *p;
+}
+
 template <int D, int QT, bool SPLITQ>
 __global__ __launch_bounds__(256, 2) void paged_attn_kernel(const AttnParams p) {
     constexpr int CH = D / 8;     // 16-B chunks per K/V row
@@ -78,6 +88,9 @@ __global__ __launch_bounds__(256, 2) void paged_attn_kernel(const AttnParams p) 
     constexpr int K_BYTES = 32 * KROW;
     constexpr int WAVE_LDS = attn_wave_lds<D, QT>();
     constexpr int TSTEP = SPLITQ ? 1 : 4;
+    // two tiles of loads in flight per wave where the register budget allows it (256 VGPRs at 2 waves/SIMD)
+    constexpr bool DBUF = (QT == 1) || (D == 64);
+    constexpr int PF = (DBUF ? 2 : 1) * TSTEP;   // prefetch distance in tiles of this wave
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;
@@ -181,8 +194,10 @@ __global__ __launch_bounds__(256, 2) void paged_attn_kernel(const AttnParams p) 
     const int vra = (lc * 4 + (lq >> 2)) * 32 + (lq & 3) * 8;  // + nb*kVSub + kb*512
     const int goff = wrow * p.slot_stride + kvh * D + wch * 8;  // elements
 
-    u32x4 kreg[NL], vreg[NL];
-    auto issue = [&](int tt) {
+    // two tiles in flight per wavefront: register sets A and B alternate (2 x 16 KiB of loads outstanding while a
+    // tile is computed -- the loop is latency x bandwidth bound, not compute bound)
+    u32x4 kA[NL], vA[NL], kB[NL], vB[NL];
+    auto issue = [&](int tt, u32x4 (&kreg)[NL], u32x4 (&vreg)[NL]) {
         const int pos0 = tt * 32;
         const int page = pos0 / p.page_size;
         const int slot0 = pos0 - page * p.page_size;
@@ -191,16 +206,13 @@ __global__ __launch_bounds__(256, 2) void paged_attn_kernel(const AttnParams p) 
         const bf16_t* vb_ = kb_ + p.kv_half;
 #pragma unroll
         for (int j = 0; j < NL; ++j)
-            kreg[j] = *reinterpret_cast<const u32x4*>(kb_ + (int64_t)j * RPI * p.slot_stride);
+            kreg[j] = ldg_stream<!SPLITQ>(reinterpret_cast<const u32x4*>(kb_ + (int64_t)j * RPI * p.slot_stride));
 #pragma unroll
         for (int j = 0; j < NL; ++j)
-            vreg[j] = *reinterpret_cast<const u32x4*>(vb_ + (int64_t)j * RPI * p.slot_stride);
+            vreg[j] = ldg_stream<!SPLITQ>(reinterpret_cast<const u32x4*>(vb_ + (int64_t)j * RPI * p.slot_stride));
     };
 
-    int t = t_begin + (SPLITQ ? 0 : wave);
-    if (t < t_end) issue(t);
-
-    for (; t < t_end; t += TSTEP) {
+    auto process = [&](int t, u32x4 (&kreg)[NL], u32x4 (&vreg)[NL]) {
         const bool need_mask = (t * 32 + 31) > lo;
         if (need_mask) {
             // rows past the request's length may hold anything (even NaN): zero V so 0*V stays 0
@@ -212,7 +224,7 @@ __global__ __launch_bounds__(256, 2) void paged_attn_kernel(const AttnParams p) 
         for (int j = 0; j < NL; ++j) *reinterpret_cast<u32x4*>(ldsK + kw[j]) = kreg[j];
 #pragma unroll
         for (int j = 0; j < NL; ++j) *reinterpret_cast<u32x4*>(ldsV + vw[j]) = vreg[j];
-        if (t + TSTEP < t_end) issue(t + TSTEP);
+        if (t + PF < t_end) issue(t + PF, kreg, vreg);
         // same-wave LDS hand-off: LDS ops of one wave execute in order
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -287,6 +299,18 @@ __global__ __launch_bounds__(256, 2) void paged_attn_kernel(const AttnParams p) 
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
+    };
+
+    int t = t_begin + (SPLITQ ? 0 : wave);
+    if (t < t_end) issue(t, kA, vA);
+    if constexpr (DBUF) {
+        if (t + TSTEP < t_end) issue(t + TSTEP, kB, vB);
+        for (; t < t_end; t += 2 * TSTEP) {
+            process(t, kA, vA);
+            if (t + TSTEP < t_end) process(t + TSTEP, kB, vB);
+        }
+    } else {
+        for (; t < t_end; t += TSTEP) process(t, kA, vA);
     }
 
     // row sums live as per-lane partials over the 4 lane groups of a query
@@ -406,7 +430,10 @@ struct AttnPlan {
     int rows_cap;  // rows per item in the workspace (decode mode)
 };
 
-constexpr int kTargetWGs = 1024;  // 256 CUs x 2 workgroups/CU x 2 rounds
+// split-KV target: one 4-wave workgroup per CU measured best on MI355X for every TP shard shape of the verify
+// step (B=64, 16K: 81 % / 80 % / 75 % / 70 % of HBM peak at KH_local = 8 / 4 / 2 / 1 vs 77 / 77 / 72 / 47 % at 1024);
+// per-workgroup prologue/epilogue and the partial-result round trip dominate once a wave owns < ~30 tiles
+int g_target_wgs = 256;  // dev knob: md_debug_set_attn_target_wgs
 
 AttnPlan make_plan(int B, int n_max, int H, int KH, int max_pages, int page_size) {
     AttnPlan pl;
@@ -417,7 +444,7 @@ AttnPlan make_plan(int B, int n_max, int H, int KH, int max_pages, int page_size
         pl.qt = rows <= 16 ? 1 : 2;
         pl.n_qgroups = 1;
         const long max_tiles = (long)max_pages * page_size / 32;
-        long want = (kTargetWGs + (long)B * KH - 1) / ((long)B * KH);
+        long want = (g_target_wgs + (long)B * KH - 1) / ((long)B * KH);
         long cap = max_tiles / 16;  // >= 16 tiles (4 per wave) per workgroup
         if (cap < 1) cap = 1;
         if (want > cap) want = cap;
@@ -455,6 +482,8 @@ int launch_attn(const AttnParams& p, int grid, hipStream_t st) {
 }
 
 }  // namespace
+
+extern "C" void md_debug_set_attn_target_wgs(int n) { g_target_wgs = n > 0 ? n : 256; }
 
 extern "C" size_t md_paged_attn_workspace_bytes(int B, int n_max, int H, int KH, int D,
                                                 int max_pages_per_req, int page_size) {

@@ -6,9 +6,13 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from magicdec_amd import ops
 
 ap = argparse.ArgumentParser()
-for k, v in dict(B=64, S=16036, KH=8, H=32, D=128, n=4, iters=20, layers=2).items():
+for k, v in dict(B=64, S=16036, KH=8, H=32, D=128, n=4, iters=20, layers=2, wgs=0).items():
     ap.add_argument(f"--{k}", type=int, default=v)
 a = ap.parse_args()
+if a.wgs:
+    import ctypes
+    from magicdec_amd import _lib
+    _lib.load().md_debug_set_attn_target_wgs(ctypes.c_int(a.wgs))
 dev = "cuda"
 mp = (a.S + 127) // 128
 g = torch.Generator(device=dev).manual_seed(0)
@@ -32,4 +36,4 @@ torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / a.iters
 nbytes = a.B * a.S * a.KH * a.D * 2 * 2 + 2 * a.B * a.n * a.H * a.D * 2
 print(f"md_paged_attn B={a.B} S={a.S} KH={a.KH} H={a.H} D={a.D} n={a.n}: {ms:.4f} ms  {nbytes / ms / 1e6:.1f} GB/s  "
-      f"{nbytes / ms / 1e6 / 80:.2f}% of 8 TB/s  (alg bytes {nbytes})")
+      f"{nbytes / ms / 1e6 / 80:.2f}% of 8 TB/s  (alg bytes {nbytes}) wgs={a.wgs}")
