@@ -59,22 +59,29 @@ def parse():
                     help="capture decode steps into hipGraphs (engine.compile()); default: on for 1 GPU")
     ap.add_argument("--no-graphs", dest="graphs", action="store_false")
     ap.add_argument("--checkpoints", type=Path, default=Path("checkpoints"))
+    ap.add_argument("--draft-tp", type=int, default=4, help="size of the draft sub-group (reference README: 4 of 8)")
     return ap.parse_args()
+
+
+def _sync(dev):
+    if torch.device(dev).type == "cuda":
+        torch.cuda.synchronize()
 
 
 class AttnTimer:
     """HIP events around every md_paged_attn launch of the verify pass, recorded on the launching stream."""
 
-    def __init__(self):
+    def __init__(self, dev="cuda"):
         self.pairs = []
         self.enabled = False
+        self.cuda = torch.device(dev).type == "cuda"
 
     def wrap(self, model):
         timer = self
         orig = model._attend
 
         def timed(q_rot, cache, qo_indptr, tab, n):
-            if not timer.enabled:
+            if not (timer.enabled and timer.cuda):
                 return orig(q_rot, cache, qo_indptr, tab, n)
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s.record()
@@ -100,12 +107,21 @@ def truncated_geometric(alpha, gamma, shape, gen, device):
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)"
     assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
     torch.cuda.set_device(local_rank)
-    dev = f"cuda:{local_rank}"
+    line = run(args, f"cuda:{local_rank}")
+    if line is not None:
+        print(json.dumps(line), flush=True)
+
+
+def run(args, dev):
+    """The benchmark proper.  `dev` is a cuda device in production; tests/test_bench_cpu.py drives the same code on
+    "cpu" (gloo, device ops replaced by oracle stand-ins) to check the multi-rank control flow without a GPU."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    on_gpu = torch.device(dev).type == "cuda"
     os.environ.setdefault("LOCAL_WORLD_SIZE", str(world))
 
     from magicdec_amd import harness, _lib
@@ -113,16 +129,17 @@ def main():
     from magicdec_amd.Engine.SnapKV.backend import LMBackend
     from magicdec_amd.Engine.SnapKV.backend_draft import LMBackend_Draft
     from magicdec_amd.Engine.utils import setup_seed
-    _lib.load()
+    if on_gpu:
+        _lib.load()
     model_core.transformer_configs.setdefault(
-        "llama-68m-gqa", dict(block_size=2048, n_layer=2, n_head=12, n_local_heads=4, dim=768, intermediate_size=3072,
+        "llama-68m-gqa", dict(block_size=2048, n_layer=2, n_head=16, n_local_heads=4, dim=1024, intermediate_size=2048,
                               vocab_size=32000))
 
     tgt_name, drf_name, B, S, ML, BUDGET, G = WORKLOADS[args.workload]
     use_tp = world > 1
     group = draft_group = None
     rank_group = list(range(world))
-    draft_ranks = list(range(min(world, 4)))
+    draft_ranks = list(range(min(world, args.draft_tp)))
     if use_tp:
         from magicdec_amd.Engine.tp import init_dist
         _, group, draft_group = init_dist(draft_ranks)
@@ -141,12 +158,12 @@ def main():
         draft.setup_caches(max_batch_size=B, max_seq_length=ML, draft_budget=BUDGET)
     if args.graphs is None:
         # TP>1: RCCL collectives inside a captured graph could not be validated on the 1-GPU development box
-        args.graphs = (world == 1) and os.environ.get("MAGICDEC_NO_GRAPHS", "0") != "1"
+        args.graphs = on_gpu and (world == 1) and os.environ.get("MAGICDEC_NO_GRAPHS", "0") != "1"
     if args.graphs:
         engine.compile()
         if draft is not None:
             draft.compile()
-    timer = AttnTimer()
+    timer = AttnTimer(dev)
     timer.wrap(engine.model)
     t_load = time.time() - t_load
 
@@ -159,13 +176,13 @@ def main():
     eot_1, eot_2 = -1, -2      # synthetic ids carry no EOT semantics
 
     # ---- prefill (untimed, as in the reference)
-    torch.cuda.synchronize()
+    _sync(dev)
     t_pf = time.time()
     st = harness.new_state(B, G, ML + 1, dev, input_ids)
     st.tokens_buffer[:, :1] = engine.encode(input_ids=input_ids)[:, -1:]
     if draft is not None:
         draft.encode(input_ids=input_ids)
-    torch.cuda.synchronize()
+    _sync(dev)
     t_pf = time.time() - t_pf
     snap = {"e": (engine.cachelens.clone(), engine.paged_kv_last_page_len.clone())}
     if draft is not None:
@@ -187,7 +204,7 @@ def main():
     def barrier():
         if use_tp:
             dist.barrier()
-        torch.cuda.synchronize()
+        _sync(dev)
 
     bcast = (draft_ranks[0], group) if (use_tp and len(draft_ranks) != world) else None
 
@@ -220,7 +237,7 @@ def main():
         timer.enabled = False
         return dt, int(tokens.item())
 
-    gen = torch.Generator(device=dev).manual_seed(2024)
+    gen = torch.Generator(device=dev if on_gpu else "cpu").manual_seed(2024)
     forced = truncated_geometric(args.alpha, G, (args.warmup + args.steps, B), gen, dev)
     dt_replay, tok_replay = run_spec(args.warmup, args.steps, forced)
     if args.graphs:
@@ -295,11 +312,10 @@ def main():
     }
     if rank == 0 and not args.no_cpu_baseline and world == 1:
         line["cpu_baseline"] = cpu_baseline(tgt_name, drf_name, S, BUDGET, G, args.alpha)
-    if rank == 0:
-        print(json.dumps(line), flush=True)
     if use_tp:
         dist.barrier()
         dist.destroy_process_group()
+    return line if rank == 0 else None
 
 
 def cpu_baseline(tgt_name, drf_name, S, budget, gamma, alpha):

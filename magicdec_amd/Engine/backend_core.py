@@ -88,6 +88,8 @@ class _BackendBase:
     _loader = None
 
     def load_model(self, checkpoints, use_tp: bool, rank_group=None, group=None):
+        from .utils import enable_tuned_gemms
+        enable_tuned_gemms()
         self.model = type(self)._loader(checkpoint_path=checkpoints, device=self.device, precision=self.dtype,
                                         use_tp=use_tp, rank_group=rank_group, group=group)
 

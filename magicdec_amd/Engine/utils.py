@@ -12,6 +12,26 @@ import numpy as np
 import torch
 
 
+TUNED_GEMMS = Path(__file__).resolve().parent.parent / "tuned" / "gemm_gfx950.csv"
+
+
+def enable_tuned_gemms(path=None):
+    """Select the hipBLASLt / rocBLAS solutions recorded by tools/tune_gemms.py (PyTorch TunableOp, look-up only --
+    no tuning happens in the serving path).  hipBLASLt's default heuristic picks un-split tiles for the skinny
+    (M = 64..256) small-N projections of the decode step; the tuned table is 20-35 % faster on those.  Returns True
+    when the table was loaded (validators = library versions must match, else PyTorch ignores the file)."""
+    path = Path(path) if path is not None else TUNED_GEMMS
+    if not path.exists() or not torch.cuda.is_available():
+        return False
+    import tempfile
+
+    import torch.cuda.tunable as tunable
+    tunable.enable(True)
+    tunable.tuning_enable(False)
+    tunable.set_filename(str(Path(tempfile.gettempdir()) / "magicdec_tunableop_unused.csv"))   # never rewrite the table
+    return bool(tunable.read_file(str(path)))
+
+
 def setup_seed(seed):
     torch.manual_seed(seed)
     if torch.cuda.is_available():

@@ -1,0 +1,53 @@
+"""bench.py's control flow (single rank and torchrun-style 2 ranks over gloo) exercised on the CPU with the device ops
+replaced by oracle stand-ins: catches crashes in the multi-GPU path (draft sub-group, token broadcast, TP loaders,
+max-over-ranks timing, JSON contract) that cannot be run on the 1-GPU development boxes."""
+import json
+import os
+import subprocess
+import sys
+import tempfile
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parents[1]
+
+WORKER = r'''
+import os, sys, json
+sys.path.insert(0, os.environ["MD_ROOT"])
+from tests import cpu_ops
+cpu_ops.install()
+import bench
+sys.argv = ["bench.py", "--gpus", os.environ["WORLD_SIZE"], "--steps", "6", "--warmup", "2", "--workload", "tiny",
+            "--no-cpu-baseline", "--draft-tp", os.environ["MD_DRAFT_TP"]]
+args = bench.parse()
+line = bench.run(args, "cpu")
+if line is not None:
+    json.dump(line, open(os.environ["MD_OUT"], "w"))
+'''
+
+
+@pytest.mark.parametrize("world,draft_tp", [(1, 4), (2, 4), (2, 1)])
+def test_bench_control_flow_on_cpu(world, draft_tp):
+    """(2,1): the draft runs on rank 0 only -> rank 1 has no draft model and receives the tokens by broadcast, the
+    8-GPU layout of the reference's README (target TP8, draft TP4) in miniature."""
+    out = tempfile.mkdtemp(prefix="md_bench_")
+    script = os.path.join(out, "w.py")
+    Path(script).write_text(WORKER)
+    port = 29700 + (os.getpid() % 1500) + world * 3 + draft_tp
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, LOCAL_RANK=str(r), LOCAL_WORLD_SIZE=str(world), RANK=str(r), WORLD_SIZE=str(world),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), MD_ROOT=str(ROOT), MD_OUT=os.path.join(out, "line.json"), MD_DRAFT_TP=str(draft_tp),
+                   OMP_NUM_THREADS="2")
+        procs.append(subprocess.Popen([sys.executable, script], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                                      cwd=out))
+    logs = [p.communicate(timeout=1200)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(logs)
+    line = json.load(open(os.path.join(out, "line.json")))
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "speedup_vs_autoregressive"):
+        assert key in line, key
+    assert line["n_gpus"] == world and line["steps"] == 6 and line["value"] > 0
+    assert line["unit"] == "tokens/s" and line["higher_is_better"] is True and line["vs_baseline"] is None
+    assert set(line["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
