@@ -296,3 +296,46 @@ def test_tensor_parallel_gloo_world2(draft_ranks, ckpt_dir):
     assert r0["iters"] == r1["iters"] and r0["iters"] > 3
     if draft_ranks == "0,1":
         assert r0["output"] == r0["oracle_output"] and r0["num_nodes"] == r0["oracle_num_nodes"]
+
+
+# ------------------------------------------------------------------ checkpoint ingestion
+def test_hf_checkpoint_conversion_roundtrip():
+    """An HF-layout (half-split RoPE rows, separate q/k/v, sharded safetensors) copy of a tiny model converts to
+    exactly the state dict the Engine loads; layout facts as convert_hf_checkpoint.py:103-114,147-161."""
+    import json as _json
+    from safetensors.torch import save_file
+    from magicdec_amd.Engine import model_core
+    from magicdec_amd.convert_hf_checkpoint import convert_hf_checkpoint
+    cfg, sd = gc.tiny("tinydrf")
+    model_core.transformer_configs["tinydrf"] = dict(block_size=4096, n_layer=cfg.n_layer, n_head=cfg.n_head,
+                                                     n_local_heads=cfg.n_local_heads, dim=cfg.dim,
+                                                     intermediate_size=cfg.intermediate_size, vocab_size=cfg.vocab_size)
+    D, H, KH = cfg.head_dim, cfg.n_head, cfg.n_local_heads
+
+    def to_hf_rows(w, nh):      # inverse of the interleave: rows (h, r, half) -> (h, half, r)
+        return w.reshape(nh, D // 2, 2, -1).transpose(1, 2).reshape(nh * D, -1)
+    hf = {"model.embed_tokens.weight": sd["tok_embeddings.weight"], "model.norm.weight": sd["norm.weight"],
+          "lm_head.weight": sd["output.weight"]}
+    for i in range(cfg.n_layer):
+        p, h = f"layers.{i}.", f"model.layers.{i}."
+        q, k, v = sd[p + "attention.wqkv.weight"].split([H * D, KH * D, KH * D])
+        hf[h + "self_attn.q_proj.weight"] = to_hf_rows(q, H).contiguous()
+        hf[h + "self_attn.k_proj.weight"] = to_hf_rows(k, KH).contiguous()
+        hf[h + "self_attn.v_proj.weight"] = v.contiguous()
+        hf[h + "self_attn.o_proj.weight"] = sd[p + "attention.wo.weight"]
+        hf[h + "mlp.gate_proj.weight"] = sd[p + "feed_forward.w1.weight"]
+        hf[h + "mlp.up_proj.weight"] = sd[p + "feed_forward.w3.weight"]
+        hf[h + "mlp.down_proj.weight"] = sd[p + "feed_forward.w2.weight"]
+        hf[h + "input_layernorm.weight"] = sd[p + "attention_norm.weight"]
+        hf[h + "post_attention_layernorm.weight"] = sd[p + "ffn_norm.weight"]
+    d = Path(tempfile.mkdtemp(prefix="md_hf_")) / "tinydrf"
+    d.mkdir()
+    names = sorted(hf)
+    shards = {"model-00001-of-00002.safetensors": names[:len(names) // 2], "model-00002-of-00002.safetensors": names[len(names) // 2:]}
+    for fn, ks in shards.items():
+        save_file({k: hf[k].contiguous() for k in ks}, str(d / fn))
+    (d / "model.safetensors.index.json").write_text(_json.dumps({"weight_map": {k: fn for fn, ks in shards.items() for k in ks}}))
+    out = torch.load(convert_hf_checkpoint(d), weights_only=True)
+    assert set(out) == set(sd)
+    for k in sd:
+        assert torch.equal(out[k], sd[k]), k
