@@ -44,6 +44,8 @@ WORKLOADS = {
     "cfg3": ("Meta-Llama-3.1-8B", "Llama-3.2-1B", 64, 16032, 16128, 257, 3),
     "cfg3-small": ("Meta-Llama-3.1-8B", "Llama-3.2-1B", 8, 2080, 2176, 257, 3),
     "tiny": ("llama-68m-gqa", "llama-68m-gqa", 4, 416, 512, 129, 3),
+    # configs[1] of BASELINE.json: self-speculation, StreamingLLM draft cache (one model, two caches)
+    "cfg2": ("Meta-Llama-3.1-8B", None, 32, 8065, 8192, 257, 3),
 }
 
 
@@ -75,13 +77,14 @@ class AttnTimer:
         self.pairs = []
         self.enabled = False
         self.cuda = torch.device(dev).type == "cuda"
+        self.n_verify = 0      # only launches with this many query rows per request (gamma+1) are timed
 
     def wrap(self, model):
         timer = self
         orig = model._attend
 
         def timed(q_rot, cache, qo_indptr, tab, n):
-            if not (timer.enabled and timer.cuda):
+            if not (timer.enabled and timer.cuda and n == timer.n_verify):
                 return orig(q_rot, cache, qo_indptr, tab, n)
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s.record()
@@ -146,12 +149,19 @@ def run(args, dev):
     in_draft = rank in draft_ranks
     setup_seed(123)
 
+    selfspec = drf_name is None
     t_load = time.time()
-    engine = LMBackend(dtype=torch.bfloat16, device=dev, dec_len=G + 1)
-    engine.load_model(args.checkpoints / tgt_name / "model.pth", use_tp=use_tp, rank_group=rank_group, group=group)
-    engine.setup_caches(max_batch_size=B, max_seq_length=ML)
+    if selfspec:
+        from magicdec_amd.Engine.StreamingLLM.backend import LMBackend as SelfSpecBackend
+        engine = SelfSpecBackend(dtype=torch.bfloat16, device=dev, dec_len=G + 1)
+        engine.load_model(args.checkpoints / tgt_name / "model.pth", use_tp=use_tp, rank_group=rank_group, group=group)
+        engine.setup_caches(max_batch_size=B, max_seq_length=ML, draft_budget=BUDGET)
+    else:
+        engine = LMBackend(dtype=torch.bfloat16, device=dev, dec_len=G + 1)
+        engine.load_model(args.checkpoints / tgt_name / "model.pth", use_tp=use_tp, rank_group=rank_group, group=group)
+        engine.setup_caches(max_batch_size=B, max_seq_length=ML)
     draft = None
-    if in_draft:
+    if in_draft and not selfspec:
         draft = LMBackend_Draft(dtype=torch.bfloat16, device=dev, draft_budget=BUDGET)
         draft.load_model(args.checkpoints / drf_name / "model.pth", use_tp=len(draft_ranks) > 1,
                          rank_group=draft_ranks, group=draft_group)
@@ -164,6 +174,7 @@ def run(args, dev):
         if draft is not None:
             draft.compile()
     timer = AttnTimer(dev)
+    timer.n_verify = G + 1
     timer.wrap(engine.model)
     t_load = time.time() - t_load
 
@@ -182,9 +193,13 @@ def run(args, dev):
     st.tokens_buffer[:, :1] = engine.encode(input_ids=input_ids)[:, -1:]
     if draft is not None:
         draft.encode(input_ids=input_ids)
+    if selfspec:
+        engine.draft_encode(input_ids=input_ids)
     _sync(dev)
     t_pf = time.time() - t_pf
     snap = {"e": (engine.cachelens.clone(), engine.paged_kv_last_page_len.clone())}
+    if selfspec:
+        snap["s"] = (engine.draft_cachelens.clone(), engine.draft_paged_kv_last_page_len.clone())
     if draft is not None:
         snap["d"] = (draft.cachelens.clone(), draft.paged_kv_last_page_len.clone(),
                      draft.draft_paged_kv_last_page_len.clone())
@@ -193,6 +208,9 @@ def run(args, dev):
     def restore():
         engine.cachelens.copy_(snap["e"][0])
         engine.paged_kv_last_page_len.copy_(snap["e"][1])
+        if selfspec:
+            engine.draft_cachelens.copy_(snap["s"][0])
+            engine.draft_paged_kv_last_page_len.copy_(snap["s"][1])
         if draft is not None:
             draft.cachelens.copy_(snap["d"][0])
             draft.paged_kv_last_page_len.copy_(snap["d"][1])
@@ -210,6 +228,8 @@ def run(args, dev):
 
     def iteration(next_double, forced):
         """One speculative iteration across the TP group (draft sub-group drafts, tokens broadcast, all verify)."""
+        if selfspec:
+            return harness.selfspec_iteration(engine, st, G, eot_1, eot_2, S + 80, next_double, True, forced)
         return harness.longspec_iteration(engine, draft, st, G, eot_1, eot_2, S + 80, next_double, forced, bcast)
 
     def run_spec(n_warm, n_steps, forced_table):
@@ -252,16 +272,17 @@ def run(args, dev):
     meas_steps = max(args.steps // 4, 4)
 
     # ---- autoregressive baseline (tests/baseline_benchmark.py loop: one token per target step)
+    target_step = engine.verify if selfspec else engine.inference
     restore()
     nt = first_tok.clone()
     for _ in range(min(args.warmup, 3)):
-        nt = engine.inference(nt)
+        nt = target_step(nt)
     restore()
     base_steps = max(args.steps // 2, 8)
     barrier()
     t0 = time.perf_counter()
     for _ in range(base_steps):
-        nt = engine.inference(nt)
+        nt = target_step(nt)
     barrier()
     dt_base = time.perf_counter() - t0
 
@@ -293,8 +314,10 @@ def run(args, dev):
         "value": round(value, 2), "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(dt_replay / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong",
         "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-        "config": {"workload": f"{args.workload}: {tgt_name} target TP{world} + {drf_name} SnapKV draft "
-                               f"TP{len(draft_ranks)} budget {BUDGET} gamma {G}, B={B} prefix={S} max_len={ML}",
+        "config": {"workload": (f"{args.workload}: {tgt_name} self-speculation TP{world}, StreamingLLM draft cache "
+                                f"budget {BUDGET} gamma {G}, B={B} prefix={S} max_len={ML}") if selfspec else
+                               (f"{args.workload}: {tgt_name} target TP{world} + {drf_name} SnapKV draft "
+                                f"TP{len(draft_ranks)} budget {BUDGET} gamma {G}, B={B} prefix={S} max_len={ML}"),
                    "acceptance": f"fixed replay alpha={args.alpha} (E[tokens/iter]={tok_replay / args.steps / B:.3f})",
                    "weights": "seeded random init (no checkpoints on the box)",
                    "hip_graphs": bool(args.graphs)},
@@ -310,7 +333,7 @@ def run(args, dev):
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                      "bytes_per_launch": attn_bytes, "avg_launch_ms": round(attn_ms, 4), "launches_timed": n_attn},
     }
-    if rank == 0 and not args.no_cpu_baseline and world == 1:
+    if rank == 0 and not args.no_cpu_baseline and world == 1 and not selfspec:
         line["cpu_baseline"] = cpu_baseline(tgt_name, drf_name, S, BUDGET, G, args.alpha)
     if use_tp:
         dist.barrier()
