@@ -221,3 +221,72 @@ def test_hipgraph_steps_equal_eager_steps(ckpt_dir):
     for x, y in zip(a, b):
         if torch.is_tensor(x):
             assert torch.equal(x, y)
+
+
+# ------------------------------------------------------------------ other model families of the reference's zoo
+EXTRA = {
+    # Qwen2.5-style: qkv bias, g = 5 (padded MFMA M tile, mis-aligned SnapKV mask), eps 1e-6, plain RoPE theta 1e6
+    "tinyqwen": dict(cfg=mr.RefConfig(n_layer=2, n_head=10, n_local_heads=2, dim=640, intermediate_size=1280,
+                                      vocab_size=2048, rope_base=1000000.0, norm_eps=1e-6, qkv_bias=True), seed=21),
+    # Llama-3.1-70B-style: g = 8 -> two MFMA M tiles per (request, kv head) in the verify kernel, D = 128
+    "tiny70b": dict(cfg=mr.RefConfig(n_layer=2, n_head=16, n_local_heads=2, dim=2048, intermediate_size=2048,
+                                     vocab_size=2048, rope_base=500000.0, scaling_factor=8, high_freq_factor=4,
+                                     low_freq_factor=1, original_max_position_embeddings=8192), seed=22),
+    # llama-68m (BASELINE configs[0]): MHA g = 1, D = 64, vocab 32000
+    "tiny68m": dict(cfg=mr.RefConfig(n_layer=2, n_head=12, n_local_heads=12, dim=768, intermediate_size=3072,
+                                     vocab_size=32000), seed=23),
+}
+
+
+def _extra_ckpt(name):
+    from pathlib import Path
+    from magicdec_amd.Engine import model_core
+    e = EXTRA[name]
+    cfg = e["cfg"]
+    sd = mr.init_state_dict(cfg, e["seed"], wo_scale=0.1)
+    d = tempfile.mkdtemp(prefix="md_ckpt_")
+    os.makedirs(os.path.join(d, name))
+    torch.save(sd, os.path.join(d, name, "model.pth"))
+    model_core.transformer_configs[name] = dict(
+        block_size=4096, n_layer=cfg.n_layer, n_head=cfg.n_head, n_local_heads=cfg.n_local_heads, dim=cfg.dim,
+        intermediate_size=cfg.intermediate_size, vocab_size=cfg.vocab_size, rope_base=cfg.rope_base,
+        norm_eps=cfg.norm_eps, scaling_factor=cfg.scaling_factor, high_freq_factor=cfg.high_freq_factor,
+        low_freq_factor=cfg.low_freq_factor, original_max_position_embeddings=cfg.original_max_position_embeddings,
+        qkv_bias=cfg.qkv_bias)
+    return cfg, sd, Path(d) / name / "model.pth"
+
+
+@pytest.mark.parametrize("name", ["tinyqwen", "tiny70b"])
+def test_selfspec_snapkv_lockstep_other_families(name):
+    """Self-speculation with a SnapKV draft cache (configs[4] style) on Qwen-like (g=5, bias) and 70B-like (g=8)."""
+    from magicdec_amd.Engine.SnapKV.backend import LMBackend
+    cfg, sd, ck = _extra_ckpt(name)
+    log = []
+    eng = Recorder(mr.RefEngine("snapkv_self", cfg, sd, gc.B, gc.MAX_LEN, gc.BUDGET), "T", log)
+    g = torch.Generator().manual_seed(5)
+    ids = torch.randint(4, cfg.vocab_size, (gc.B, gc.S), generator=g)
+    hr.selfspec_batch(eng, ids, gc.GAMMA, gc.MAX_LEN, gc.EOT_1, gc.EOT_2, False)
+    e = LMBackend(dtype=torch.bfloat16, device=DEV, dec_len=gc.GAMMA + 1, draft_dec_len=1)
+    e.load_model(ck, use_tp=False)
+    e.setup_caches(max_batch_size=gc.B, max_seq_length=gc.MAX_LEN, draft_budget=gc.BUDGET)
+    npos, nties, err = replay(log, {"T": e})
+    print(f"[lockstep selfspec/{name}] calls={len(log)} positions={npos} near-tie flips={nties} max logit err={err:.4f}")
+    assert nties <= 0.05 * npos
+
+
+def test_baseline_llama68m_shape_lockstep():
+    """BASELINE.json configs[0]: llama-68m autoregressive baseline, B=1, prefix 129 (MHA, D=64, vocab 32000)."""
+    from magicdec_amd.Engine.SnapKV.backend import LMBackend
+    cfg, sd, ck = _extra_ckpt("tiny68m")
+    log = []
+    eng = Recorder(mr.RefEngine("target", cfg, sd, 1, 256), "T", log)
+    g = torch.Generator().manual_seed(6)
+    ids = torch.randint(4, cfg.vocab_size, (1, 129), generator=g)
+    out = hr.baseline_batch(eng, ids, 256, -1, -1)
+    assert out["steps"] == 126 and eng.cachelens.tolist() == [255] and eng.paged_kv_last_page_len.tolist() == [127]
+    e = LMBackend(dtype=torch.bfloat16, device=DEV)
+    e.load_model(ck, use_tp=False)
+    e.setup_caches(max_batch_size=1, max_seq_length=256)
+    npos, nties, err = replay(log, {"T": e})
+    print(f"[lockstep baseline/68m] calls={len(log)} positions={npos} near-tie flips={nties} max logit err={err:.4f}")
+    assert nties <= 0.05 * npos
