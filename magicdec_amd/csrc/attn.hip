@@ -391,35 +391,37 @@ __global__ __launch_bounds__(256, 2) void paged_attn_kernel(const AttnParams p) 
     }
 }
 
-// combine split-KV partials: one block per (request, kv head) item
+// combine split-KV partials: one thread per 4 consecutive d of one (item, row)
 template <int D>
 __global__ __launch_bounds__(256) void attn_merge_kernel(const AttnParams p, int rows_cap) {
-    const int item = blockIdx.x;  // pair * n_qgroups + qg  (n_qgroups == 1 in decode mode)
+    constexpr int VPR = D / 4;                         // float4 vectors per row
+    const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t total = (int64_t)p.B * p.KH * p.n_qgroups * rows_cap * VPR;
+    if (gid >= total) return;
+    const int v = (int)(gid % VPR);
+    const int64_t rowid = gid / VPR;
+    const int Rl = (int)(rowid % rows_cap);
+    const int item = (int)(rowid / rows_cap);          // pair * n_qgroups + qg  (n_qgroups == 1 in decode mode)
     const int pair = item / p.n_qgroups, qg = item % p.n_qgroups;
     const int b = pair / p.KH, kvh = pair % p.KH;
     const int q0 = p.qo_indptr[b];
     const int n_b = p.qo_indptr[b + 1] - q0;
-    const int nrows = n_b * p.g;
-    for (int e = threadIdx.x; e < rows_cap * D; e += 256) {
-        const int Rl = e / D, d = e - Rl * D;
-        const int R = qg * rows_cap + Rl;
-        if (R >= nrows) continue;
-        float M = -1e30f;
-        for (int s = 0; s < p.nsplit; ++s) {
-            const int64_t slot = ((int64_t)item * p.nsplit + s) * rows_cap + Rl;
-            M = fmaxf(M, p.ws_ml[slot * 2]);
-        }
-        float L = 0.f, acc = 0.f;
-        for (int s = 0; s < p.nsplit; ++s) {
-            const int64_t slot = ((int64_t)item * p.nsplit + s) * rows_cap + Rl;
-            const float sc = __builtin_amdgcn_exp2f(p.ws_ml[slot * 2] - M);
-            L += p.ws_ml[slot * 2 + 1] * sc;
-            acc += p.ws_o[slot * D + d] * sc;
-        }
-        const int i = R / p.g, r = R - i * p.g;
-        const float val = L > 0.f ? acc / L : 0.f;
-        p.out[((int64_t)(q0 + i) * p.H + kvh * p.g + r) * D + d] = f32_to_bf16(val);
+    const int R = qg * rows_cap + Rl;
+    if (R >= n_b * p.g) return;
+    float M = -1e30f;
+    for (int s = 0; s < p.nsplit; ++s) M = fmaxf(M, p.ws_ml[(((int64_t)item * p.nsplit + s) * rows_cap + Rl) * 2]);
+    float L = 0.f;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < p.nsplit; ++s) {
+        const int64_t slot = ((int64_t)item * p.nsplit + s) * rows_cap + Rl;
+        const float sc = __builtin_amdgcn_exp2f(p.ws_ml[slot * 2] - M);
+        L += p.ws_ml[slot * 2 + 1] * sc;
+        acc += *reinterpret_cast<const f32x4*>(p.ws_o + slot * D + v * 4) * sc;
     }
+    const int i = R / p.g, r = R - i * p.g;
+    const float inv = L > 0.f ? 1.f / L : 0.f;
+    *reinterpret_cast<bf16x4*>(p.out + ((int64_t)(q0 + i) * p.H + kvh * p.g + r) * D + v * 4) =
+        __builtin_convertvector(acc * inv, bf16x4);
 }
 
 struct AttnPlan {
@@ -565,10 +567,12 @@ extern "C" int md_paged_attn(const void* q, int64_t q_row_stride, const void* ca
     }
     if (rc != MD_OK) return rc;
     if (!pl.splitq && pl.nsplit > 1) {
+        const int64_t threads = (int64_t)B * KH * pl.n_qgroups * pl.rows_cap * (D / 4);
+        const unsigned mgrid = (unsigned)((threads + 255) / 256);
         if (D == 128)
-            hipLaunchKernelGGL((attn_merge_kernel<128>), dim3(B * KH), dim3(256), 0, st, p, pl.rows_cap);
+            hipLaunchKernelGGL((attn_merge_kernel<128>), dim3(mgrid), dim3(256), 0, st, p, pl.rows_cap);
         else
-            hipLaunchKernelGGL((attn_merge_kernel<64>), dim3(B * KH), dim3(256), 0, st, p, pl.rows_cap);
+            hipLaunchKernelGGL((attn_merge_kernel<64>), dim3(mgrid), dim3(256), 0, st, p, pl.rows_cap);
         MD_CHECK_LAUNCH("md_paged_attn(merge)");
     }
     return MD_OK;
