@@ -61,6 +61,9 @@ def parse():
                     help="capture decode steps into hipGraphs (engine.compile()); default: on for 1 GPU")
     ap.add_argument("--no-graphs", dest="graphs", action="store_false")
     ap.add_argument("--checkpoints", type=Path, default=Path("checkpoints"))
+    ap.add_argument("--kv-dtype", default="bf16", choices=["bf16", "fp8"],
+                    help="full-context KV cache storage (fp8 = OCP e4m3fn, BASELINE configs[4]; default bf16 = the "
+                         "reference's)")
     ap.add_argument("--draft-tp", type=int, default=4, help="size of the draft sub-group (reference README: 4 of 8)")
     return ap.parse_args()
 
@@ -83,12 +86,12 @@ class AttnTimer:
         timer = self
         orig = model._attend
 
-        def timed(q_rot, cache, qo_indptr, tab, n):
+        def timed(q_rot, cache, qo_indptr, tab, n, kv_scales=None):
             if not (timer.enabled and timer.cuda and n == timer.n_verify):
-                return orig(q_rot, cache, qo_indptr, tab, n)
+                return orig(q_rot, cache, qo_indptr, tab, n, kv_scales)
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s.record()
-            o = orig(q_rot, cache, qo_indptr, tab, n)
+            o = orig(q_rot, cache, qo_indptr, tab, n, kv_scales)
             e.record()
             timer.pairs.append((s, e))
             return o
@@ -155,11 +158,11 @@ def run(args, dev):
         from magicdec_amd.Engine.StreamingLLM.backend import LMBackend as SelfSpecBackend
         engine = SelfSpecBackend(dtype=torch.bfloat16, device=dev, dec_len=G + 1)
         engine.load_model(args.checkpoints / tgt_name / "model.pth", use_tp=use_tp, rank_group=rank_group, group=group)
-        engine.setup_caches(max_batch_size=B, max_seq_length=ML, draft_budget=BUDGET)
+        engine.setup_caches(max_batch_size=B, max_seq_length=ML, draft_budget=BUDGET, kv_dtype=args.kv_dtype)
     else:
         engine = LMBackend(dtype=torch.bfloat16, device=dev, dec_len=G + 1)
         engine.load_model(args.checkpoints / tgt_name / "model.pth", use_tp=use_tp, rank_group=rank_group, group=group)
-        engine.setup_caches(max_batch_size=B, max_seq_length=ML)
+        engine.setup_caches(max_batch_size=B, max_seq_length=ML, kv_dtype=args.kv_dtype)
     draft = None
     if in_draft and not selfspec:
         draft = LMBackend_Draft(dtype=torch.bfloat16, device=dev, draft_budget=BUDGET)
@@ -299,12 +302,13 @@ def run(args, dev):
     cfg = engine.model.config
     H_loc, KH_loc, D = cfg.n_head, cfg.n_local_heads, cfg.head_dim
     L_kv = S + 40 + G + 1                                 # mean kv length over a batch's 80 generated tokens
-    attn_bytes = B * L_kv * KH_loc * D * 2 * 2 + 2 * B * (G + 1) * H_loc * D * 2
+    kv_elem = 1 if args.kv_dtype == "fp8" else 2
+    attn_bytes = B * L_kv * KH_loc * D * 2 * kv_elem + 2 * B * (G + 1) * H_loc * D * 2
     achieved = attn_bytes / (attn_ms * 1e-3) / 1e9 if attn_ms > 0 else 0.0
 
     traffic = None
     pmc_path = os.path.join(ROOT, "profiles", "r01_verify_attn_pmc.json")
-    if args.workload == "cfg3" and world == 1 and os.path.exists(pmc_path):
+    if args.workload == "cfg3" and world == 1 and args.kv_dtype == "bf16" and os.path.exists(pmc_path):
         # HBM bytes per launch from the committed rocprofv3 PMC passes of this kernel at this layer shape
         # (FETCH_SIZE x2 + WRITE_SIZE, see the file); PMC collection cannot run inside bench.py itself
         with open(pmc_path) as f:
@@ -313,7 +317,7 @@ def run(args, dev):
         "metric": "decode tokens/s/node + speedup vs autoregressive, Llama-3.1-8B B=64 prefix=16K",
         "value": round(value, 2), "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(dt_replay / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong",
-        "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "vs_baseline": None, "dtype": "bf16", "kv_cache_dtype": args.kv_dtype, "data": "synthetic",
         "config": {"workload": (f"{args.workload}: {tgt_name} self-speculation TP{world}, StreamingLLM draft cache "
                                 f"budget {BUDGET} gamma {G}, B={B} prefix={S} max_len={ML}") if selfspec else
                                (f"{args.workload}: {tgt_name} target TP{world} + {drf_name} SnapKV draft "
@@ -328,7 +332,8 @@ def run(args, dev):
                                     "tokens_per_iter_per_seq": round(tok_meas / meas_steps / B, 3),
                                     "ms_per_step": round(dt_meas / meas_steps * 1e3, 4)},
         "prefill_s": round(t_pf, 2), "load_s": round(t_load, 2),
-        "roofline": {"kernel": "paged_attn_kernel<128,1,false> (verify attention, md_paged_attn)", "bound": "hbm",
+        "roofline": {"kernel": f"paged_attn_kernel<128,1,false,{'true' if args.kv_dtype == 'fp8' else 'false'}> "
+                               "(verify attention, md_paged_attn)", "bound": "hbm",
                      "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                      "bytes_per_launch": attn_bytes, "avg_launch_ms": round(attn_ms, 4), "launches_timed": n_attn},

@@ -42,6 +42,12 @@ extern "C" {
 
 typedef void* md_stream_t; /* hipStream_t */
 
+/* KV-cache element type.  MD_KV_FP8_E4M3 = OCP e4m3fn bytes (CDNA4 native, NOT the MI300 fnuz format) with one
+ * fp32 dequantisation scale per kv head for K and for V (value = byte * scale); the reference has no fp8 path
+ * (row "next" 8f-2 of SURVEY.md, BASELINE configs[4]); accuracy is gated in tests/test_gpu_fp8.py. */
+#define MD_KV_BF16 0
+#define MD_KV_FP8_E4M3 1
+
 /* ABI version (bumped on any signature change). */
 int md_abi_version(void);
 /* Message of the calling thread's most recent error ("" if none). Host. */
@@ -59,7 +65,8 @@ const char* md_last_error_string(void);
 int md_append_paged_kv(const void* k, const void* v, int64_t k_row_stride, int64_t v_row_stride,
                        const int32_t* append_indptr, void* cache, const int32_t* page_indices,
                        const int32_t* page_indptr, const int32_t* last_page_len, int B, int n_max,
-                       int KH, int D, int page_size, md_stream_t stream);
+                       int KH, int D, int page_size, int kv_dtype, const float* k_scale,
+                       const float* v_scale, md_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * K5  mylib::rope / mylib::draft_rope -> flashinfer.rope.apply_rope /
@@ -90,7 +97,7 @@ int md_rope_fill_table_host(float* table_host, int max_pos, int D, double theta,
  * (contiguous) and rotated k plus v straight into the pages.  When
  * cache2 != NULL the same rows are also appended to a second cache with its
  * own page table (self-spec verify writes target and draft caches,
- * Engine/SnapKV/model.py:347-348). */
+ * Engine/SnapKV/model.py:347-348).  kv_dtype applies to `cache`; `cache2` is always bf16. */
 int md_rope_append(const void* q, const void* k, const void* v, int64_t q_row_stride,
                    int64_t k_row_stride, int64_t v_row_stride, void* q_out,
                    const int32_t* indptr, const int32_t* offsets, int B, int n_max, int H, int KH,
@@ -98,7 +105,7 @@ int md_rope_append(const void* q, const void* k, const void* v, int64_t q_row_st
                    const int32_t* page_indices, const int32_t* page_indptr,
                    const int32_t* last_page_len, void* cache2, const int32_t* page_indices2,
                    const int32_t* page_indptr2, const int32_t* last_page_len2, int page_size,
-                   md_stream_t stream);
+                   int kv_dtype, const float* k_scale, const float* v_scale, md_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * K1/K2/K3  mylib::target_decode / target_prefill / draft_decode /
@@ -122,8 +129,8 @@ int md_paged_attn(const void* q, int64_t q_row_stride, const void* cache, void* 
                   const int32_t* qo_indptr, const int32_t* page_indices,
                   const int32_t* page_indptr, const int32_t* last_page_len, int B, int n_max,
                   int H, int KH, int D, int page_size, int causal, float sm_scale,
-                  int max_pages_per_req, void* workspace, size_t workspace_bytes,
-                  md_stream_t stream);
+                  int max_pages_per_req, int kv_dtype, const float* k_scale, const float* v_scale,
+                  void* workspace, size_t workspace_bytes, md_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * K6  Attention.gen_draft_kv  (SnapKV select)
@@ -137,6 +144,7 @@ int md_paged_attn(const void* q, int64_t q_row_stride, const void* cache, void* 
  * and kv head, the selected rows followed by the last `window` rows to the
  * draft cache at positions [draft_len_b - budget, draft_len_b).
  * idx_out: [B, KH, budget-window] int32 (selected positions, reference order).
+ * kv_dtype describes `cache`; the draft cache is bf16 (fp8 rows are dequantised while gathering).
  * ---------------------------------------------------------------------- */
 size_t md_snapkv_workspace_bytes(int B, int H, int KH, int ctx_len, int window);
 /* byte offset, inside the (256-byte aligned) workspace, of the pooled group
@@ -147,7 +155,8 @@ int md_snapkv_select(const void* q_win, const void* cache, const int32_t* page_i
                      const int32_t* page_indptr, int B, int H, int KH, int D, int page_size,
                      int ctx_len, int window, int budget, int pool_kernel, void* draft_cache,
                      const int32_t* draft_page_indices, const int32_t* draft_page_indptr,
-                     const int32_t* draft_last_page_len, int32_t* idx_out, void* workspace,
+                     const int32_t* draft_last_page_len, int32_t* idx_out, int kv_dtype,
+                     const float* k_scale, const float* v_scale, void* workspace,
                      size_t workspace_bytes, md_stream_t stream);
 
 /* ------------------------------------------------------------------------

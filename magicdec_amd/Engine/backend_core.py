@@ -120,7 +120,10 @@ class SnapKVTargetBackend(_BackendBase):
         self.draft_cachelens = None
 
     @torch.no_grad()
-    def setup_caches(self, max_batch_size: int = 1, max_seq_length: int = 2048, draft_budget=0, window_size=32):
+    def setup_caches(self, max_batch_size: int = 1, max_seq_length: int = 2048, draft_budget=0, window_size=32,
+                     kv_dtype="bf16"):
+        """kv_dtype="fp8": the full-context cache is OCP e4m3fn with static per-head scales calibrated on the
+        first prefill chunk (not in the reference; BASELINE.json configs[4]).  The compressed draft cache stays bf16."""
         self.max_length, self.batch_size = max_seq_length, max_batch_size
         dev = self.device
         self.page_size = PAGE_SIZE
@@ -138,10 +141,10 @@ class SnapKVTargetBackend(_BackendBase):
             self._d.reset(last_page_len_init=1, full_table=True)
             self.model.setup_caches(num_pages=self.max_num_pages, page_size=PAGE_SIZE, spec=True,
                                     draft_num_pages=self.draft_num_pages, draft_budget=draft_budget,
-                                    window_size=window_size, max_positions=max_seq_length + 256)
+                                    window_size=window_size, max_positions=max_seq_length + 256, kv_dtype=kv_dtype)
         else:
             self.model.setup_caches(num_pages=self.max_num_pages, page_size=PAGE_SIZE,
-                                    max_positions=max_seq_length + 256)
+                                    max_positions=max_seq_length + 256, kv_dtype=kv_dtype)
 
     @torch.no_grad()
     def clear_kv(self):
@@ -415,7 +418,7 @@ class StreamingSelfSpecBackend(_BackendBase, _StreamingMixin):
         self.draft_cachelens = None
 
     @torch.no_grad()
-    def setup_caches(self, max_batch_size: int = 1, max_seq_length: int = 2048, draft_budget=0):
+    def setup_caches(self, max_batch_size: int = 1, max_seq_length: int = 2048, draft_budget=0, kv_dtype="bf16"):
         self.draft_budget, self.batch_size = draft_budget, max_batch_size
         dev = self.device
         self.page_size = PAGE_SIZE
@@ -431,7 +434,7 @@ class StreamingSelfSpecBackend(_BackendBase, _StreamingMixin):
         self._d.reset(indptr_stride=self.draft_max_num_pages_per_request)
         self.model.setup_caches(num_pages=self.max_num_pages, page_size=PAGE_SIZE, spec=True,
                                 draft_num_pages=self.draft_max_num_pages, draft_budget=draft_budget, streaming=True,
-                                max_positions=max_seq_length + 256)
+                                max_positions=max_seq_length + 256, kv_dtype=kv_dtype)
 
     @torch.no_grad()
     def clear_kv(self):

@@ -123,6 +123,9 @@ transformer_configs = {
 
 SINK = 16          # StreamingLLM sink tokens (Engine/StreamingLLM/model_draft.py:124)
 POOL_KERNEL = 5    # SnapKV avg-pool width (Engine/SnapKV/model.py:169)
+KV_DTYPES = {"bf16": torch.bfloat16, "fp8": ops.FP8_DTYPE}   # fp8 = OCP e4m3fn full-context cache (BASELINE cfg5)
+FP8_MAX = 448.0
+FP8_MARGIN = 1.5
 
 
 class RMSNorm(nn.Module):
@@ -139,17 +142,39 @@ class KVCache(nn.Module):
     """Paged caches of one layer: `kv_cache` [pages, 2, 128, KH, D] and, for speculation, `draft_cache`."""
 
     def __init__(self, max_num_pages, page_size, n_heads, head_dim, dtype=torch.bfloat16, draft_max_num_pages=0,
-                 kv_len=0):
+                 kv_len=0, kv_dtype=torch.bfloat16):
+        """kv_dtype=float8_e4m3fn stores `kv_cache` as OCP e4m3fn bytes with static per-kv-head scales
+        (`k_scale`, `v_scale`, float32 [KH]; x ~ byte * scale); `draft_cache` is always bf16."""
         super().__init__()
         if max_num_pages > 0:
-            self.register_buffer("kv_cache", torch.zeros((max_num_pages, 2, page_size, n_heads, head_dim), dtype=dtype),
+            self.register_buffer("kv_cache",
+                                 torch.zeros((max_num_pages, 2, page_size, n_heads, head_dim), dtype=kv_dtype),
                                  persistent=False)
+        self.fp8 = kv_dtype == ops.FP8_DTYPE
+        if self.fp8:
+            self.register_buffer("k_scale", torch.ones(n_heads, dtype=torch.float32), persistent=False)
+            self.register_buffer("v_scale", torch.ones(n_heads, dtype=torch.float32), persistent=False)
+        self.calibrated = False
         if draft_max_num_pages > 0:
             self.register_buffer("draft_cache",
                                  torch.zeros((draft_max_num_pages, 2, page_size, n_heads, head_dim), dtype=dtype),
                                  persistent=False)
         self.kv_len = kv_len
         self.page_size = page_size
+
+    def scales(self, which="kv_cache"):
+        return (self.k_scale, self.v_scale) if (self.fp8 and which == "kv_cache") else None
+
+    def calibrate(self, k, v, margin=FP8_MARGIN):
+        """Static scales from the first prefill chunk: K's bound is the largest rotary-pair norm (what any
+        rotation angle can turn into one component), V's the largest |v|; `margin` leaves headroom for later
+        tokens (values beyond it saturate at +-448 in the quantiser)."""
+        rows, KH, D = k.shape
+        kb = k.float().view(rows, KH, D // 2, 2).square().sum(-1).amax(dim=(0, 2)).sqrt()
+        vb = v.float().abs().amax(dim=(0, 2))
+        self.k_scale.copy_((kb * (margin / FP8_MAX)).clamp_min(2.0 ** -20))
+        self.v_scale.copy_((vb * (margin / FP8_MAX)).clamp_min(2.0 ** -20))
+        self.calibrated = True
 
 
 class Attention(nn.Module):
@@ -224,7 +249,7 @@ class Transformer(nn.Module):
 
     # ------------------------------------------------------------------ setup
     def setup_caches(self, num_pages, page_size=128, spec=False, draft_num_pages=0, draft_budget=0, window_size=32,
-                     max_positions=None, streaming=False):
+                     max_positions=None, streaming=False, kv_dtype="bf16"):
         """Allocates the per-layer KV slabs and the device-side constants of the step
         (Engine/SnapKV/model.py:127-169 / StreamingLLM/model_draft.py:157-189 without the op registration)."""
         c = self.config
@@ -232,13 +257,18 @@ class Transformer(nn.Module):
         dtype = self.output.weight.dtype if self.output.weight.dtype == torch.float16 else torch.bfloat16
         if dtype != torch.bfloat16:
             raise NotImplementedError("the gfx950 kernels are bf16")
+        if kv_dtype not in KV_DTYPES:
+            raise ValueError(f"kv_dtype must be one of {sorted(KV_DTYPES)}")
+        if kv_dtype == "fp8" and streaming and not spec:
+            raise NotImplementedError("the StreamingLLM ring cache is bf16 only (in-place shift + re-rotation)")
         head_dim = c.dim // c.n_head
         self.page_size = page_size
         self.spec, self.streaming = spec, streaming
         self.draft_budget, self.window_size = draft_budget, window_size
         for b in self.layers:
             b.attention.kv_cache = KVCache(num_pages, page_size, c.n_local_heads, head_dim, dtype,
-                                           draft_num_pages if spec else 0, kv_len=draft_budget).to(dev)
+                                           draft_num_pages if spec else 0, kv_len=draft_budget,
+                                           kv_dtype=KV_DTYPES[kv_dtype]).to(dev)
         if max_positions is None:
             max_positions = max(num_pages, draft_num_pages, 1) * page_size + 256
         llama31 = c.high_freq_factor is not None and c.low_freq_factor is not None
@@ -323,13 +353,13 @@ class Transformer(nn.Module):
         dist.all_reduce(all_i, group=self.process_group)
         return ops.tp_argmax_merge(all_v, all_i)
 
-    def _attend(self, q_rot, cache, qo_indptr, tab: PageTable, n):
+    def _attend(self, q_rot, cache, qo_indptr, tab: PageTable, n, kv_scales=None):
         return ops.paged_attention(q_rot, cache, qo_indptr, tab.indices, tab.indptr, tab.last_page_len, n,
-                                   tab.max_pages, self.workspace, causal=True)
+                                   tab.max_pages, self.workspace, causal=True, kv_scales=kv_scales)
 
     # ------------------------------------------------------------------ step variants
     def _std_step(self, idx, offsets, qo_indptr, tab: PageTable, which="kv_cache", tab2: PageTable = None,
-                  snap_tab: PageTable = None):
+                  snap_tab: PageTable = None, calibrate=False):
         """rope(offsets) -> append (-> 2nd cache) -> attention (-> SnapKV select): Attention.forward / verify /
         draft_forward / prefill of Engine/SnapKV/model.py:322-387."""
         c = self.config
@@ -338,14 +368,18 @@ class Transformer(nn.Module):
             kvc = layer.attention.kv_cache
             cache = getattr(kvc, which)
             cache2 = kvc.draft_cache if tab2 is not None else None
+            scales = kvc.scales(which)
+            if scales is not None and calibrate and not kvc.calibrated:
+                kvc.calibrate(k, v)
             q_rot = ops.rope_append(q, k, v, qo_indptr, offsets, self.rope_table, cache, tab.indices, tab.indptr,
                                     tab.last_page_len, cache2, tab2.indices if tab2 else None,
-                                    tab2.indptr if tab2 else None, tab2.last_page_len if tab2 else None, n_max=n)
-            o = self._attend(q_rot, cache, qo_indptr, tab, n)
+                                    tab2.indptr if tab2 else None, tab2.last_page_len if tab2 else None, n_max=n,
+                                    kv_scales=scales)
+            o = self._attend(q_rot, cache, qo_indptr, tab, n, scales)
             if snap_tab is not None:
                 ops.snapkv_select(q_rot, cache, tab.indices, tab.indptr, self._snap_ctx_len, self.window_size,
                                   self.draft_budget, POOL_KERNEL, kvc.draft_cache, snap_tab.indices, snap_tab.indptr,
-                                  snap_tab.last_page_len, self.workspace)
+                                  snap_tab.last_page_len, self.workspace, kv_scales=scales)
             return o
         return self._run(idx, fn)
 
@@ -365,7 +399,7 @@ class Transformer(nn.Module):
         ctx_len = offsets[0]+seqlen is passed by the back-end (host-known, no device read)."""
         snap = draft_tab if (is_last and self.spec and not self.streaming and draft_tab is not None) else None
         self._snap_ctx_len = ctx_len
-        return self._std_step(idx, input_pos, kv_append_indptr, tab, snap_tab=snap)
+        return self._std_step(idx, input_pos, kv_append_indptr, tab, snap_tab=snap, calibrate=True)
 
     def stream_prefill(self, idx, ctx, kv_append_indptr, tab: PageTable, is_last, which, B):
         """StreamingLLM draft prefill of one chunk (Attention.prefill + KVCache.prefill,

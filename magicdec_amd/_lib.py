@@ -11,7 +11,7 @@ from ctypes import c_char_p, c_double, c_float, c_int, c_int64, c_size_t, c_void
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmagicdec_hip.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 _lib = None
 _err = None
@@ -23,16 +23,16 @@ L = c_int64
 _SIGNATURES = {
     "md_abi_version": (c_int, []),
     "md_last_error_string": (c_char_p, []),
-    "md_append_paged_kv": (c_int, [P, P, L, L, P, P, P, P, P, I, I, I, I, I, P]),
+    "md_append_paged_kv": (c_int, [P, P, L, L, P, P, P, P, P, I, I, I, I, I, I, P, P, P]),
     "md_rope": (c_int, [P, P, L, L, P, P, P, P, I, I, I, I, I, P, I, P]),
     "md_rope_fill_table_host": (c_int, [P, I, I, c_double, c_double, c_double, c_double, c_double]),
-    "md_rope_append": (c_int, [P, P, P, L, L, L, P, P, P, I, I, I, I, I, P, I, P, P, P, P, P, P, P, P, I, P]),
+    "md_rope_append": (c_int, [P, P, P, L, L, L, P, P, P, I, I, I, I, I, P, I, P, P, P, P, P, P, P, P, I, I, P, P, P]),
     "md_paged_attn_workspace_bytes": (c_size_t, [I, I, I, I, I, I, I]),
     "md_debug_set_attn_target_wgs": (None, [I]),
-    "md_paged_attn": (c_int, [P, L, P, P, P, P, P, P, I, I, I, I, I, I, I, c_float, I, P, c_size_t, P]),
+    "md_paged_attn": (c_int, [P, L, P, P, P, P, P, P, I, I, I, I, I, I, I, c_float, I, I, P, P, P, c_size_t, P]),
     "md_snapkv_workspace_bytes": (c_size_t, [I, I, I, I, I]),
     "md_snapkv_scores_offset": (c_size_t, [I, I, I, I, I]),
-    "md_snapkv_select": (c_int, [P, P, P, P, I, I, I, I, I, I, I, I, I, P, P, P, P, P, P, c_size_t, P]),
+    "md_snapkv_select": (c_int, [P, P, P, P, I, I, I, I, I, I, I, I, I, P, P, P, P, P, I, P, P, P, c_size_t, P]),
     "md_streaming_shift_append": (c_int, [P, P, L, L, P, I, I, I, I, I, I, I, I, P]),
     "md_streaming_rotate": (c_int, [P, P, I, I, I, I, I, I, P, I, P]),
     "md_rmsnorm": (c_int, [P, P, P, I, I, c_float, P]),

@@ -33,7 +33,7 @@ namespace {
 
 struct AttnParams {
     const bf16_t* q;
-    const bf16_t* cache;
+    const void* cache;     // bf16 or OCP e4m3fn bytes (MD_KV_FP8_E4M3)
     bf16_t* out;
     const int32_t* qo_indptr;
     const int32_t* page_indices;
@@ -47,6 +47,8 @@ struct AttnParams {
     int slot_stride;       // elements: KH*D
     int B, H, KH, g, page_size, causal, nsplit, n_qgroups;
     float scale_log2;
+    const float* k_scale;  // fp8 KV: per-kv-head dequant scales (K folded into the softmax scale, V into 1/l)
+    const float* v_scale;
 };
 
 constexpr int kVSub = 1056;  // bytes per [32 keys][16 d] V sub-tile (+32 B pad: conflict-free ds_write_b128)
@@ -77,11 +79,30 @@ __device__ __forceinline__ u32x4 ldg_stream(const u32x4* p) {
         return *p;
 }
 
-template <int D, int QT, bool SPLITQ>
+// 16 e4m3fn bytes -> 16 bf16 (exact: e4m3 is a subset of bf16), v_cvt_scalef32_pk_bf16_fp8 with scale 1
+__device__ __forceinline__ void cvt16_fp8_bf16(const u32x4 x, u32x4& lo, u32x4& hi) {
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        const bf16x2 a = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(x[w], 1.0f, false);
+        const bf16x2 b = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(x[w], 1.0f, true);
+        const unsigned ua = *reinterpret_cast<const unsigned*>(&a), ub = *reinterpret_cast<const unsigned*>(&b);
+        if (w < 2) {
+            lo[2 * w] = ua;
+            lo[2 * w + 1] = ub;
+        } else {
+            hi[2 * (w - 2)] = ua;
+            hi[2 * (w - 2) + 1] = ub;
+        }
+    }
+}
+
+template <int D, int QT, bool SPLITQ, bool FP8>
 __global__ __launch_bounds__(256, 2) void paged_attn_kernel(const AttnParams p) {
-    constexpr int CH = D / 8;     // 16-B chunks per K/V row
-    constexpr int RPI = 64 / CH;  // rows per wave-wide load instruction
-    constexpr int NL = 32 / RPI;  // load instructions per 32-key tile (K or V)
+    constexpr int EB = FP8 ? 1 : 2;          // bytes per cache element
+    constexpr int CH = D * EB / 16;          // 16-B chunks per K/V row in HBM
+    constexpr int RPI = 64 / CH;             // rows per wave-wide load instruction
+    constexpr int NL = 32 / RPI;             // load instructions per 32-key tile (K or V)
+    constexpr int CHL = D / 8;               // 16-B chunks per row of the bf16 LDS image
     constexpr int KS = D / 32;    // MFMA k-steps of QK^T
     constexpr int NB = D / 16;    // 16-wide d blocks of PV
     constexpr int KROW = D * 2;
@@ -89,7 +110,7 @@ __global__ __launch_bounds__(256, 2) void paged_attn_kernel(const AttnParams p) 
     constexpr int WAVE_LDS = attn_wave_lds<D, QT>();
     constexpr int TSTEP = SPLITQ ? 1 : 4;
     // two tiles of loads in flight per wave where the register budget allows it (256 VGPRs at 2 waves/SIMD)
-    constexpr bool DBUF = (QT == 1) || (D == 64);
+    constexpr bool DBUF = (QT == 1) || (D == 64) || FP8;
     constexpr int PF = (DBUF ? 2 : 1) * TSTEP;   // prefetch distance in tiles of this wave
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -160,6 +181,9 @@ __global__ __launch_bounds__(256, 2) void paged_attn_kernel(const AttnParams p) 
         }
     }
 
+    // fp8 KV: K's per-head scale is folded into the softmax scale, V's into the final 1/l
+    const float sl2 = FP8 ? p.scale_log2 * p.k_scale[kvh] : p.scale_log2;
+    const float vsc = FP8 ? p.v_scale[kvh] : 1.0f;
     f32x4 o[QT][NB];
     float m[QT], l[QT];
 #pragma unroll
@@ -173,14 +197,22 @@ __global__ __launch_bounds__(256, 2) void paged_attn_kernel(const AttnParams p) 
     unsigned char* ldsK = smem + wave * WAVE_LDS;
     unsigned char* ldsV = ldsK + K_BYTES;
 
-    // staging (write) side: lane -> (row wrow + j*RPI, 16-B chunk wch)
+    // staging (write) side: lane -> (row wrow + j*RPI, 16-B HBM chunk wch).  bf16 cache: one 16-B LDS chunk;
+    // fp8 cache: the 16 bytes expand to two adjacent bf16 chunks (2*wch, 2*wch+1) = one V sub-tile row
     const int wrow = lane / CH, wch = lane % CH;
-    int kw[NL], vw[NL];
+    int kw[NL], kw2[NL], vw[NL];
 #pragma unroll
     for (int j = 0; j < NL; ++j) {
         const int row = wrow + j * RPI;
-        kw[j] = row * KROW + ((wch ^ (row & (CH - 1))) << 4);
-        vw[j] = (wch >> 1) * kVSub + row * 32 + (wch & 1) * 16;
+        if constexpr (FP8) {
+            kw[j] = row * KROW + (((2 * wch) ^ (row & (CHL - 1))) << 4);
+            kw2[j] = row * KROW + (((2 * wch + 1) ^ (row & (CHL - 1))) << 4);
+            vw[j] = wch * kVSub + row * 32;
+        } else {
+            kw[j] = row * KROW + ((wch ^ (row & (CHL - 1))) << 4);
+            kw2[j] = 0;
+            vw[j] = (wch >> 1) * kVSub + row * 32 + (wch & 1) * 16;
+        }
     }
     // fragment (read) side
     int kra[2][KS];
@@ -189,10 +221,10 @@ __global__ __launch_bounds__(256, 2) void paged_attn_kernel(const AttnParams p) 
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
             const int row = kb * 16 + lq, ch = s * 4 + lc;
-            kra[kb][s] = row * KROW + ((ch ^ (row & (CH - 1))) << 4);
+            kra[kb][s] = row * KROW + ((ch ^ (row & (CHL - 1))) << 4);
         }
     const int vra = (lc * 4 + (lq >> 2)) * 32 + (lq & 3) * 8;  // + nb*kVSub + kb*512
-    const int goff = wrow * p.slot_stride + kvh * D + wch * 8;  // elements
+    const int goff = (wrow * p.slot_stride + kvh * D) * EB + wch * 16;  // bytes
 
     // two tiles in flight per wavefront: register sets A and B alternate (2 x 16 KiB of loads outstanding while a
     // tile is computed -- the loop is latency x bandwidth bound, not compute bound)
@@ -202,14 +234,15 @@ __global__ __launch_bounds__(256, 2) void paged_attn_kernel(const AttnParams p) 
         const int page = pos0 / p.page_size;
         const int slot0 = pos0 - page * p.page_size;
         const int pid = __builtin_amdgcn_readfirstlane(p.page_indices[pg0 + page]);
-        const bf16_t* kb_ = p.cache + (int64_t)pid * p.page_stride + (int64_t)slot0 * p.slot_stride + goff;
-        const bf16_t* vb_ = kb_ + p.kv_half;
+        const unsigned char* kb_ = reinterpret_cast<const unsigned char*>(p.cache) +
+                                   ((int64_t)pid * p.page_stride + (int64_t)slot0 * p.slot_stride) * EB + goff;
+        const unsigned char* vb_ = kb_ + p.kv_half * EB;
 #pragma unroll
         for (int j = 0; j < NL; ++j)
-            kreg[j] = ldg_stream<!SPLITQ>(reinterpret_cast<const u32x4*>(kb_ + (int64_t)j * RPI * p.slot_stride));
+            kreg[j] = ldg_stream<!SPLITQ>(reinterpret_cast<const u32x4*>(kb_ + (int64_t)j * RPI * p.slot_stride * EB));
 #pragma unroll
         for (int j = 0; j < NL; ++j)
-            vreg[j] = ldg_stream<!SPLITQ>(reinterpret_cast<const u32x4*>(vb_ + (int64_t)j * RPI * p.slot_stride));
+            vreg[j] = ldg_stream<!SPLITQ>(reinterpret_cast<const u32x4*>(vb_ + (int64_t)j * RPI * p.slot_stride * EB));
     };
 
     auto process = [&](int t, u32x4 (&kreg)[NL], u32x4 (&vreg)[NL]) {
@@ -220,10 +253,27 @@ __global__ __launch_bounds__(256, 2) void paged_attn_kernel(const AttnParams p) 
             for (int j = 0; j < NL; ++j)
                 if (t * 32 + wrow + j * RPI >= kv_len) vreg[j] = u32x4{0u, 0u, 0u, 0u};
         }
+        if constexpr (FP8) {
 #pragma unroll
-        for (int j = 0; j < NL; ++j) *reinterpret_cast<u32x4*>(ldsK + kw[j]) = kreg[j];
+            for (int j = 0; j < NL; ++j) {
+                u32x4 lo, hi;
+                cvt16_fp8_bf16(kreg[j], lo, hi);
+                *reinterpret_cast<u32x4*>(ldsK + kw[j]) = lo;
+                *reinterpret_cast<u32x4*>(ldsK + kw2[j]) = hi;
+            }
 #pragma unroll
-        for (int j = 0; j < NL; ++j) *reinterpret_cast<u32x4*>(ldsV + vw[j]) = vreg[j];
+            for (int j = 0; j < NL; ++j) {
+                u32x4 lo, hi;
+                cvt16_fp8_bf16(vreg[j], lo, hi);
+                *reinterpret_cast<u32x4*>(ldsV + vw[j]) = lo;
+                *reinterpret_cast<u32x4*>(ldsV + vw[j] + 16) = hi;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < NL; ++j) *reinterpret_cast<u32x4*>(ldsK + kw[j]) = kreg[j];
+#pragma unroll
+            for (int j = 0; j < NL; ++j) *reinterpret_cast<u32x4*>(ldsV + vw[j]) = vreg[j];
+        }
         if (t + PF < t_end) issue(t + PF, kreg, vreg);
         // same-wave LDS hand-off: LDS ops of one wave execute in order
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -255,7 +305,7 @@ __global__ __launch_bounds__(256, 2) void paged_attn_kernel(const AttnParams p) 
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) v[kb * 4 + j] = s[qt][kb][j] * p.scale_log2;
+                for (int j = 0; j < 4; ++j) v[kb * 4 + j] = s[qt][kb][j] * sl2;
             if (need_mask) {
 #pragma unroll
                 for (int kb = 0; kb < 2; ++kb)
@@ -327,7 +377,7 @@ __global__ __launch_bounds__(256, 2) void paged_attn_kernel(const AttnParams p) 
             const int R = (tile_base + qt) * 16 + lq;
             if (R < nrows) {
                 const int i = R / g, r = R - i * g;
-                const float inv = l[qt] > 0.f ? 1.f / l[qt] : 0.f;
+                const float inv = l[qt] > 0.f ? vsc / l[qt] : 0.f;
                 bf16_t* op = p.out + ((int64_t)(q0 + i) * p.H + kvh * g + r) * D + lc * 4;
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb) {
@@ -377,7 +427,7 @@ __global__ __launch_bounds__(256, 2) void paged_attn_kernel(const AttnParams p) 
             }
             if (p.nsplit == 1) {
                 const int i = R / g, r = R - i * g;
-                const float val = L > 0.f ? acc / L : 0.f;
+                const float val = L > 0.f ? acc * vsc / L : 0.f;
                 p.out[((int64_t)(q0 + i) * p.H + kvh * g + r) * D + d] = f32_to_bf16(val);
             } else {
                 const int64_t slot = ((int64_t)item * p.nsplit + split) * ROWS + Rl;
@@ -419,7 +469,7 @@ __global__ __launch_bounds__(256) void attn_merge_kernel(const AttnParams p, int
         acc += *reinterpret_cast<const f32x4*>(p.ws_o + slot * D + v * 4) * sc;
     }
     const int i = R / p.g, r = R - i * p.g;
-    const float inv = L > 0.f ? 1.f / L : 0.f;
+    const float inv = L > 0.f ? (p.v_scale ? p.v_scale[kvh] : 1.f) / L : 0.f;
     *reinterpret_cast<bf16x4*>(p.out + ((int64_t)(q0 + i) * p.H + kvh * p.g + r) * D + v * 4) =
         __builtin_convertvector(acc * inv, bf16x4);
 }
@@ -464,13 +514,13 @@ AttnPlan make_plan(int B, int n_max, int H, int KH, int max_pages, int page_size
     return pl;
 }
 
-template <int D, int QT, bool SPLITQ>
+template <int D, int QT, bool SPLITQ, bool FP8>
 int launch_attn(const AttnParams& p, int grid, hipStream_t st) {
     constexpr int lds = 4 * attn_wave_lds<D, QT>();
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(
-            reinterpret_cast<const void*>(&paged_attn_kernel<D, QT, SPLITQ>),
+            reinterpret_cast<const void*>(&paged_attn_kernel<D, QT, SPLITQ, FP8>),
             hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) {
             md_set_error("md_paged_attn: hipFuncSetAttribute(%d B LDS) failed: %s", lds, hipGetErrorString(e));
@@ -478,7 +528,7 @@ int launch_attn(const AttnParams& p, int grid, hipStream_t st) {
         }
         attr_set = true;
     }
-    hipLaunchKernelGGL((paged_attn_kernel<D, QT, SPLITQ>), dim3(grid), dim3(256), lds, st, p);
+    hipLaunchKernelGGL((paged_attn_kernel<D, QT, SPLITQ, FP8>), dim3(grid), dim3(256), lds, st, p);
     MD_CHECK_LAUNCH("md_paged_attn");
     return MD_OK;
 }
@@ -500,8 +550,9 @@ extern "C" int md_paged_attn(const void* q, int64_t q_row_stride, const void* ca
                              const int32_t* qo_indptr, const int32_t* page_indices,
                              const int32_t* page_indptr, const int32_t* last_page_len, int B,
                              int n_max, int H, int KH, int D, int page_size, int causal,
-                             float sm_scale, int max_pages_per_req, void* workspace,
-                             size_t workspace_bytes, md_stream_t stream) {
+                             float sm_scale, int max_pages_per_req, int kv_dtype, const float* k_scale,
+                             const float* v_scale, void* workspace, size_t workspace_bytes,
+                             md_stream_t stream) {
     MD_CHECK_ARG(q && cache && out && qo_indptr && page_indices && page_indptr && last_page_len,
                  "md_paged_attn: null pointer argument");
     MD_CHECK_ARG(B > 0 && n_max > 0 && H > 0 && KH > 0 && H % KH == 0,
@@ -515,11 +566,16 @@ extern "C" int md_paged_attn(const void* q, int64_t q_row_stride, const void* ca
                      ((uintptr_t)out & 7) == 0,
                  "md_paged_attn: q/cache must be 16-byte aligned with a row stride multiple of 8");
     MD_CHECK_ARG(max_pages_per_req > 0, "md_paged_attn: max_pages_per_req must be > 0");
+    MD_CHECK_ARG(kv_dtype == MD_KV_BF16 || (kv_dtype == MD_KV_FP8_E4M3 && k_scale && v_scale),
+                 "md_paged_attn: kv_dtype must be MD_KV_BF16 or MD_KV_FP8_E4M3 (with per-head scales)");
+    const bool fp8 = kv_dtype == MD_KV_FP8_E4M3;
 
     const AttnPlan pl = make_plan(B, n_max, H, KH, max_pages_per_req, page_size);
     AttnParams p;
     p.q = (const bf16_t*)q;
-    p.cache = (const bf16_t*)cache;
+    p.cache = cache;
+    p.k_scale = fp8 ? k_scale : nullptr;
+    p.v_scale = fp8 ? v_scale : nullptr;
     p.out = (bf16_t*)out;
     p.qo_indptr = qo_indptr;
     p.page_indices = page_indices;
@@ -554,17 +610,14 @@ extern "C" int md_paged_attn(const void* q, int64_t q_row_stride, const void* ca
     const int npairs8 = (B * KH + 7) / 8 * 8;
     const int grid = npairs8 * pl.n_qgroups * pl.nsplit;
     int rc;
-    if (D == 128) {
-        if (pl.splitq)
-            rc = pl.qt == 2 ? launch_attn<128, 2, true>(p, grid, st) : launch_attn<128, 1, true>(p, grid, st);
-        else
-            rc = pl.qt == 2 ? launch_attn<128, 2, false>(p, grid, st) : launch_attn<128, 1, false>(p, grid, st);
-    } else {
-        if (pl.splitq)
-            rc = pl.qt == 2 ? launch_attn<64, 2, true>(p, grid, st) : launch_attn<64, 1, true>(p, grid, st);
-        else
-            rc = pl.qt == 2 ? launch_attn<64, 2, false>(p, grid, st) : launch_attn<64, 1, false>(p, grid, st);
-    }
+#define MD_ATTN_DISPATCH(DD, FP)                                                                                  \
+    (pl.splitq ? (pl.qt == 2 ? launch_attn<DD, 2, true, FP>(p, grid, st) : launch_attn<DD, 1, true, FP>(p, grid, st)) \
+               : (pl.qt == 2 ? launch_attn<DD, 2, false, FP>(p, grid, st) : launch_attn<DD, 1, false, FP>(p, grid, st)))
+    if (D == 128)
+        rc = fp8 ? MD_ATTN_DISPATCH(128, true) : MD_ATTN_DISPATCH(128, false);
+    else
+        rc = fp8 ? MD_ATTN_DISPATCH(64, true) : MD_ATTN_DISPATCH(64, false);
+#undef MD_ATTN_DISPATCH
     if (rc != MD_OK) return rc;
     if (!pl.splitq && pl.nsplit > 1) {
         const int64_t threads = (int64_t)B * KH * pl.n_qgroups * pl.rows_cap * (D / 4);

@@ -32,11 +32,39 @@ __device__ __forceinline__ int64_t page_row_offset(const int32_t* indices, int p
     return (pid * 2 * page_size + slot) * (int64_t)(KH * D);
 }
 
+// 8 bf16 -> 8 OCP e4m3fn bytes: q = rne_e4m3(clamp(x * inv_scale, +-448))   (oracle: flashinfer_ref.quantize_fp8)
+__device__ __forceinline__ u32x2 quant8_fp8(const u32x4 x, float inv_scale) {
+    float f[8];
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        f[2 * w] = __uint_as_float(x[w] << 16);
+        f[2 * w + 1] = __uint_as_float(x[w] & 0xffff0000u);
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) f[e] = fminf(fmaxf(__fmul_rn(f[e], inv_scale), -448.f), 448.f);
+    u32x2 r = {0u, 0u};
+    r[0] = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], r[0], false);
+    r[0] = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], r[0], true);
+    r[1] = __builtin_amdgcn_cvt_pk_fp8_f32(f[4], f[5], r[1], false);
+    r[1] = __builtin_amdgcn_cvt_pk_fp8_f32(f[6], f[7], r[1], true);
+    return r;
+}
+
+// store 8 consecutive cache elements starting at element offset `off` (bf16 or fp8 cache)
+template <bool FP8>
+__device__ __forceinline__ void store8(void* cache, int64_t off, const u32x4 v, float inv_scale) {
+    if constexpr (FP8)
+        *reinterpret_cast<u32x2*>(reinterpret_cast<unsigned char*>(cache) + off) = quant8_fp8(v, inv_scale);
+    else
+        *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(cache) + off) = v;
+}
+
+template <bool FP8>
 __global__ __launch_bounds__(256) void append_kernel(const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
                                                      int64_t ks, int64_t vs, const int32_t* append_indptr,
-                                                     bf16_t* cache, const int32_t* indices,
+                                                     void* cache, const int32_t* indices,
                                                      const int32_t* indptr, const int32_t* last, int KH, int D,
-                                                     int page_size) {
+                                                     int page_size, const float* k_scale, const float* v_scale) {
     const int b = blockIdx.y, j = blockIdx.x;
     const int a0 = append_indptr[b];
     const int n_b = append_indptr[b + 1] - a0;
@@ -50,11 +78,11 @@ __global__ __launch_bounds__(256) void append_kernel(const bf16_t* __restrict__ 
     const int nvec = KH * D / 8;
     const u32x4* ksrc = reinterpret_cast<const u32x4*>(k + (int64_t)(a0 + j) * ks);
     const u32x4* vsrc = reinterpret_cast<const u32x4*>(v + (int64_t)(a0 + j) * vs);
-    u32x4* kdst = reinterpret_cast<u32x4*>(cache + dst);
-    u32x4* vdst = reinterpret_cast<u32x4*>(cache + dst + half);
+    const int cpr = D / 8;
     for (int i = threadIdx.x; i < nvec; i += blockDim.x) {
-        kdst[i] = ksrc[i];
-        vdst[i] = vsrc[i];
+        const int h = i / cpr;
+        store8<FP8>(cache, dst + i * 8, ksrc[i], FP8 ? 1.0f / k_scale[h] : 1.f);
+        store8<FP8>(cache, dst + half + i * 8, vsrc[i], FP8 ? 1.0f / v_scale[h] : 1.f);
     }
 }
 
@@ -107,19 +135,21 @@ __global__ __launch_bounds__(256) void rope_kernel(const bf16_t* __restrict__ q,
 }
 
 struct PageTable {
-    bf16_t* cache;
+    void* cache;
     const int32_t* indices;
     const int32_t* indptr;
     const int32_t* last;
 };
 
+template <bool FP8>
 __global__ __launch_bounds__(256) void rope_append_kernel(const bf16_t* __restrict__ q,
                                                           const bf16_t* __restrict__ k,
                                                           const bf16_t* __restrict__ v, int64_t qs, int64_t ks,
                                                           int64_t vs, bf16_t* q_out, const int32_t* indptr,
                                                           const int32_t* offsets, int H, int KH, int D,
                                                           const float* __restrict__ cos_sin, int max_pos,
-                                                          PageTable t1, PageTable t2, int page_size) {
+                                                          PageTable t1, PageTable t2, int page_size,
+                                                          const float* k_scale, const float* v_scale) {
     const int b = blockIdx.y, j = blockIdx.x;
     const int a0 = indptr[b];
     const int n_b = indptr[b + 1] - a0;
@@ -152,13 +182,14 @@ __global__ __launch_bounds__(256) void rope_append_kernel(const bf16_t* __restri
             const int c = ii % cpr;
             const u32x4 x = *reinterpret_cast<const u32x4*>(k + (int64_t)row * ks + ii * 8);
             const u32x4 y = rope8(x, cs + c * 8);
-            if (d1 >= 0) *reinterpret_cast<u32x4*>(t1.cache + d1 + ii * 8) = y;
-            if (d2 >= 0) *reinterpret_cast<u32x4*>(t2.cache + d2 + ii * 8) = y;
+            // the first cache may be fp8 (target); a second cache (self-spec draft cache) is always bf16
+            if (d1 >= 0) store8<FP8>(t1.cache, d1 + ii * 8, y, FP8 ? 1.0f / k_scale[ii / cpr] : 1.f);
+            if (d2 >= 0) store8<false>(t2.cache, d2 + ii * 8, y, 1.f);
         } else {
             const int ii = i - nq - nk;
             const u32x4 x = *reinterpret_cast<const u32x4*>(v + (int64_t)row * vs + ii * 8);
-            if (d1 >= 0) *reinterpret_cast<u32x4*>(t1.cache + d1 + half + ii * 8) = x;
-            if (d2 >= 0) *reinterpret_cast<u32x4*>(t2.cache + d2 + half + ii * 8) = x;
+            if (d1 >= 0) store8<FP8>(t1.cache, d1 + half + ii * 8, x, FP8 ? 1.0f / v_scale[ii / cpr] : 1.f);
+            if (d2 >= 0) store8<false>(t2.cache, d2 + half + ii * 8, x, 1.f);
         }
     }
 }
@@ -170,16 +201,24 @@ bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 extern "C" int md_append_paged_kv(const void* k, const void* v, int64_t k_row_stride, int64_t v_row_stride,
                                   const int32_t* append_indptr, void* cache, const int32_t* page_indices,
                                   const int32_t* page_indptr, const int32_t* last_page_len, int B, int n_max,
-                                  int KH, int D, int page_size, md_stream_t stream) {
+                                  int KH, int D, int page_size, int kv_dtype, const float* k_scale,
+                                  const float* v_scale, md_stream_t stream) {
     MD_CHECK_ARG(k && v && append_indptr && cache && page_indices && page_indptr && last_page_len,
                  "md_append_paged_kv: null pointer argument");
     MD_CHECK_ARG(B > 0 && n_max > 0 && KH > 0 && D > 0 && D % 8 == 0 && page_size > 0,
                  "md_append_paged_kv: bad shape B=%d n_max=%d KH=%d D=%d", B, n_max, KH, D);
     MD_CHECK_ARG(aligned16(k) && aligned16(v) && aligned16(cache) && k_row_stride % 8 == 0 && v_row_stride % 8 == 0,
                  "md_append_paged_kv: k/v/cache must be 16-byte aligned, row strides multiples of 8");
-    hipLaunchKernelGGL(append_kernel, dim3(n_max, B), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)k,
-                       (const bf16_t*)v, k_row_stride, v_row_stride, append_indptr, (bf16_t*)cache, page_indices,
-                       page_indptr, last_page_len, KH, D, page_size);
+    MD_CHECK_ARG(kv_dtype == MD_KV_BF16 || (kv_dtype == MD_KV_FP8_E4M3 && k_scale && v_scale),
+                 "md_append_paged_kv: kv_dtype must be MD_KV_BF16 or MD_KV_FP8_E4M3 (with per-head scales)");
+    if (kv_dtype == MD_KV_FP8_E4M3)
+        hipLaunchKernelGGL((append_kernel<true>), dim3(n_max, B), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)k,
+                           (const bf16_t*)v, k_row_stride, v_row_stride, append_indptr, cache, page_indices,
+                           page_indptr, last_page_len, KH, D, page_size, k_scale, v_scale);
+    else
+        hipLaunchKernelGGL((append_kernel<false>), dim3(n_max, B), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)k,
+                           (const bf16_t*)v, k_row_stride, v_row_stride, append_indptr, cache, page_indices,
+                           page_indptr, last_page_len, KH, D, page_size, k_scale, v_scale);
     MD_CHECK_LAUNCH("md_append_paged_kv");
     return MD_OK;
 }
@@ -231,7 +270,7 @@ extern "C" int md_rope_append(const void* q, const void* k, const void* v, int64
                               int max_pos, void* cache, const int32_t* page_indices, const int32_t* page_indptr,
                               const int32_t* last_page_len, void* cache2, const int32_t* page_indices2,
                               const int32_t* page_indptr2, const int32_t* last_page_len2, int page_size,
-                              md_stream_t stream) {
+                              int kv_dtype, const float* k_scale, const float* v_scale, md_stream_t stream) {
     MD_CHECK_ARG(q && k && v && q_out && indptr && offsets && cos_sin && cache && page_indices && page_indptr &&
                      last_page_len,
                  "md_rope_append: null pointer argument");
@@ -243,11 +282,18 @@ extern "C" int md_rope_append(const void* q, const void* k, const void* v, int64
                      aligned16(cos_sin) && (!cache2 || aligned16(cache2)) && q_row_stride % 8 == 0 &&
                      k_row_stride % 8 == 0 && v_row_stride % 8 == 0,
                  "md_rope_append: tensors must be 16-byte aligned, row strides multiples of 8");
-    PageTable t1{(bf16_t*)cache, page_indices, page_indptr, last_page_len};
-    PageTable t2{(bf16_t*)cache2, page_indices2, page_indptr2, last_page_len2};
-    hipLaunchKernelGGL(rope_append_kernel, dim3(n_max, B), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)q,
-                       (const bf16_t*)k, (const bf16_t*)v, q_row_stride, k_row_stride, v_row_stride, (bf16_t*)q_out,
-                       indptr, offsets, H, KH, D, cos_sin, max_pos, t1, t2, page_size);
+    MD_CHECK_ARG(kv_dtype == MD_KV_BF16 || (kv_dtype == MD_KV_FP8_E4M3 && k_scale && v_scale),
+                 "md_rope_append: kv_dtype must be MD_KV_BF16 or MD_KV_FP8_E4M3 (with per-head scales)");
+    PageTable t1{cache, page_indices, page_indptr, last_page_len};
+    PageTable t2{cache2, page_indices2, page_indptr2, last_page_len2};
+    if (kv_dtype == MD_KV_FP8_E4M3)
+        hipLaunchKernelGGL((rope_append_kernel<true>), dim3(n_max, B), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)q,
+                           (const bf16_t*)k, (const bf16_t*)v, q_row_stride, k_row_stride, v_row_stride, (bf16_t*)q_out,
+                           indptr, offsets, H, KH, D, cos_sin, max_pos, t1, t2, page_size, k_scale, v_scale);
+    else
+        hipLaunchKernelGGL((rope_append_kernel<false>), dim3(n_max, B), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)q,
+                           (const bf16_t*)k, (const bf16_t*)v, q_row_stride, k_row_stride, v_row_stride, (bf16_t*)q_out,
+                           indptr, offsets, H, KH, D, cos_sin, max_pos, t1, t2, page_size, k_scale, v_scale);
     MD_CHECK_LAUNCH("md_rope_append");
     return MD_OK;
 }

@@ -25,7 +25,8 @@ constexpr int kChunkCols = 1024;
 
 struct SnapParams {
     const bf16_t* q;      // [B*W, H, D]
-    const bf16_t* cache;  // paged full KV
+    const void* cache;    // paged full KV (bf16, or e4m3fn bytes with per-head scales)
+    const float* k_scale;
     const int32_t* page_indices;
     const int32_t* page_indptr;
     float* partials;        // [B*KH][L][nch][2]
@@ -37,7 +38,7 @@ struct SnapParams {
 
 // K fragment (A operand) of 16 consecutive columns (kv positions) col0..col0+15 for head kvh:
 // lane (lq,lc) holds K[col0+lq][ks*32 + lc*8 .. +8]
-template <int D>
+template <int D, bool FP8>
 __device__ __forceinline__ void load_kfrag(const SnapParams& p, int b, int kvh, int col0, int lq, int lc,
                                            bf16x8 (&kf)[D / 32]) {
     const int col = col0 + lq;
@@ -45,9 +46,29 @@ __device__ __forceinline__ void load_kfrag(const SnapParams& p, int b, int kvh, 
     if (col < p.S) {
         const int page = col / p.page_size, slot = col - page * p.page_size;
         const int64_t pid = p.page_indices[p.page_indptr[b] + page];
-        const bf16_t* kp = p.cache + pid * p.page_stride + (int64_t)slot * p.slot_stride + kvh * D + lc * 8;
+        const int64_t off = pid * p.page_stride + (int64_t)slot * p.slot_stride + kvh * D + lc * 8;   // elements
+        if constexpr (FP8) {
+            const unsigned char* kp = reinterpret_cast<const unsigned char*>(p.cache) + off;
 #pragma unroll
-        for (int ks = 0; ks < D / 32; ++ks) kf[ks] = *reinterpret_cast<const bf16x8*>(kp + ks * 32);
+            for (int ks = 0; ks < D / 32; ++ks) {
+                const u32x2 w = *reinterpret_cast<const u32x2*>(kp + ks * 32);   // 8 e4m3fn bytes -> 8 bf16 (exact)
+                bf16x8 r;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const bf16x2 a = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(w[h], 1.0f, false);
+                    const bf16x2 c = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(w[h], 1.0f, true);
+                    r[4 * h] = a[0];
+                    r[4 * h + 1] = a[1];
+                    r[4 * h + 2] = c[0];
+                    r[4 * h + 3] = c[1];
+                }
+                kf[ks] = r;
+            }
+        } else {
+            const bf16_t* kp = reinterpret_cast<const bf16_t*>(p.cache) + off;
+#pragma unroll
+            for (int ks = 0; ks < D / 32; ++ks) kf[ks] = *reinterpret_cast<const bf16x8*>(kp + ks * 32);
+        }
     } else {
 #pragma unroll
         for (int ks = 0; ks < D / 32; ++ks) kf[ks] = z;
@@ -58,7 +79,7 @@ __device__ __forceinline__ void load_kfrag(const SnapParams& p, int b, int kvh, 
 // (row rt*16+lq, col col0+lc*4+j); masked / out-of-range entries are -inf
 template <int D>
 __device__ __forceinline__ f32x4 score_tile(const SnapParams& p, int b, int kvh, int rt, int col0, int lq, int lc,
-                                            const bf16x8 (&kf)[D / 32]) {
+                                            const bf16x8 (&kf)[D / 32], float kscale) {
     const int rg = rt * 16 + lq;  // row within the kv head, ordered (r,l)
     const int r = rg / p.W, l = rg - r * p.W;
     const bf16_t* qp = p.q + ((int64_t)(b * p.W + l) * p.H + kvh * p.g + r) * D + lc * 8;
@@ -75,7 +96,7 @@ __device__ __forceinline__ f32x4 score_tile(const SnapParams& p, int b, int kvh,
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int col = col0 + lc * 4 + j;
-        float v = bf16_to_f32(f32_to_bf16(acc[j]));
+        float v = bf16_to_f32(f32_to_bf16(acc[j] * kscale));      // kscale = 1 for a bf16 cache
         const int jcol = col - (p.S - p.W);
         if (col >= p.S || (mrow >= 0 && jcol > mrow)) v = -INFINITY;
         s[j] = v;
@@ -83,7 +104,7 @@ __device__ __forceinline__ f32x4 score_tile(const SnapParams& p, int b, int kvh,
     return s;
 }
 
-template <int D>
+template <int D, bool FP8>
 __global__ __launch_bounds__(256) void snapkv_stats_kernel(const SnapParams p) {
     extern __shared__ __attribute__((aligned(16))) float sm[];  // [4 waves][L][2]
     const int chunk = blockIdx.x, kvh = blockIdx.y, b = blockIdx.z;
@@ -98,9 +119,10 @@ __global__ __launch_bounds__(256) void snapkv_stats_kernel(const SnapParams p) {
         const int col0 = chunk * kChunkCols + cg * 16;
         if (col0 >= p.S) break;
         bf16x8 kf[D / 32];
-        load_kfrag<D>(p, b, kvh, col0, lq, lc, kf);
+        load_kfrag<D, FP8>(p, b, kvh, col0, lq, lc, kf);
+        const float kscale = FP8 ? p.k_scale[kvh] : 1.0f;
         for (int rt = 0; rt < RT; ++rt) {
-            const f32x4 s = score_tile<D>(p, b, kvh, rt, col0, lq, lc, kf);
+            const f32x4 s = score_tile<D>(p, b, kvh, rt, col0, lq, lc, kf, kscale);
             float mx = fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3]));
             mx = fmaxf(mx, __shfl_xor(mx, 16));
             mx = fmaxf(mx, __shfl_xor(mx, 32));
@@ -136,7 +158,7 @@ __global__ __launch_bounds__(256) void snapkv_stats_kernel(const SnapParams p) {
     }
 }
 
-template <int D>
+template <int D, bool FP8>
 __global__ __launch_bounds__(256) void snapkv_accum_kernel(const SnapParams p) {
     extern __shared__ __attribute__((aligned(16))) float sm[];  // [L][2] row stats, then [4][g][16] accumulators
     const int ctile = blockIdx.x, kvh = blockIdx.y, b = blockIdx.z;
@@ -159,10 +181,11 @@ __global__ __launch_bounds__(256) void snapkv_accum_kernel(const SnapParams p) {
     const int col0 = ctile * 64 + wave * 16;
     if (col0 >= N) return;
     bf16x8 kf[D / 32];
-    load_kfrag<D>(p, b, kvh, col0, lq, lc, kf);
+    load_kfrag<D, FP8>(p, b, kvh, col0, lq, lc, kf);
+    const float kscale = FP8 ? p.k_scale[kvh] : 1.0f;
     const int RT = p.L / 16;
     for (int rt = 0; rt < RT; ++rt) {
-        const f32x4 s = score_tile<D>(p, b, kvh, rt, col0, lq, lc, kf);
+        const f32x4 s = score_tile<D>(p, b, kvh, rt, col0, lq, lc, kf, kscale);
         const int row = rt * 16 + lq;
         const float M = MZ[row * 2], Z = MZ[row * 2 + 1];
         f32x4 gs;
@@ -326,7 +349,9 @@ __global__ __launch_bounds__(1024) void snapkv_select_kernel(const unsigned shor
 }
 
 struct GatherParams {
-    const bf16_t* cache;
+    const void* cache;
+    const float* k_scale;
+    const float* v_scale;
     const int32_t* page_indices;
     const int32_t* page_indptr;
     bf16_t* dcache;
@@ -337,6 +362,7 @@ struct GatherParams {
     int KH, D, page_size, S, W, budget, topk;
 };
 
+template <bool FP8>
 __global__ __launch_bounds__(64) void snapkv_gather_kernel(const GatherParams p) {
     const int j = blockIdx.x, kvh = blockIdx.y, b = blockIdx.z;
     const int src = j < p.topk ? p.idx[((int64_t)b * p.KH + kvh) * p.topk + j] : p.S - p.W + (j - p.topk);
@@ -357,8 +383,24 @@ __global__ __launch_bounds__(64) void snapkv_gather_kernel(const GatherParams p)
     for (int i = threadIdx.x; i < 2 * nv; i += 64) {
         const int64_t h = i < nv ? 0 : half;
         const int c = i < nv ? i : i - nv;
-        *reinterpret_cast<u32x4*>(p.dcache + doff + h + c * 8) =
-            *reinterpret_cast<const u32x4*>(p.cache + soff + h + c * 8);
+        if constexpr (FP8) {   // dequantise into the bf16 draft cache: bf16(byte * scale)
+            const float sc = i < nv ? p.k_scale[kvh] : p.v_scale[kvh];
+            const u32x2 w = *reinterpret_cast<const u32x2*>(reinterpret_cast<const unsigned char*>(p.cache) + soff + h + c * 8);
+            bf16x8 r;
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+                const f32x2 a = __builtin_amdgcn_cvt_pk_f32_fp8(w[hh], false);
+                const f32x2 cc = __builtin_amdgcn_cvt_pk_f32_fp8(w[hh], true);
+                r[4 * hh] = f32_to_bf16(a[0] * sc);
+                r[4 * hh + 1] = f32_to_bf16(a[1] * sc);
+                r[4 * hh + 2] = f32_to_bf16(cc[0] * sc);
+                r[4 * hh + 3] = f32_to_bf16(cc[1] * sc);
+            }
+            *reinterpret_cast<bf16x8*>(p.dcache + doff + h + c * 8) = r;
+        } else {
+            *reinterpret_cast<u32x4*>(p.dcache + doff + h + c * 8) =
+                *reinterpret_cast<const u32x4*>(reinterpret_cast<const bf16_t*>(p.cache) + soff + h + c * 8);
+        }
     }
 }
 
@@ -389,7 +431,8 @@ extern "C" int md_snapkv_select(const void* q_win, const void* cache, const int3
                                 const int32_t* page_indptr, int B, int H, int KH, int D, int page_size, int ctx_len,
                                 int window, int budget, int pool_kernel, void* draft_cache,
                                 const int32_t* draft_page_indices, const int32_t* draft_page_indptr,
-                                const int32_t* draft_last_page_len, int32_t* idx_out, void* workspace,
+                                const int32_t* draft_last_page_len, int32_t* idx_out, int kv_dtype,
+                                const float* k_scale, const float* v_scale, void* workspace,
                                 size_t workspace_bytes, md_stream_t stream) {
     MD_CHECK_ARG(q_win && cache && page_indices && page_indptr && draft_cache && draft_page_indices &&
                      draft_page_indptr && draft_last_page_len && idx_out && workspace,
@@ -412,11 +455,15 @@ extern "C" int md_snapkv_select(const void* q_win, const void* cache, const int3
     MD_CHECK_ARG(workspace_bytes >= md_snapkv_workspace_bytes(B, H, KH, ctx_len, window) &&
                      (((uintptr_t)workspace) & 255) == 0,
                  "md_snapkv_select: workspace too small or not 256-byte aligned");
+    MD_CHECK_ARG(kv_dtype == MD_KV_BF16 || (kv_dtype == MD_KV_FP8_E4M3 && k_scale && v_scale),
+                 "md_snapkv_select: kv_dtype must be MD_KV_BF16 or MD_KV_FP8_E4M3 (with per-head scales)");
+    const bool fp8 = kv_dtype == MD_KV_FP8_E4M3;
     hipStream_t st = (hipStream_t)stream;
 
     SnapParams p;
     p.q = (const bf16_t*)q_win;
-    p.cache = (const bf16_t*)cache;
+    p.cache = cache;
+    p.k_scale = k_scale;
     p.page_indices = page_indices;
     p.page_indptr = page_indptr;
     p.B = B;
@@ -439,13 +486,17 @@ extern "C" int md_snapkv_select(const void* q_win, const void* cache, const int3
 
     const size_t lds1 = (size_t)4 * L * 2 * 4;
     const size_t lds2 = (size_t)L * 2 * 4 + (size_t)4 * g * 16 * 4;
+#define MD_SNAP_LAUNCH(DD, FP)                                                                                   \
+    do {                                                                                                         \
+        hipLaunchKernelGGL((snapkv_stats_kernel<DD, FP>), dim3(p.nch, KH, B), dim3(256), lds1, st, p);            \
+        hipLaunchKernelGGL((snapkv_accum_kernel<DD, FP>), dim3((N + 63) / 64, KH, B), dim3(256), lds2, st, p);    \
+    } while (0)
     if (D == 128) {
-        hipLaunchKernelGGL((snapkv_stats_kernel<128>), dim3(p.nch, KH, B), dim3(256), lds1, st, p);
-        hipLaunchKernelGGL((snapkv_accum_kernel<128>), dim3((N + 63) / 64, KH, B), dim3(256), lds2, st, p);
+        if (fp8) MD_SNAP_LAUNCH(128, true); else MD_SNAP_LAUNCH(128, false);
     } else {
-        hipLaunchKernelGGL((snapkv_stats_kernel<64>), dim3(p.nch, KH, B), dim3(256), lds1, st, p);
-        hipLaunchKernelGGL((snapkv_accum_kernel<64>), dim3((N + 63) / 64, KH, B), dim3(256), lds2, st, p);
+        if (fp8) MD_SNAP_LAUNCH(64, true); else MD_SNAP_LAUNCH(64, false);
     }
+#undef MD_SNAP_LAUNCH
     MD_CHECK_LAUNCH("md_snapkv_select(scores)");
 
     const size_t lds3 = (size_t)((N + 7) / 8 * 8) * 2 + (256 + 1024 + 32) * 4;
@@ -464,7 +515,9 @@ extern "C" int md_snapkv_select(const void* q_win, const void* cache, const int3
     MD_CHECK_LAUNCH("md_snapkv_select(select)");
 
     GatherParams gp;
-    gp.cache = (const bf16_t*)cache;
+    gp.cache = cache;
+    gp.k_scale = k_scale;
+    gp.v_scale = v_scale;
     gp.page_indices = page_indices;
     gp.page_indptr = page_indptr;
     gp.dcache = (bf16_t*)draft_cache;
@@ -479,7 +532,10 @@ extern "C" int md_snapkv_select(const void* q_win, const void* cache, const int3
     gp.W = window;
     gp.budget = budget;
     gp.topk = topk;
-    hipLaunchKernelGGL(snapkv_gather_kernel, dim3(budget, KH, B), dim3(64), 0, st, gp);
+    if (fp8)
+        hipLaunchKernelGGL((snapkv_gather_kernel<true>), dim3(budget, KH, B), dim3(64), 0, st, gp);
+    else
+        hipLaunchKernelGGL((snapkv_gather_kernel<false>), dim3(budget, KH, B), dim3(64), 0, st, gp);
     MD_CHECK_LAUNCH("md_snapkv_select(gather)");
     return MD_OK;
 }

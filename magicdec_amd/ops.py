@@ -21,6 +21,25 @@ from . import _lib
 from ._lib import MagicDecHipError, check  # noqa: F401
 
 PAGE_SIZE = 128
+MD_KV_BF16, MD_KV_FP8_E4M3 = 0, 1      # include/magicdec_hip.h
+FP8_DTYPE = torch.float8_e4m3fn
+
+
+def _kv_args(kv_cache, kv_scales):
+    """(kv_dtype, k_scale ptr, v_scale ptr) for a paged cache: bf16 caches take no scales, e4m3fn caches
+    need per-kv-head float32 dequantisation scales `(k_scale[KH], v_scale[KH])`."""
+    if kv_cache.dtype == torch.bfloat16:
+        return MD_KV_BF16, None, None
+    if kv_cache.dtype != FP8_DTYPE:
+        raise TypeError(f"paged KV cache must be bfloat16 or float8_e4m3fn, got {kv_cache.dtype}")
+    if kv_scales is None:
+        raise ValueError("an fp8 KV cache needs kv_scales=(k_scale, v_scale)")
+    ks, vs = kv_scales
+    KH = kv_cache.shape[3]
+    for t in (ks, vs):
+        if t.dtype != torch.float32 or t.numel() != KH or not t.is_contiguous() or not t.is_cuda:
+            raise ValueError("kv scales must be contiguous float32 [KH] tensors on the GPU")
+    return MD_KV_FP8_E4M3, _p(ks), _p(vs)
 
 
 def _p(t):
@@ -51,7 +70,8 @@ def _row_stride(t):
 
 
 # ----------------------------------------------------------------------------- K4
-def update_kv(k, v, kv_append_indptr, kv_cache, kv_page_indices, kv_page_indptr, kv_page_lastlen, n_max=None):
+def update_kv(k, v, kv_append_indptr, kv_cache, kv_page_indices, kv_page_indptr, kv_page_lastlen, n_max=None,
+              kv_scales=None):
     """mylib::update_kv (Engine/utils.py:31-54).  In place on kv_cache."""
     _gpu(k, v, kv_cache)
     B = kv_page_indptr.numel() - 1
@@ -62,7 +82,8 @@ def update_kv(k, v, kv_append_indptr, kv_cache, kv_page_indices, kv_page_indptr,
     lib = _lib.load()
     check(lib.md_append_paged_kv(_p(k), _p(v), _row_stride(k), _row_stride(v), _p(_i32(kv_append_indptr)),
                                  _p(kv_cache), _p(_i32(kv_page_indices)), _p(_i32(kv_page_indptr)),
-                                 _p(_i32(kv_page_lastlen)), B, n_max, KH, D, kv_cache.shape[2], _stream()),
+                                 _p(_i32(kv_page_lastlen)), B, n_max, KH, D, kv_cache.shape[2],
+                                 *_kv_args(kv_cache, kv_scales), _stream()),
           "md_append_paged_kv")
 
 
@@ -103,8 +124,10 @@ def rope(q, k, indptr, offsets, table: RopeTable, n_max=None):
 
 
 def rope_append(q, k, v, indptr, offsets, table: RopeTable, kv_cache, page_indices, page_indptr, last_page_len,
-                kv_cache2=None, page_indices2=None, page_indptr2=None, last_page_len2=None, n_max=None):
-    """Fused mylib::rope + mylib::update_kv (+ second cache for self-spec verify).  Returns rotated q."""
+                kv_cache2=None, page_indices2=None, page_indptr2=None, last_page_len2=None, n_max=None,
+                kv_scales=None):
+    """Fused mylib::rope + mylib::update_kv (+ second cache for self-spec verify).  Returns rotated q.
+    kv_cache may be fp8 (with kv_scales); kv_cache2 is always bf16."""
     _gpu(q, k, v, kv_cache, kv_cache2)
     B = indptr.numel() - 1
     H, D = q.shape[1], q.shape[2]
@@ -117,7 +140,7 @@ def rope_append(q, k, v, indptr, offsets, table: RopeTable, kv_cache, page_indic
                              _p(_i32(indptr)), _p(_i32(offsets)), B, n_max, H, KH, D, _p(table.table), table.max_pos,
                              _p(kv_cache), _p(_i32(page_indices)), _p(_i32(page_indptr)), _p(_i32(last_page_len)),
                              _p(kv_cache2), _p(page_indices2), _p(page_indptr2), _p(last_page_len2),
-                             kv_cache.shape[2], _stream()), "md_rope_append")
+                             kv_cache.shape[2], *_kv_args(kv_cache, kv_scales), _stream()), "md_rope_append")
     return q_out
 
 
@@ -136,7 +159,7 @@ class AttnWorkspace:
 
 
 def paged_attention(q, kv_cache, qo_indptr, page_indices, page_indptr, last_page_len, n_max, max_pages_per_req,
-                    workspace: AttnWorkspace, causal=True, sm_scale=None, out=None):
+                    workspace: AttnWorkspace, causal=True, sm_scale=None, out=None, kv_scales=None):
     """mylib::target_decode / target_prefill / draft_decode / draft_prefill
     (Engine/SnapKV/backend.py:56-107): flashinfer BatchPrefillWithPagedKVCacheWrapper.run with the
     plan() arguments passed explicitly."""
@@ -154,7 +177,8 @@ def paged_attention(q, kv_cache, qo_indptr, page_indices, page_indptr, last_page
     ws = workspace.get(nbytes)
     check(lib.md_paged_attn(_p(q), _row_stride(q), _p(kv_cache), _p(out), _p(_i32(qo_indptr)), _p(_i32(page_indices)),
                             _p(_i32(page_indptr)), _p(_i32(last_page_len)), B, n_max, H, KH, D, page_size,
-                            1 if causal else 0, float(sm_scale), max_pages_per_req, _p(ws), ws.numel(), _stream()),
+                            1 if causal else 0, float(sm_scale), max_pages_per_req, *_kv_args(kv_cache, kv_scales),
+                            _p(ws), ws.numel(), _stream()),
           "md_paged_attn")
     return out
 
@@ -162,7 +186,7 @@ def paged_attention(q, kv_cache, qo_indptr, page_indices, page_indptr, last_page
 # ----------------------------------------------------------------------------- K6
 def snapkv_select(q_win, kv_cache, page_indices, page_indptr, ctx_len, window, budget, pool_kernel, draft_cache,
                   draft_page_indices, draft_page_indptr, draft_last_page_len, workspace: AttnWorkspace,
-                  return_scores=False):
+                  return_scores=False, kv_scales=None):
     """Attention.gen_draft_kv (Engine/SnapKV/model.py:389-439): writes budget rows per request and kv head
     into draft_cache; returns the selected positions [B, KH, budget-window] int32 (reference order)."""
     _gpu(q_win, kv_cache, draft_cache)
@@ -181,7 +205,8 @@ def snapkv_select(q_win, kv_cache, page_indices, page_indptr, ctx_len, window, b
     check(lib.md_snapkv_select(_p(q_win), _p(kv_cache), _p(_i32(page_indices)), _p(_i32(page_indptr)), B, H, KH, D,
                                kv_cache.shape[2], ctx_len, window, budget, pool_kernel, _p(draft_cache),
                                _p(_i32(draft_page_indices)), _p(_i32(draft_page_indptr)), _p(_i32(draft_last_page_len)),
-                               _p(idx), ctypes.c_void_p(ws.data_ptr() + off), nbytes, _stream()), "md_snapkv_select")
+                               _p(idx), *_kv_args(kv_cache, kv_scales), ctypes.c_void_p(ws.data_ptr() + off), nbytes,
+                               _stream()), "md_snapkv_select")
     if return_scores:
         soff = lib.md_snapkv_scores_offset(B, H, KH, ctx_len, window)
         n = B * KH * (ctx_len - window)

@@ -56,6 +56,33 @@ def append_paged_kv_cache(k, v, append_indptr, cache, indices, indptr, last_page
             cache[page, 1, slot] = v[a0 + j]
 
 
+# ---------------------------------------------------------------------------- fp8 (OCP e4m3fn) KV cache
+# Not a flashinfer 0.1.6 / MagicDec feature: BASELINE.json configs[4] asks for it as the CDNA4 fp8 path, so the
+# definition below IS the specification and the GPU kernels are checked against it.
+FP8_MAX = 448.0
+
+
+def quantize_fp8(x, scale):
+    """x [rows, KH, D] bf16, scale [KH] float32 -> e4m3fn bytes: rne(clamp(x * (1/scale), +-448)).
+    (float32 multiply by the float32 reciprocal; the clamp makes the cast saturating.)"""
+    inv = (1.0 / scale.float()).view(1, -1, 1)
+    return (x.float() * inv).clamp(-FP8_MAX, FP8_MAX).to(torch.float8_e4m3fn)
+
+
+def append_paged_kv_cache_fp8(k, v, append_indptr, cache, indices, indptr, last_page_len, k_scale, v_scale):
+    """append_paged_kv_cache into an e4m3fn cache (viewed as uint8 for the row copies)."""
+    append_paged_kv_cache(quantize_fp8(k, k_scale).view(torch.uint8), quantize_fp8(v, v_scale).view(torch.uint8),
+                          append_indptr, cache.view(torch.uint8), indices, indptr, last_page_len)
+
+
+def dequantize_cache_fp8(cache, k_scale, v_scale):
+    """e4m3fn cache [pages, 2, ps, KH, D] -> float32 cache of exact products byte * scale."""
+    out = cache.float()
+    out[:, 0] *= k_scale.float().view(1, 1, -1, 1)
+    out[:, 1] *= v_scale.float().view(1, 1, -1, 1)
+    return out
+
+
 def gather_request_kv(cache, indices, indptr, last_page_len, b):
     """All K,V rows of request b as [len_b, KH, D] tensors."""
     page_size = cache.shape[2]

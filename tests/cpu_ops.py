@@ -11,6 +11,18 @@ from oracle import flashinfer_ref as fr
 from oracle import magicdec_ref as mr
 
 TOPK_REPLAY = {"table": None, "pos": 0}     # reference tie resolution replay (see tests/test_oracle_golden.py)
+FP8_DTYPE = torch.float8_e4m3fn
+
+
+def _append(k, v, ip, cache, indices, indptr, last, kv_scales):
+    if cache.dtype == FP8_DTYPE:
+        fr.append_paged_kv_cache_fp8(k, v, ip, cache, indices, indptr, last, *kv_scales)
+    else:
+        fr.append_paged_kv_cache(k, v, ip, cache, indices, indptr, last)
+
+
+def _deq(cache, kv_scales):
+    return fr.dequantize_cache_fp8(cache, *kv_scales) if cache.dtype == FP8_DTYPE else cache
 
 
 class RopeTable:
@@ -29,8 +41,8 @@ class AttnWorkspace:
         return None
 
 
-def update_kv(k, v, ip, cache, indices, indptr, last, n_max=None):
-    fr.append_paged_kv_cache(k, v, ip, cache, indices, indptr, last)
+def update_kv(k, v, ip, cache, indices, indptr, last, n_max=None, kv_scales=None):
+    _append(k, v, ip, cache, indices, indptr, last, kv_scales)
 
 
 def rope(q, k, indptr, offsets, table, n_max=None):
@@ -41,22 +53,23 @@ def rope(q, k, indptr, offsets, table, n_max=None):
 
 
 def rope_append(q, k, v, indptr, offsets, table, cache, indices, iptr, last, cache2=None, indices2=None, iptr2=None,
-                last2=None, n_max=None):
+                last2=None, n_max=None, kv_scales=None):
     rq, rk = fr.apply_rope(q, k, indptr, offsets, table.table)
-    fr.append_paged_kv_cache(rk, v, indptr, cache, indices, iptr, last)
+    _append(rk, v, indptr, cache, indices, iptr, last, kv_scales)
     if cache2 is not None:
         fr.append_paged_kv_cache(rk, v, indptr, cache2, indices2, iptr2, last2)
     return rq
 
 
 def paged_attention(q, cache, qo_indptr, indices, indptr, last, n_max, max_pages, workspace, causal=True,
-                    sm_scale=None, out=None):
-    return fr.batch_prefill_paged(q, cache, qo_indptr, indices, indptr, last, q.shape[1], cache.shape[3], q.shape[2],
-                                  causal=causal, sm_scale=sm_scale)
+                    sm_scale=None, out=None, kv_scales=None):
+    return fr.batch_prefill_paged(q, _deq(cache, kv_scales), qo_indptr, indices, indptr, last, q.shape[1],
+                                  cache.shape[3], q.shape[2], causal=causal, sm_scale=sm_scale)
 
 
 def snapkv_select(q_win, cache, indices, indptr, ctx_len, window, budget, pool_kernel, draft_cache, dindices, dindptr,
-                  dlast, workspace, return_scores=False):
+                  dlast, workspace, return_scores=False, kv_scales=None):
+    cache = _deq(cache, kv_scales)          # fp8: rows are gathered as bf16(byte * scale)
     B = indptr.numel() - 1
     H, KH = q_win.shape[1], cache.shape[3]
     g = H // KH
@@ -78,7 +91,8 @@ def snapkv_select(q_win, cache, indices, indptr, ctx_len, window, budget, pool_k
     if TOPK_REPLAY["table"] is not None:
         TOPK_REPLAY["pos"] += 1
     ip = (torch.arange(B + 1) * budget).to(torch.int32)
-    fr.append_paged_kv_cache(torch.cat(nk), torch.cat(nv), ip, draft_cache, dindices, dindptr, dlast)
+    fr.append_paged_kv_cache(torch.cat(nk).to(draft_cache.dtype), torch.cat(nv).to(draft_cache.dtype), ip, draft_cache,
+                             dindices, dindptr, dlast)
     return torch.stack(idxs).to(torch.int32)
 
 

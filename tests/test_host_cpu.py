@@ -54,10 +54,11 @@ def test_ops_refuse_cpu_tensors_and_bad_arguments():
     with pytest.raises(ValueError):
         ops.rmsnorm(x, torch.ones(64, dtype=torch.bfloat16), 1e-5)
     lib = _lib.load()
-    rc = lib.md_paged_attn(None, 0, None, None, None, None, None, None, 1, 1, 8, 2, 128, 128, 1, 1.0, 1, None, 0, None)
+    rc = lib.md_paged_attn(None, 0, None, None, None, None, None, None, 1, 1, 8, 2, 128, 128, 1, 1.0, 1, 0, None, None,
+                           None, 0, None)
     assert rc == -1 and b"null pointer" in lib.md_last_error_string()
     p = ctypes.c_void_p(256)
-    rc = lib.md_paged_attn(p, 1024, p, p, p, p, p, p, 1, 1, 8, 2, 96, 128, 1, 1.0, 1, None, 0, None)
+    rc = lib.md_paged_attn(p, 1024, p, p, p, p, p, p, 1, 1, 8, 2, 96, 128, 1, 1.0, 1, 0, None, None, None, 0, None)
     assert rc == -2 and b"head_dim" in lib.md_last_error_string()
 
 
@@ -339,3 +340,33 @@ def test_hf_checkpoint_conversion_roundtrip():
     assert set(out) == set(sd)
     for k in sd:
         assert torch.equal(out[k], sd[k]), k
+
+
+def test_fp8_kv_cache_host_logic(cpu_ops_patched, ckpt_dir):
+    """kv_dtype="fp8" (BASELINE configs[4], not in the reference): the full cache is e4m3fn, scales are calibrated on
+    the first prefill chunk, the compressed draft cache stays bf16, and teacher-forced logits stay close to the
+    bf16-cache engine's (gate: relative L2 error of the verify logits <= 5%)."""
+    from magicdec_amd.Engine.SnapKV.backend import LMBackend
+    ids = next(iter(gc.synthetic_batches()))
+    logits = {}
+    for kvd in ("bf16", "fp8"):
+        eng = LMBackend(dtype=torch.bfloat16, device="cpu", dec_len=gc.GAMMA + 1, draft_dec_len=1)
+        eng.load_model(ckpt_dir / "tinytgt" / "model.pth", use_tp=False)
+        eng.setup_caches(max_batch_size=gc.B, max_seq_length=gc.MAX_LEN, draft_budget=gc.BUDGET, kv_dtype=kvd)
+        eng.encode(ids)
+        kvc = eng.model.layers[0].attention.kv_cache
+        assert kvc.kv_cache.dtype == (torch.float8_e4m3fn if kvd == "fp8" else torch.bfloat16)
+        assert kvc.draft_cache.dtype == torch.bfloat16
+        if kvd == "fp8":
+            assert kvc.calibrated and (kvc.k_scale != 1).all() and (kvc.v_scale > 0).all()
+            assert kvc.draft_cache.float().abs().sum() > 0          # SnapKV gather dequantised into the draft cache
+        probe = ids[:, :gc.GAMMA + 1].clone()
+        eng.verify(probe)
+        logits[kvd] = eng.model._last_logits.float()
+    rel = (logits["fp8"] - logits["bf16"]).norm() / logits["bf16"].norm()
+    assert rel <= 5e-2, rel
+    with pytest.raises(NotImplementedError):
+        from magicdec_amd.Engine.StreamingLLM.backend_draft import LMBackend_Draft
+        d = LMBackend_Draft(dtype=torch.bfloat16, device="cpu")
+        d.load_model(ckpt_dir / "tinytgt" / "model.pth", use_tp=False)
+        d.model.setup_caches(num_pages=4, streaming=True, draft_budget=gc.BUDGET, kv_dtype="fp8")
