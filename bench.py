@@ -61,6 +61,9 @@ def parse():
                     help="capture decode steps into hipGraphs (engine.compile()); default: on for 1 GPU")
     ap.add_argument("--no-graphs", dest="graphs", action="store_false")
     ap.add_argument("--checkpoints", type=Path, default=Path("checkpoints"))
+    ap.add_argument("--force-tp", action="store_true",
+                    help="development: take the tensor-parallel code path (RCCL init, sharding, all-reduces, TP argmax "
+                         "merge) even with one rank, to exercise it on a 1-GPU box")
     ap.add_argument("--kv-dtype", default="bf16", choices=["bf16", "fp8"],
                     help="full-context KV cache storage (fp8 = OCP e4m3fn, BASELINE configs[4]; default bf16 = the "
                          "reference's)")
@@ -142,7 +145,7 @@ def run(args, dev):
                               vocab_size=32000))
 
     tgt_name, drf_name, B, S, ML, BUDGET, G = WORKLOADS[args.workload]
-    use_tp = world > 1
+    use_tp = world > 1 or getattr(args, "force_tp", False)
     group = draft_group = None
     rank_group = list(range(world))
     draft_ranks = list(range(min(world, args.draft_tp)))
@@ -166,12 +169,15 @@ def run(args, dev):
     draft = None
     if in_draft and not selfspec:
         draft = LMBackend_Draft(dtype=torch.bfloat16, device=dev, draft_budget=BUDGET)
-        draft.load_model(args.checkpoints / drf_name / "model.pth", use_tp=len(draft_ranks) > 1,
+        draft.load_model(args.checkpoints / drf_name / "model.pth", use_tp=len(draft_ranks) > 1 or getattr(args, "force_tp", False),
                          rank_group=draft_ranks, group=draft_group)
         draft.setup_caches(max_batch_size=B, max_seq_length=ML, draft_budget=BUDGET)
     if args.graphs is None:
-        # TP>1: RCCL collectives inside a captured graph could not be validated on the 1-GPU development box
-        args.graphs = on_gpu and (world == 1) and os.environ.get("MAGICDEC_NO_GRAPHS", "0") != "1"
+        # Also under TP: the per-layer RCCL all-reduces are captured with the step (validated with a 1-rank RCCL
+        # group on the development box, profiles/r01_tp1rank_rccl_graphs.log; a capture failure falls back to
+        # eager launching with a warning, Engine/graph.py).  A TP8 shard's step is ~10 us kernels: eager
+        # launching would be host-bound by >2x.
+        args.graphs = on_gpu and os.environ.get("MAGICDEC_NO_GRAPHS", "0") != "1"
     if args.graphs:
         engine.compile()
         if draft is not None:
@@ -266,9 +272,10 @@ def run(args, dev):
     if args.graphs:
         # HIP events cannot be recorded inside a replayed graph: time the verify-attention launches in an eager
         # pass of the same iterations (same kernels, same shapes, same stream) right after the timed region
+        was = engine._use_graphs            # False if a capture failed and the back-end fell back to eager
         engine._use_graphs = False
         run_spec(1, min(args.steps, 8), forced)
-        engine._use_graphs = True
+        engine._use_graphs = was
     attn_ms = timer.mean_ms()
     n_attn = len(timer.pairs)
     dt_meas, tok_meas = run_spec(min(args.warmup, 2), max(args.steps // 4, 4), None)
@@ -324,7 +331,7 @@ def run(args, dev):
                                 f"TP{len(draft_ranks)} budget {BUDGET} gamma {G}, B={B} prefix={S} max_len={ML}"),
                    "acceptance": f"fixed replay alpha={args.alpha} (E[tokens/iter]={tok_replay / args.steps / B:.3f})",
                    "weights": "seeded random init (no checkpoints on the box)",
-                   "hip_graphs": bool(args.graphs)},
+                   "hip_graphs": bool(engine._use_graphs)},
         "speedup_vs_autoregressive": round(value / base_tps, 4),
         "autoregressive_tokens_per_s": round(base_tps, 2),
         "autoregressive_ms_per_step": round(dt_base / base_steps * 1e3, 4),

@@ -13,6 +13,8 @@ reference's semantics are unchanged); in the steady state of our own loop (in-pl
 """
 from __future__ import annotations
 
+import warnings
+
 import torch
 
 _STATE_BY_KIND = {
@@ -89,8 +91,19 @@ def run_captured(backend, key, fn, input_ids):
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
-            ent.static_out = fn(ent.static_in)
+        try:
+            with torch.cuda.graph(g):
+                ent.static_out = fn(ent.static_in)
+        except Exception as e:  # noqa: BLE001 -- e.g. a collective this RCCL build cannot capture
+            # Capture executes nothing and the warm-up runs above are idempotent, so the step can still be run
+            # eagerly.  The failure is deterministic (same code on every rank), so all ranks of a TP group take
+            # this branch together.  Loud, once: silently running eager would misreport what was measured.
+            torch.cuda.synchronize()
+            warnings.warn(f"[magicdec_amd] hipGraph capture of step {key} failed ({type(e).__name__}: {e}); "
+                          "this back-end continues WITHOUT graphs", RuntimeWarning, stacklevel=2)
+            backend._use_graphs = False
+            backend._graphs.clear()
+            return fn(input_ids)
         ent.graph = g
         backend._graphs[full_key] = ent
     _bind_state(backend, ent)
