@@ -16,9 +16,13 @@
 //     moves between lanes: the S^T accumulator registers ARE the B operand of
 //     the PV MFMA (after bf16 packing) with the key permutation
 //     slot(c,t) -> key (t>>2)*16 + c*4 + (t&3).
-//   * K image: row-major, 16-B chunks XOR-swizzled by (row & (CH-1)) ->
-//     conflict-free ds_read_b128 fragment reads.  V image: [d/16][32 keys][16]
+//   * K image: row-major with a 16-B row pad (pitch D*2+16: consecutive rows
+//     start 4 banks apart -> conflict-free ds_read_b128 fragment reads, and
+//     every LDS address is lane base + immediate).  V image: [d/16][32 keys][16]
 //     sub-tiles read with ds_read_b64_tr_b16 (hardware transpose).
+//   * the tile loop has a branch-free steady state (unconditional prefetch of
+//     tile t+NS) so that s_waitcnt vmcnt() only waits for the tile being
+//     consumed; the ragged tail runs in a separate drain loop.
 //   * g*(gamma+1) query rows share every K/V tile (16 rows for Llama-3.1-8B
 //     at gamma=3 = exactly one MFMA M tile).
 //   * verify/draft ("decode" variant): the 4 waves of a workgroup split the KV
@@ -27,6 +31,8 @@
 //   * chunked prefill ("splitq" variant): the 4 waves own different 16/32-row
 //     query tiles and each streams the causal KV range; workgroups sharing a
 //     (request, kv head) are placed on one XCD (block id mod 8) to share L2.
+#include <type_traits>
+
 #include "md_common.h"
 
 namespace {
@@ -55,7 +61,7 @@ constexpr int kVSub = 1056;  // bytes per [32 keys][16 d] V sub-tile (+32 B pad:
 
 template <int D, int QT>
 __host__ __device__ constexpr int attn_wave_lds() {
-    int stage = 32 * D * 2 + (D / 16) * kVSub;
+    int stage = 32 * (D * 2 + 16) + (D / 16) * kVSub;
     int merge = QT * D * 64 + QT * 128;
     int m = stage > merge ? stage : merge;
     return (m + 255) / 256 * 256;
@@ -102,16 +108,28 @@ __global__ __launch_bounds__(256, 2) void paged_attn_kernel(const AttnParams p) 
     constexpr int CH = D * EB / 16;          // 16-B chunks per K/V row in HBM
     constexpr int RPI = 64 / CH;             // rows per wave-wide load instruction
     constexpr int NL = 32 / RPI;             // load instructions per 32-key tile (K or V)
-    constexpr int CHL = D / 8;               // 16-B chunks per row of the bf16 LDS image
     constexpr int KS = D / 32;    // MFMA k-steps of QK^T
     constexpr int NB = D / 16;    // 16-wide d blocks of PV
-    constexpr int KROW = D * 2;
+    constexpr int KROW = D * 2 + 16;         // K image row pitch: +16 B pad instead of an XOR swizzle, so that every
+                                             // LDS address is (per-lane base + compile-time immediate)
     constexpr int K_BYTES = 32 * KROW;
+    // fp8, D=128: a lane's 16 bytes become two 16-B bf16 chunks; writing (lo,hi) to slots (2c,2c+1) makes 8
+    // consecutive lanes hit 32-B-strided addresses (2-way bank conflict).  Lanes with c >= 4 therefore write
+    // (lo,hi) to slots (2c+1,2c): this permutes d inside the K image (undone by loading Q with the same permutation)
+    // and inside V sub-tiles 4..7 (undone when O is stored).
+    constexpr bool FP8_SWAP = FP8 && D == 128;
     constexpr int WAVE_LDS = attn_wave_lds<D, QT>();
     constexpr int TSTEP = SPLITQ ? 1 : 4;
     // two tiles of loads in flight per wave where the register budget allows it (256 VGPRs at 2 waves/SIMD)
-    constexpr bool DBUF = (QT == 1) || (D == 64) || FP8;
-    constexpr int PF = (DBUF ? 2 : 1) * TSTEP;   // prefetch distance in tiles of this wave
+    // register staging depth: tiles of this wave whose loads are in flight while one tile is consumed.  Two where
+    // the register budget allows it (256 VGPRs at 2 waves/SIMD; QT=2 at D=128 needs them for O and Q).  Deeper
+    // staging was measured and does not help: with exact wait counts two tiles already cover the HBM latency.
+    constexpr int NS = ((QT == 1) || (D == 64) || FP8) ? 2 : 1;
+    // fp8 with two M tiles (e.g. Qwen2.5-32B: g=5, gamma+1=4 -> 20 rows) has no registers left for the duplicated
+    // steady-state body; it keeps both tiles in flight with the plain (conditional-prefetch) loop
+    constexpr bool STEADY = !(FP8 && QT == 2 && D == 128);
+    constexpr bool BATCH = (FP8 || D == 64) && QT == 1;
+    constexpr int PF = NS * TSTEP;   // prefetch distance in tiles of this wave
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;
@@ -173,11 +191,13 @@ __global__ __launch_bounds__(256, 2) void paged_attn_kernel(const AttnParams p) 
         const int R = (tile_base + qt) * 16 + lq;
         const bool valid = R < nrows;
         const int i = R / g, r = R - i * g;
-        const bf16_t* qp = p.q + (int64_t)(q0 + i) * p.q_row_stride + (kvh * g + r) * D + lc * 8;
+        const bf16_t* qp = p.q + (int64_t)(q0 + i) * p.q_row_stride + (kvh * g + r) * D;
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
             bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
-            qf[qt][s] = valid ? *reinterpret_cast<const bf16x8*>(qp + s * 32) : z;
+            int slot = s * 4 + lc;                       // 8-element d group held by K-image chunk slot `slot`
+            if (FP8_SWAP && s >= 2) slot ^= 1;
+            qf[qt][s] = valid ? *reinterpret_cast<const bf16x8*>(qp + slot * 8) : z;
         }
     }
 
@@ -200,18 +220,21 @@ __global__ __launch_bounds__(256, 2) void paged_attn_kernel(const AttnParams p) 
     // staging (write) side: lane -> (row wrow + j*RPI, 16-B HBM chunk wch).  bf16 cache: one 16-B LDS chunk;
     // fp8 cache: the 16 bytes expand to two adjacent bf16 chunks (2*wch, 2*wch+1) = one V sub-tile row
     const int wrow = lane / CH, wch = lane % CH;
-    int kw[NL], kw2[NL], vw[NL];
+    const bool swp = FP8_SWAP && wch >= 4;
+    int kw[NL], kw2[NL], vw[NL], vw2[NL];
 #pragma unroll
     for (int j = 0; j < NL; ++j) {
         const int row = wrow + j * RPI;
         if constexpr (FP8) {
-            kw[j] = row * KROW + (((2 * wch) ^ (row & (CHL - 1))) << 4);
-            kw2[j] = row * KROW + (((2 * wch + 1) ^ (row & (CHL - 1))) << 4);
-            vw[j] = wch * kVSub + row * 32;
+            kw[j] = row * KROW + ((2 * wch + (swp ? 1 : 0)) << 4);
+            kw2[j] = row * KROW + ((2 * wch + (swp ? 0 : 1)) << 4);
+            vw[j] = wch * kVSub + row * 32 + (swp ? 16 : 0);
+            vw2[j] = wch * kVSub + row * 32 + (swp ? 0 : 16);
         } else {
-            kw[j] = row * KROW + ((wch ^ (row & (CHL - 1))) << 4);
+            kw[j] = row * KROW + (wch << 4);
             kw2[j] = 0;
             vw[j] = (wch >> 1) * kVSub + row * 32 + (wch & 1) * 16;
+            vw2[j] = 0;
         }
     }
     // fragment (read) side
@@ -221,31 +244,53 @@ __global__ __launch_bounds__(256, 2) void paged_attn_kernel(const AttnParams p) 
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
             const int row = kb * 16 + lq, ch = s * 4 + lc;
-            kra[kb][s] = row * KROW + ((ch ^ (row & (CHL - 1))) << 4);
+            kra[kb][s] = row * KROW + (ch << 4);
         }
     const int vra = (lc * 4 + (lq >> 2)) * 32 + (lq & 3) * 8;  // + nb*kVSub + kb*512
-    const int goff = (wrow * p.slot_stride + kvh * D) * EB + wch * 16;  // bytes
+    const unsigned goff = (unsigned)((wrow * p.slot_stride + kvh * D) * EB + wch * 16);  // bytes, per lane
 
     // two tiles in flight per wavefront: register sets A and B alternate (2 x 16 KiB of loads outstanding while a
     // tile is computed -- the loop is latency x bandwidth bound, not compute bound)
-    u32x4 kA[NL], vA[NL], kB[NL], vB[NL];
+    u32x4 kR[NS][NL], vR[NS][NL];
     auto issue = [&](int tt, u32x4 (&kreg)[NL], u32x4 (&vreg)[NL]) {
         const int pos0 = tt * 32;
         const int page = pos0 / p.page_size;
         const int slot0 = pos0 - page * p.page_size;
         const int pid = __builtin_amdgcn_readfirstlane(p.page_indices[pg0 + page]);
+        // wave-uniform 64-bit base (SGPRs) + one shared 32-bit per-lane offset: the 2*NL loads of a tile then need
+        // no per-load address VGPRs (global_load ... v_off, s[base:base+1])
         const unsigned char* kb_ = reinterpret_cast<const unsigned char*>(p.cache) +
-                                   ((int64_t)pid * p.page_stride + (int64_t)slot0 * p.slot_stride) * EB + goff;
+                                   ((int64_t)pid * p.page_stride + (int64_t)slot0 * p.slot_stride) * EB;
         const unsigned char* vb_ = kb_ + p.kv_half * EB;
+        const int64_t jstep = (int64_t)RPI * p.slot_stride * EB;
 #pragma unroll
         for (int j = 0; j < NL; ++j)
-            kreg[j] = ldg_stream<!SPLITQ>(reinterpret_cast<const u32x4*>(kb_ + (int64_t)j * RPI * p.slot_stride * EB));
+            kreg[j] = ldg_stream<!SPLITQ>(reinterpret_cast<const u32x4*>(kb_ + j * jstep + goff));
 #pragma unroll
         for (int j = 0; j < NL; ++j)
-            vreg[j] = ldg_stream<!SPLITQ>(reinterpret_cast<const u32x4*>(vb_ + (int64_t)j * RPI * p.slot_stride * EB));
+            vreg[j] = ldg_stream<!SPLITQ>(reinterpret_cast<const u32x4*>(vb_ + j * jstep + goff));
     };
 
-    auto process = [&](int t, u32x4 (&kreg)[NL], u32x4 (&vreg)[NL]) {
+    // `always_prefetch` (a std::bool_constant): the steady-state loop issues the next tile's loads unconditionally, so
+    // the loop body is straight-line code and the compiler's s_waitcnt vmcnt() values are exact (only this tile's loads
+    // are waited for; the other NS-1 tiles stay in flight).  With a conditional prefetch the wait-count analysis
+    // merges the "issued" and "not issued" states at every join and degrades to vmcnt(0): every tile then drains the
+    // whole queue and a wavefront processes one tile per HBM round trip.
+    auto process = [&](auto always_prefetch, int t, u32x4 (&kreg)[NL], u32x4 (&vreg)[NL]) {
+#ifdef MD_ATTN_LOADS_ONLY   // experiment: memory-side ceiling of this access pattern (results are garbage)
+        {
+            u32x4 acc = {0u, 0u, 0u, 0u};
+#pragma unroll
+            for (int j = 0; j < NL; ++j) acc = acc ^ kreg[j] ^ vreg[j];
+            o[0][0][0] += __uint_as_float((acc[0] ^ acc[1] ^ acc[2] ^ acc[3]) & 0x007fffffu);
+            if constexpr (decltype(always_prefetch)::value) {
+                issue(t + PF, kreg, vreg);
+            } else {
+                if (t + PF < t_end) issue(t + PF, kreg, vreg);
+            }
+            return;
+        }
+#endif
         const bool need_mask = (t * 32 + 31) > lo;
         if (need_mask) {
             // rows past the request's length may hold anything (even NaN): zero V so 0*V stays 0
@@ -266,7 +311,7 @@ __global__ __launch_bounds__(256, 2) void paged_attn_kernel(const AttnParams p) 
                 u32x4 lo, hi;
                 cvt16_fp8_bf16(vreg[j], lo, hi);
                 *reinterpret_cast<u32x4*>(ldsV + vw[j]) = lo;
-                *reinterpret_cast<u32x4*>(ldsV + vw[j] + 16) = hi;
+                *reinterpret_cast<u32x4*>(ldsV + vw2[j]) = hi;
             }
         } else {
 #pragma unroll
@@ -274,7 +319,11 @@ __global__ __launch_bounds__(256, 2) void paged_attn_kernel(const AttnParams p) 
 #pragma unroll
             for (int j = 0; j < NL; ++j) *reinterpret_cast<u32x4*>(ldsV + vw[j]) = vreg[j];
         }
-        if (t + PF < t_end) issue(t + PF, kreg, vreg);
+        if constexpr (decltype(always_prefetch)::value) {
+            issue(t + PF, kreg, vreg);
+        } else {
+            if (t + PF < t_end) issue(t + PF, kreg, vreg);
+        }
         // same-wave LDS hand-off: LDS ops of one wave execute in order
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -287,15 +336,34 @@ __global__ __launch_bounds__(256, 2) void paged_attn_kernel(const AttnParams p) 
             s[qt][0] = f32x4{0.f, 0.f, 0.f, 0.f};
             s[qt][1] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
+        // BATCH (fp8 / D=64 variants: half the staging registers, so VGPRs are free and the per-key work is what
+        // bounds them): all K fragments of the tile are requested before the first MFMA -- one LDS round trip
+        // instead of 2*KS dependent ones.  The bf16 D=128 variants are HBM-bound and keep the register-lean order.
+        if constexpr (BATCH) {
+            bf16x8 kf[2][KS];
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
+            for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                const bf16x8 kf = lds_read_b128(ldsK + kra[kb][ks]);
+                for (int ks = 0; ks < KS; ++ks) kf[kb][ks] = lds_read_b128(ldsK + kra[kb][ks]);
+            __builtin_amdgcn_sched_barrier(0);   // keep the reads clustered (the scheduler would re-serialise them)
 #pragma unroll
-                for (int qt = 0; qt < QT; ++qt)
-                    s[qt][kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qt][ks], s[qt][kb], 0, 0, 0);
-            }
+            for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int qt = 0; qt < QT; ++qt)
+                        s[qt][kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[kb][ks], qf[qt][ks], s[qt][kb], 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    const bf16x8 kf = lds_read_b128(ldsK + kra[kb][ks]);
+#pragma unroll
+                    for (int qt = 0; qt < QT; ++qt)
+                        s[qt][kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qt][ks], s[qt][kb], 0, 0, 0);
+                }
+        }
 
         // ---- online softmax (log2 domain), statistics are per lane (query lq)
         bf16x8 pf[QT];
@@ -338,29 +406,47 @@ __global__ __launch_bounds__(256, 2) void paged_attn_kernel(const AttnParams p) 
         }
 
         // ---- O^T += V^T.P^T : A = V fragment (d x key slots) via transpose read
+        constexpr int VG = BATCH ? 4 : 1;   // V fragments requested per LDS round trip
 #pragma unroll
-        for (int nb = 0; nb < NB; ++nb) {
-            const bf16x4 v0 = lds_read_tr(ldsV + nb * kVSub + vra);
-            const bf16x4 v1 = lds_read_tr(ldsV + nb * kVSub + 512 + vra);
-            const bf16x8 vf = __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7);
+        for (int nb0 = 0; nb0 < NB; nb0 += VG) {
+            bf16x8 vf[VG];
 #pragma unroll
-            for (int qt = 0; qt < QT; ++qt)
-                o[qt][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[qt], o[qt][nb], 0, 0, 0);
+            for (int u = 0; u < VG; ++u) {
+                const bf16x4 v0 = lds_read_tr(ldsV + (nb0 + u) * kVSub + vra);
+                const bf16x4 v1 = lds_read_tr(ldsV + (nb0 + u) * kVSub + 512 + vra);
+                vf[u] = __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7);
+            }
+            if constexpr (BATCH) __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < VG; ++u)
+#pragma unroll
+                for (int qt = 0; qt < QT; ++qt)
+                    o[qt][nb0 + u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[u], pf[qt], o[qt][nb0 + u], 0, 0, 0);
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
     };
 
     int t = t_begin + (SPLITQ ? 0 : wave);
-    if (t < t_end) issue(t, kA, vA);
-    if constexpr (DBUF) {
-        if (t + TSTEP < t_end) issue(t + TSTEP, kB, vB);
-        for (; t < t_end; t += 2 * TSTEP) {
-            process(t, kA, vA);
-            if (t + TSTEP < t_end) process(t + TSTEP, kB, vB);
-        }
+    if (STEADY && t + (2 * NS - 1) * TSTEP < t_end) {
+        // steady state: NS tiles in flight, every processed tile re-arms its register set with tile t + PF
+#pragma unroll
+        for (int st = 0; st < NS; ++st) issue(t + st * TSTEP, kR[st], vR[st]);
+        do {
+#pragma unroll
+            for (int st = 0; st < NS; ++st) process(std::true_type{}, t + st * TSTEP, kR[st], vR[st]);
+            t += NS * TSTEP;
+        } while (t + (2 * NS - 1) * TSTEP < t_end);
+        // here tiles t + st*TSTEP (st < NS) are valid and in flight: the drain loop below finishes them
     } else {
-        for (; t < t_end; t += TSTEP) process(t, kA, vA);
+#pragma unroll
+        for (int st = 0; st < NS; ++st)
+            if (t + st * TSTEP < t_end) issue(t + st * TSTEP, kR[st], vR[st]);
+    }
+    for (; t < t_end; t += NS * TSTEP) {
+#pragma unroll
+        for (int st = 0; st < NS; ++st)
+            if (t + st * TSTEP < t_end) process(std::false_type{}, t + st * TSTEP, kR[st], vR[st]);
     }
 
     // row sums live as per-lane partials over the 4 lane groups of a query
@@ -378,11 +464,12 @@ __global__ __launch_bounds__(256, 2) void paged_attn_kernel(const AttnParams p) 
             if (R < nrows) {
                 const int i = R / g, r = R - i * g;
                 const float inv = l[qt] > 0.f ? vsc / l[qt] : 0.f;
-                bf16_t* op = p.out + ((int64_t)(q0 + i) * p.H + kvh * g + r) * D + lc * 4;
+                bf16_t* op = p.out + ((int64_t)(q0 + i) * p.H + kvh * g + r) * D;
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb) {
                     const f32x4 ov = o[qt][nb] * inv;
-                    *reinterpret_cast<bf16x4*>(op + nb * 16) = __builtin_convertvector(ov, bf16x4);
+                    const int dd = nb * 16 + ((FP8_SWAP && nb >= 4) ? (lc ^ 2) : lc) * 4;
+                    *reinterpret_cast<bf16x4*>(op + dd) = __builtin_convertvector(ov, bf16x4);
                 }
             }
         }
@@ -396,7 +483,10 @@ __global__ __launch_bounds__(256, 2) void paged_attn_kernel(const AttnParams p) 
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) mo[(qt * D + nb * 16 + lc * 4 + r) * 16 + lq] = o[qt][nb][r];
+                for (int r = 0; r < 4; ++r) {
+                    const int dd = nb * 16 + ((FP8_SWAP && nb >= 4) ? (lc ^ 2) : lc) * 4 + r;
+                    mo[(qt * D + dd) * 16 + lq] = o[qt][nb][r];
+                }
             if (lc == 0) {
                 mst[(qt * 16 + lq) * 2 + 0] = m[qt];
                 mst[(qt * 16 + lq) * 2 + 1] = l[qt];

@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from magicdec_amd import ops
 
 ap = argparse.ArgumentParser()
-for k, v in dict(B=64, S=16036, KH=8, H=32, D=128, n=4, iters=20, layers=2, wgs=0).items():
+for k, v in dict(B=64, S=16036, KH=8, H=32, D=128, n=4, iters=20, layers=2, wgs=0, fp8=0).items():
     ap.add_argument(f"--{k}", type=int, default=v)
 a = ap.parse_args()
 if a.wgs:
@@ -18,6 +18,10 @@ mp = (a.S + 127) // 128
 g = torch.Generator(device=dev).manual_seed(0)
 caches = [torch.randn(a.B * mp, 2, 128, a.KH, a.D, device=dev, generator=g, dtype=torch.float32).to(torch.bfloat16)
           for _ in range(a.layers)]           # > 256 MiB each: defeats the Infinity Cache between launches
+scales = None
+if a.fp8:
+    caches = [c.to(torch.float8_e4m3fn) for c in caches]
+    scales = (torch.full((a.KH,), 0.5, device=dev), torch.full((a.KH,), 0.25, device=dev))
 q = torch.randn(a.B * a.n, a.H, a.D, device=dev, generator=g, dtype=torch.float32).to(torch.bfloat16)
 indices = torch.arange(a.B * mp, dtype=torch.int32, device=dev)
 indptr = torch.arange(a.B + 1, dtype=torch.int32, device=dev) * mp
@@ -25,15 +29,15 @@ last = torch.full((a.B,), a.S - (mp - 1) * 128, dtype=torch.int32, device=dev)
 qo = torch.arange(a.B + 1, dtype=torch.int32, device=dev) * a.n
 ws = ops.AttnWorkspace(dev)
 for i in range(3):
-    ops.paged_attention(q, caches[i % a.layers], qo, indices, indptr, last, a.n, mp, ws)
+    ops.paged_attention(q, caches[i % a.layers], qo, indices, indptr, last, a.n, mp, ws, kv_scales=scales)
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
 for i in range(a.iters):
-    ops.paged_attention(q, caches[i % a.layers], qo, indices, indptr, last, a.n, mp, ws)
+    ops.paged_attention(q, caches[i % a.layers], qo, indices, indptr, last, a.n, mp, ws, kv_scales=scales)
 e1.record()
 torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / a.iters
-nbytes = a.B * a.S * a.KH * a.D * 2 * 2 + 2 * a.B * a.n * a.H * a.D * 2
+nbytes = a.B * a.S * a.KH * a.D * 2 * (1 if a.fp8 else 2) + 2 * a.B * a.n * a.H * a.D * 2
 print(f"md_paged_attn B={a.B} S={a.S} KH={a.KH} H={a.H} D={a.D} n={a.n}: {ms:.4f} ms  {nbytes / ms / 1e6:.1f} GB/s  "
-      f"{nbytes / ms / 1e6 / 80:.2f}% of 8 TB/s  (alg bytes {nbytes}) wgs={a.wgs}")
+      f"{nbytes / ms / 1e6 / 80:.2f}% of 8 TB/s  (alg bytes {nbytes}) wgs={a.wgs} fp8={a.fp8} map={os.environ.get('MD_ATTN_MAP', '0')}")
