@@ -13,7 +13,8 @@
  *     the parameter name ends in `_host`;
  *   - bf16 tensors are passed as `const void*` / `void*` (2-byte elements);
  *   - every call is asynchronous on `stream` (a hipStream_t passed as void*);
- *     nothing synchronises, allocates or frees device memory;
+ *     nothing synchronises, allocates or frees device memory (except the
+ *     md_ar_* set-up / tear-down calls);
  *   - return value: MD_OK (0) or a negative MD_ERR_* code; the message for
  *     the calling thread's last error is md_last_error_string();
  *   - page tables use the reference's (flashinfer 0.1.x) triple
@@ -231,6 +232,32 @@ int md_accept_rollback(int64_t* tokens_buffer, const int64_t* target_tokens, int
                        int draft_cap, int64_t eot_1, int64_t eot_2, int64_t max_nodes,
                        int64_t* accept_nums, int64_t* bonus, int64_t* double_buffer,
                        int64_t* cachelens_update, int32_t* flags, md_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * C1  one-shot sum-all-reduce of bf16 partials over peer-mapped buffers (xGMI)
+ *     reference: the two dist.all_reduce per layer, Engine/SnapKV/model.py:336,455
+ *     (Attention.forward / FeedForward.forward) and the StreamingLLM twins; NCCL there.
+ * One communicator per process group.  Set-up (host, once):
+ *   md_ar_create      allocates this rank's registered data buffer (2 x max_bytes) and signal area;
+ *   md_ar_get_handles writes 2 IPC handles (data, signal; MD_AR_HANDLE_BYTES each) to handles_host;
+ *                     the caller all-gathers them (any transport: torch.distributed / MPI / files);
+ *   md_ar_open_peers  takes the world x 2 handles in rank order and maps the peers' buffers.
+ * md_allreduce_oneshot: out = sum over ranks of in (count bf16, multiple of 8, count*2 <= max_bytes;
+ * in == out allowed), fp32 accumulation in rank order 0..world-1 -> bit-identical on every rank.
+ * Asynchronous on `stream`, capturable into a hipGraph (the call counter lives in device memory).
+ * All ranks of the communicator must issue the same sequence of calls.  A peer that never arrives makes
+ * the kernel give up after ~2 s and set the status word (md_ar_status: 0 = ok, 1 = timed out) instead
+ * of hanging the GPU.  Requires HSA_ENABLE_IPC_MODE_LEGACY=0 (dmabuf IPC) in the environment.
+ * ---------------------------------------------------------------------- */
+#define MD_AR_HANDLE_BYTES 64
+#define MD_AR_MAX_RANKS 8
+typedef struct md_ar_comm md_ar_comm;
+int md_ar_create(int rank, int world, size_t max_bytes, md_ar_comm** comm_out);
+int md_ar_get_handles(md_ar_comm* comm, void* handles_host /* 2 * MD_AR_HANDLE_BYTES */);
+int md_ar_open_peers(md_ar_comm* comm, const void* all_handles_host /* world * 2 * MD_AR_HANDLE_BYTES */);
+int md_allreduce_oneshot(md_ar_comm* comm, const void* in, void* out, size_t count, md_stream_t stream);
+int md_ar_status(md_ar_comm* comm, int* status_host);
+int md_ar_destroy(md_ar_comm* comm);
 
 #ifdef __cplusplus
 }

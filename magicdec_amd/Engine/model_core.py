@@ -293,8 +293,15 @@ class Transformer(nn.Module):
 
     # ------------------------------------------------------------------ building blocks
     def _reduce(self, y, group):
+        """The per-layer sum-all-reduce (C1).  RCCL by default; the one-shot xGMI kernel when tp.apply_tp attached
+        one (MAGICDEC_ONESHOT_AR=1) and the message fits its registered buffer (decode steps do, prefill chunks
+        do not)."""
         if group is not None:
-            dist.all_reduce(y, group=group)
+            ar = getattr(self, "_oneshot", None)
+            if ar is not None and ar.fits(y):
+                ar.all_reduce_(y)
+            else:
+                dist.all_reduce(y, group=group)
         return y
 
     def _qkv(self, layer, y2d):

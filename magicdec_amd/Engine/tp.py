@@ -39,7 +39,13 @@ def init_dist(draft_ranks=None):
     world_size = _get_world_size()
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29500")
-    if torch.cuda.is_available():
+    if torch.cuda.is_available() and os.environ.get("MAGICDEC_TP_SINGLE_GPU", "0") == "1":
+        # development / test hook: every rank uses GPU 0 (a 1-GPU box), gloo as the bootstrap and fallback
+        # transport (RCCL refuses two ranks on one device); with MAGICDEC_ONESHOT_AR=1 the per-layer all-reduces
+        # still run through the IPC one-shot kernel.  tests/test_gpu_engine.py::test_tp2_on_one_gpu
+        torch.cuda.set_device(0)
+        dist.init_process_group(backend="gloo", rank=global_rank, world_size=world_size)
+    elif torch.cuda.is_available():
         torch.cuda.set_device(global_rank)
         dist.init_process_group(backend="nccl", rank=global_rank, world_size=world_size,
                                 device_id=torch.device(f"cuda:{global_rank}"))
@@ -91,3 +97,6 @@ def apply_tp(model, rank_group, group) -> None:
     model.process_group = group
     model.world_size = dist.get_world_size(group)
     model.rank = dist.get_rank(group)
+    from . import oneshot
+    if oneshot.enabled():
+        model._oneshot = oneshot.OneShotAllReduce(group)

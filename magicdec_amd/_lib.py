@@ -11,7 +11,7 @@ from ctypes import c_char_p, c_double, c_float, c_int, c_int64, c_size_t, c_void
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmagicdec_hip.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 _lib = None
 _err = None
@@ -33,6 +33,12 @@ _SIGNATURES = {
     "md_snapkv_workspace_bytes": (c_size_t, [I, I, I, I, I]),
     "md_snapkv_scores_offset": (c_size_t, [I, I, I, I, I]),
     "md_snapkv_select": (c_int, [P, P, P, P, I, I, I, I, I, I, I, I, I, P, P, P, P, P, I, P, P, P, c_size_t, P]),
+    "md_ar_create": (c_int, [I, I, c_size_t, P]),
+    "md_ar_get_handles": (c_int, [P, P]),
+    "md_ar_open_peers": (c_int, [P, P]),
+    "md_allreduce_oneshot": (c_int, [P, P, P, c_size_t, P]),
+    "md_ar_status": (c_int, [P, P]),
+    "md_ar_destroy": (c_int, [P]),
     "md_streaming_shift_append": (c_int, [P, P, L, L, P, I, I, I, I, I, I, I, I, P]),
     "md_streaming_rotate": (c_int, [P, P, I, I, I, I, I, I, P, I, P]),
     "md_rmsnorm": (c_int, [P, P, P, I, I, c_float, P]),

@@ -1,0 +1,83 @@
+"""Worker of tests/test_gpu_allreduce.py: one of WORLD_SIZE processes that all use GPU 0 (the GPU box has a single
+device; IPC handles work between processes on the same device, which exercises the whole md_ar_* path -- handle
+export / exchange / mapping, the flag protocol, double buffering, graph replay -- everything except the xGMI hop).
+Bootstrap transport is gloo (RCCL refuses two ranks on one GPU)."""
+import os
+import sys
+
+import torch
+import torch.distributed as dist
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def expected(world, n, seed):
+    """sum in rank order, fp32 accumulate, one rounding -- the kernel's definition (csrc/allreduce.hip)."""
+    acc = torch.zeros(n, dtype=torch.float32)
+    ins = []
+    for r in range(world):
+        g = torch.Generator().manual_seed(seed * 100 + r)
+        x = (torch.randn(n, generator=g) * 3).to(torch.bfloat16)
+        ins.append(x)
+        acc += x.float()
+    return ins, acc.to(torch.bfloat16)
+
+
+def main():
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    from magicdec_amd.Engine.oneshot import OneShotAllReduce
+    ar = OneShotAllReduce(dist.group.WORLD, max_bytes=4 << 20)
+    dev = "cuda:0"
+    call = 0
+    # eager calls of many sizes (1 vector ... the full 4 MiB buffer), in place; odd/even call counts hit both halves
+    for n in (8, 64, 4096, 64 * 2048, 256 * 4096, 256 * 4096 + 8, 2 * 1024 * 1024):
+        for rep in range(3):
+            call += 1
+            ins, want = expected(world, n, call)
+            t = ins[rank].to(dev)
+            ar.all_reduce_(t)
+            got = t.cpu()
+            assert torch.equal(got.view(torch.int16), want.view(torch.int16)), (n, rep, "eager mismatch")
+    # a captured graph with three dependent all-reduces, replayed with fresh inputs (flags live in device memory)
+    n = 256 * 4096
+    static = [torch.zeros(n, dtype=torch.bfloat16, device=dev) for _ in range(3)]
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        for t in static:
+            ar.all_reduce_(t)              # warm-up outside capture
+    torch.cuda.current_stream().wait_stream(s)
+    torch.cuda.synchronize()
+    dist.barrier()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for t in static:
+            ar.all_reduce_(t)
+    for it in range(5):
+        wants = []
+        for k, t in enumerate(static):
+            call += 1
+            ins, want = expected(world, n, call)
+            t.copy_(ins[rank])
+            wants.append(want)
+        g.replay()
+        torch.cuda.synchronize()
+        for k, t in enumerate(static):
+            assert torch.equal(t.cpu().view(torch.int16), wants[k].view(torch.int16)), (it, k, "graph mismatch")
+    # argument validation
+    bad = torch.zeros(12, dtype=torch.bfloat16, device=dev)
+    try:
+        ar.all_reduce_(bad)
+        raise SystemExit("numel % 8 != 0 was accepted")
+    except ValueError:
+        pass
+    assert ar.status() == 0, "a kernel timed out waiting for its peer"
+    dist.barrier()
+    ar.close()
+    dist.destroy_process_group()
+    print(f"rank {rank}: OK ({call} all-reduces)")
+
+
+if __name__ == "__main__":
+    main()

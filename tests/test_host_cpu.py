@@ -60,6 +60,10 @@ def test_ops_refuse_cpu_tensors_and_bad_arguments():
     p = ctypes.c_void_p(256)
     rc = lib.md_paged_attn(p, 1024, p, p, p, p, p, p, 1, 1, 8, 2, 96, 128, 1, 1.0, 1, 0, None, None, None, 0, None)
     assert rc == -2 and b"head_dim" in lib.md_last_error_string()
+    comm = ctypes.c_void_p()
+    assert lib.md_ar_create(0, 9, 1 << 20, ctypes.byref(comm)) == -1 and b"world" in lib.md_last_error_string()
+    assert lib.md_ar_create(2, 2, 1 << 20, ctypes.byref(comm)) == -1
+    assert lib.md_allreduce_oneshot(None, p, p, 8, None) == -1
 
 
 # ------------------------------------------------------------------ host logic vs the reference's own traces
