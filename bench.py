@@ -331,7 +331,9 @@ def run(args, dev):
                                 f"TP{len(draft_ranks)} budget {BUDGET} gamma {G}, B={B} prefix={S} max_len={ML}"),
                    "acceptance": f"fixed replay alpha={args.alpha} (E[tokens/iter]={tok_replay / args.steps / B:.3f})",
                    "weights": "seeded random init (no checkpoints on the box)",
-                   "hip_graphs": bool(engine._use_graphs)},
+                   "hip_graphs": bool(engine._use_graphs),
+                   "allreduce": (None if not use_tp else
+                                 "oneshot-ipc" if getattr(engine.model, "_oneshot", None) is not None else "rccl")},
         "speedup_vs_autoregressive": round(value / base_tps, 4),
         "autoregressive_tokens_per_s": round(base_tps, 2),
         "autoregressive_ms_per_step": round(dt_base / base_steps * 1e3, 4),
