@@ -39,5 +39,8 @@ e1.record()
 torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / a.iters
 nbytes = a.B * a.S * a.KH * a.D * 2 * (1 if a.fp8 else 2) + 2 * a.B * a.n * a.H * a.D * 2
+flops = 4.0 * a.B * a.n * a.H * a.D * (a.S - a.n / 2.0)          # causal: row i of the chunk sees S - n + i + 1 keys
+if a.n >= 32:
+    print(f"  prefill view: {flops / ms / 1e9:.1f} TFLOP/s = {flops / ms / 1e9 / 25:.2f}% of 2.5 PFLOP/s dense bf16")
 print(f"md_paged_attn B={a.B} S={a.S} KH={a.KH} H={a.H} D={a.D} n={a.n}: {ms:.4f} ms  {nbytes / ms / 1e6:.1f} GB/s  "
       f"{nbytes / ms / 1e6 / 80:.2f}% of 8 TB/s  (alg bytes {nbytes}) wgs={a.wgs} fp8={a.fp8} map={os.environ.get('MD_ATTN_MAP', '0')}")
