@@ -153,6 +153,10 @@ def run(args, dev):
         from magicdec_amd.Engine.tp import init_dist
         _, group, draft_group = init_dist(draft_ranks)
     in_draft = rank in draft_ranks
+    # Collective of the per-layer partial sums: RCCL unless MAGICDEC_ONESHOT_AR=1 (Engine/oneshot.py; validated
+    # against RCCL at start-up, falls back on any disagreement).  Not the default: one-shot pulls (N-1) x the message
+    # into every rank -- right for the 256 KiB draft messages, no better than RCCL's ring for the 2 MiB verify
+    # message at N=8 (14 MiB inbound per rank) -- and it has only been exercised with processes sharing one GPU.
     setup_seed(123)
 
     selfspec = drf_name is None
@@ -320,6 +324,11 @@ def run(args, dev):
         # (FETCH_SIZE x2 + WRITE_SIZE, see the file); PMC collection cannot run inside bench.py itself
         with open(pmc_path) as f:
             traffic = json.load(f)["traffic_bytes_per_launch"]
+    ar_timeouts = None
+    if use_tp:
+        ars = [m._oneshot for m in ([engine.model] + ([draft.model] if draft is not None else []))
+               if getattr(m, "_oneshot", None) is not None]
+        ar_timeouts = sum(a.status() for a in ars) if ars else None      # must be 0: a time-out invalidates the run
     line = {
         "metric": "decode tokens/s/node + speedup vs autoregressive, Llama-3.1-8B B=64 prefix=16K",
         "value": round(value, 2), "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -333,7 +342,8 @@ def run(args, dev):
                    "weights": "seeded random init (no checkpoints on the box)",
                    "hip_graphs": bool(engine._use_graphs),
                    "allreduce": (None if not use_tp else
-                                 "oneshot-ipc" if getattr(engine.model, "_oneshot", None) is not None else "rccl")},
+                                 "oneshot-ipc" if getattr(engine.model, "_oneshot", None) is not None else "rccl"),
+                   "allreduce_timeouts": ar_timeouts},
         "speedup_vs_autoregressive": round(value / base_tps, 4),
         "autoregressive_tokens_per_s": round(base_tps, 2),
         "autoregressive_ms_per_step": round(dt_base / base_steps * 1e3, 4),

@@ -99,4 +99,4 @@ def apply_tp(model, rank_group, group) -> None:
     model.rank = dist.get_rank(group)
     from . import oneshot
     if oneshot.enabled():
-        model._oneshot = oneshot.OneShotAllReduce(group)
+        model._oneshot = oneshot.try_create(group)       # None (-> RCCL) unless every rank validated it

@@ -16,6 +16,7 @@
 //   area; then sums slice b over the N data buffers [k & 1] and writes `out`.
 // Two data buffers make a closing barrier unnecessary: a rank can only reach call k+2 (which overwrites buffer
 // [k & 1]) after every peer entered call k+1, i.e. after every peer finished reading in call k (stream order).
+// Every call launches the same kMaxBlocks blocks so that all per-block counters stay equal (see the launcher).
 // Signals live in uncached (fine-grained) memory; data buffers are ordinary device memory -- the system-scope
 // release / acquire pair performs the L2 write-back / invalidate the AMDGPU memory model prescribes.
 // Spins are bounded (kSpinTimeoutTicks): on timeout the kernel records an error and returns instead of hanging the GPU.
@@ -190,9 +191,11 @@ extern "C" int md_allreduce_oneshot(md_ar_comm* c, const void* in, void* out, si
         MD_CHECK_ARG(c->dev.data[r] && c->dev.sig[r], "md_allreduce_oneshot: peer %d not opened (md_ar_open_peers)", r);
     if (count == 0) return MD_OK;
     const size_t n_vec = count / 8;
-    // enough blocks to pull ~2 MiB over 7 links quickly, few enough that all of them are co-resident on every rank
-    int blocks = (int)((n_vec + 2 * kThreads - 1) / (2 * kThreads));
-    blocks = blocks < 1 ? 1 : (blocks > kMaxBlocks ? kMaxBlocks : blocks);
+    // Always the full grid, whatever the message size: every block then advances its call counter on every call,
+    // so all blocks of call k agree on the data-buffer half (k & 1).  (With a size-dependent grid the per-block
+    // counters drift apart when message sizes alternate, and a small call could overwrite a region of the half a
+    // slower peer is still reading for the previous, larger call.)  Idle blocks only run the flag handshake.
+    const int blocks = kMaxBlocks;
     hipStream_t st = (hipStream_t)stream;
 #define MD_AR_LAUNCH(N)                                                                                       \
     case N:                                                                                                   \

@@ -32,6 +32,21 @@ def main():
     dev = "cuda:0"
     call = 0
     # eager calls of many sizes (1 vector ... the full 4 MiB buffer), in place; odd/even call counts hit both halves
+    # sizes alternate (large, small, large, ...) without any host synchronisation between calls: a small call must
+    # never disturb the half-buffer a slower peer is still reading for the previous large call
+    pending = []
+    for rep in range(6):
+        for n in (2 * 1024 * 1024, 8, 256 * 4096, 4096, 64 * 2048, 64):
+            call += 1
+            ins, want = expected(world, n, call)
+            pending.append((n, ins[rank].to(dev), want))
+    torch.cuda.synchronize()
+    dist.barrier()
+    for n, t, want in pending:            # 36 kernels queued back to back
+        ar.all_reduce_(t)
+    torch.cuda.synchronize()
+    for n, t, want in pending:
+        assert torch.equal(t.cpu().view(torch.int16), want.view(torch.int16)), (n, "back-to-back mismatch")
     for n in (8, 64, 4096, 64 * 2048, 256 * 4096, 256 * 4096 + 8, 2 * 1024 * 1024):
         for rep in range(3):
             call += 1
