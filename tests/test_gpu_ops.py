@@ -85,6 +85,43 @@ def test_paged_attention_vs_oracle(ops, name, B, n, H, KH, D, lens, causal, scat
     assert (o - ref).abs().max().item() <= tol
 
 
+@pytest.mark.parametrize("name,H,KH,D,ns,lens,fp8", [
+    ("verify-ragged-rows", 8, 2, 128, [3, 4, 1], [300, 257, 64], False),
+    ("prefill-ragged-rows", 8, 2, 128, [100, 128, 0, 17], [384, 300, 50, 17], False),
+    ("prefill-ragged-rows-8waves", 16, 2, 128, [128, 37], [640, 200], False),
+    ("prefill-ragged-rows-d64", 32, 8, 64, [128, 5], [256, 130], False),
+    ("prefill-ragged-rows-fp8", 8, 2, 128, [100, 128, 17], [384, 300, 17], True),
+])
+def test_paged_attention_ragged_query_counts(ops, name, H, KH, D, ns, lens, fp8):
+    """qo_indptr with a different number of query rows per request (flashinfer allows it; the Engine happens to pass
+    equal counts): rows past a request's count must neither be read nor written, requests with 0 rows are skipped."""
+    B = len(ns)
+    cache, indices, indptr, last, max_pages = make_paged(B, lens, KH, D, seed=11, scatter=True)
+    g = torch.Generator().manual_seed(2)
+    tot = sum(ns)
+    q = torch.randn(tot, H, D, generator=g).to(BF)
+    qo = torch.tensor([0] + list(np.cumsum(ns)), dtype=torch.int32)
+    scales = None
+    ref_cache, dev_cache = cache, cache.to(DEV)
+    if fp8:
+        ks = 0.02 * (1 + torch.arange(KH, dtype=torch.float32))
+        vs = 0.015 * (1 + torch.arange(KH, dtype=torch.float32))
+        P, _, ps, _, _ = cache.shape
+        c8 = torch.empty(cache.shape, dtype=torch.float8_e4m3fn)
+        c8[:, 0] = fr.quantize_fp8(cache[:, 0].reshape(-1, KH, D), ks).view(P, ps, KH, D)
+        c8[:, 1] = fr.quantize_fp8(cache[:, 1].reshape(-1, KH, D), vs).view(P, ps, KH, D)
+        ref_cache, dev_cache, scales = fr.dequantize_cache_fp8(c8, ks, vs), c8.to(DEV), (ks.to(DEV), vs.to(DEV))
+    ref = fr.batch_prefill_paged(q, ref_cache, qo, indices, indptr, last, H, KH, D, causal=True).float()
+    ws = ops.AttnWorkspace(DEV)
+    out = torch.full((tot + 2, H, D), 7.0, dtype=BF, device=DEV)          # 2 guard rows
+    ops.paged_attention(q.to(DEV), dev_cache, qo.to(DEV), indices.to(DEV), indptr.to(DEV), last.to(DEV), max(ns),
+                        max_pages, ws, causal=True, out=out[:tot], kv_scales=scales)
+    o = out.float().cpu()
+    assert (o[tot:] == 7.0).all(), "wrote past the last query row"
+    tol = 2e-2 * max(1.0, ref.abs().max().item())
+    assert not torch.isnan(o).any() and (o[:tot] - ref).abs().max().item() <= tol
+
+
 def test_paged_attention_ignores_garbage_beyond_length(ops):
     """Rows past a request's length may hold NaN/Inf (stale pages): they must not leak into the output."""
     B, n, H, KH, D = 2, 4, 8, 2, 128
