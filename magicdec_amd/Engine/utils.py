@@ -46,7 +46,7 @@ def _random_init_(model, seed, device, dtype, std=0.02):
         g = torch.Generator(device="cpu").manual_seed(seed * 100003 + j)
         if p.dim() == 1 and "norm" in name:
             t = torch.ones(p.shape, dtype=dtype)
-        elif p.numel() > (1 << 24) and torch.device(device).type == "cuda":
+        elif p.numel() >= (1 << 20) and torch.device(device).type == "cuda":      # Philox on the GPU: same bits on every rank
             gg = torch.Generator(device=device).manual_seed(seed * 100003 + j)
             t = (torch.randn(p.shape, generator=gg, device=device, dtype=torch.float32) * std).to(dtype)
         else:
