@@ -129,11 +129,15 @@ __global__ __launch_bounds__(256, 2) void paged_attn_kernel(const AttnParams p) 
     // register staging depth: tiles of this wave whose loads are in flight while one tile is consumed.  Two where
     // the register budget allows it (256 VGPRs at 2 waves/SIMD; QT=2 at D=128 needs them for O and Q).  Deeper
     // staging was measured and does not help: with exact wait counts two tiles already cover the HBM latency.
-    constexpr int NS = ((QT == 1) || (D == 64) || FP8) ? 2 : 1;
+    // two M tiles at D=128 (g*(gamma+1) in 17..32: Qwen2.5-32B g=5, Llama-70B g=8) are register-bound; measured best:
+    // fp8: both tiles in flight + batched fragment reads, plain loop (60-63 % of peak vs 57-59 % for the other
+    // combinations); bf16: one tile in flight, steady loop (70-78 %; batching / plain loop measured equal, two tiles spill)
+    constexpr bool Q2F8 = FP8 && QT == 2 && D == 128 && !SPLITQ;
+    constexpr int NS = Q2F8 ? 2 : (QT == 2 && D == 128) ? 1 : 2;
     // fp8 with two M tiles (e.g. Qwen2.5-32B: g=5, gamma+1=4 -> 20 rows) has no registers left for the duplicated
     // steady-state body; it keeps both tiles in flight with the plain (conditional-prefetch) loop
-    constexpr bool STEADY = !(FP8 && QT == 2 && D == 128);
-    constexpr bool BATCH = (FP8 || D == 64) && QT == 1;
+    constexpr bool STEADY = !Q2F8;
+    constexpr bool BATCH = Q2F8 || ((FP8 || D == 64) && QT == 1);
     constexpr int PF = NS * TSTEP;   // prefetch distance in tiles of this wave
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
