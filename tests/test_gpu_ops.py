@@ -407,3 +407,53 @@ def test_snapkv_select_vs_reference_fixture(ops, tag, golden_dir):
             assert torch.equal(bits(rows_v[:topk]), bits(v[b][mine, h]))
             assert torch.equal(bits(rows_k[topk:]), bits(k[b][S - W:, h]))
             assert torch.equal(bits(rows_v[topk:]), bits(v[b][S - W:, h]))
+
+
+def test_snapkv_select_full_size_properties(ops):
+    """SnapKV select at the BASELINE context length (S=16032, window 32, budget 257; 1B-draft head geometry): the
+    oracle is too slow at this size, so the size-independent properties are asserted instead -- indices unique and
+    inside [0, S-W); exactly the stable descending top-k of the kernel's own pooled scores (order and tie-break);
+    draft-cache rows bit-equal to the source rows at those indices followed by the last W rows; run-to-run
+    deterministic; stale bytes beyond S never selected."""
+    B, KH, g, D, S, W, budget = 4, 2, 4, 64, 16032, 32, 257
+    H = KH * g
+    npg = (S + 127) // 128
+    gen = torch.Generator(device=DEV).manual_seed(5)
+    cache = torch.randn(B * npg, 2, 128, KH, D, device=DEV, generator=gen, dtype=torch.float32).to(BF)
+    # poison the slots past S in every request's last page: they must never be read as candidates
+    tail = S - (npg - 1) * 128
+    for b in range(B):
+        cache[(b + 1) * npg - 1, :, tail:] = float("nan")
+    q = (torch.randn(B * W, H, D, device=DEV, generator=gen, dtype=torch.float32) * 0.3).to(BF)
+    dppr = budget // 128 + 1
+    indices = torch.arange(B * npg, dtype=torch.int32, device=DEV)
+    indptr = (torch.arange(B + 1, dtype=torch.int32) * npg).to(DEV)
+    dind = torch.arange(B * dppr, dtype=torch.int32, device=DEV)
+    dptr = (torch.arange(B + 1, dtype=torch.int32) * dppr).to(DEV)
+    dlast = torch.ones(B, dtype=torch.int32, device=DEV)
+    ws = ops.AttnWorkspace(DEV)
+    runs = []
+    for _ in range(2):
+        dcache = torch.zeros(B * dppr, 2, 128, KH, D, dtype=BF, device=DEV)
+        idx, sc = ops.snapkv_select(q, cache, indices, indptr, S, W, budget, 5, dcache, dind, dptr, dlast, ws,
+                                    return_scores=True)
+        runs.append((idx.cpu().long(), sc.cpu(), dcache.cpu()))
+    (idx, sc, dk), (idx2, sc2, dk2) = runs
+    assert torch.equal(idx, idx2) and torch.equal(bits(sc), bits(sc2)) and torch.equal(bits(dk), bits(dk2))
+    assert not torch.isnan(sc.float()).any()
+    topk = budget - W
+    src = cache.cpu()
+    for b in range(B):
+        k_all = src[b * npg:(b + 1) * npg, 0].reshape(-1, KH, D)
+        v_all = src[b * npg:(b + 1) * npg, 1].reshape(-1, KH, D)
+        for h in range(KH):
+            mine = idx[b, h]
+            assert mine.min() >= 0 and mine.max() < S - W and len(set(mine.tolist())) == topk
+            want = torch.sort(sc[b, h].float(), descending=True, stable=True).indices[:topk]
+            assert torch.equal(mine, want), "not the stable descending top-k of the pooled scores"
+            rows_k = dk[b * dppr:(b + 1) * dppr, 0].reshape(-1, KH, D)[:budget, h]
+            rows_v = dk[b * dppr:(b + 1) * dppr, 1].reshape(-1, KH, D)[:budget, h]
+            assert torch.equal(bits(rows_k[:topk]), bits(k_all[mine, h]))
+            assert torch.equal(bits(rows_v[:topk]), bits(v_all[mine, h]))
+            assert torch.equal(bits(rows_k[topk:]), bits(k_all[S - W:S, h]))
+            assert torch.equal(bits(rows_v[topk:]), bits(v_all[S - W:S, h]))
