@@ -64,6 +64,10 @@ def parse():
     ap.add_argument("--force-tp", action="store_true",
                     help="development: take the tensor-parallel code path (RCCL init, sharding, all-reduces, TP argmax "
                          "merge) even with one rank, to exercise it on a 1-GPU box")
+    ap.add_argument("--emulate-tp", type=int, default=0, metavar="N",
+                    help="development: shard the models as rank 0 of an N-way tensor-parallel group but run alone "
+                         "(collectives over a 1-rank group): measures one rank's compute of a TP-N run on a 1-GPU box; "
+                         "tokens are meaningless (partial sums are not reduced)")
     ap.add_argument("--kv-dtype", default="bf16", choices=["bf16", "fp8"],
                     help="full-context KV cache storage (fp8 = OCP e4m3fn, BASELINE configs[4]; default bf16 = the "
                          "reference's)")
@@ -121,6 +125,14 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
     torch.cuda.set_device(local_rank)
     line = run(args, f"cuda:{local_rank}")
+    # RCCL prints its version banner through C stdio, which is fully buffered on a pipe and would otherwise be
+    # flushed at process exit, i.e. AFTER the JSON line: flush it first so that the JSON line is the last line
+    import ctypes
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except OSError:
+        pass
+    sys.stderr.flush()
     if line is not None:
         print(json.dumps(line), flush=True)
 
@@ -145,13 +157,14 @@ def run(args, dev):
                               vocab_size=32000))
 
     tgt_name, drf_name, B, S, ML, BUDGET, G = WORKLOADS[args.workload]
-    use_tp = world > 1 or getattr(args, "force_tp", False)
+    emu = getattr(args, "emulate_tp", 0)
+    use_tp = world > 1 or getattr(args, "force_tp", False) or emu > 1
     group = draft_group = None
-    rank_group = list(range(world))
-    draft_ranks = list(range(min(world, args.draft_tp)))
+    rank_group = list(range(emu if emu > 1 else world))
+    draft_ranks = list(range(min(len(rank_group), args.draft_tp)))
     if use_tp:
         from magicdec_amd.Engine.tp import init_dist
-        _, group, draft_group = init_dist(draft_ranks)
+        _, group, draft_group = init_dist([0] if emu > 1 else draft_ranks)
     in_draft = rank in draft_ranks
     # Collective of the per-layer partial sums: RCCL unless MAGICDEC_ONESHOT_AR=1 (Engine/oneshot.py; validated
     # against RCCL at start-up, falls back on any disagreement).  Not the default: one-shot pulls (N-1) x the message
@@ -237,7 +250,7 @@ def run(args, dev):
             dist.barrier()
         _sync(dev)
 
-    bcast = (draft_ranks[0], group) if (use_tp and len(draft_ranks) != world) else None
+    bcast = (draft_ranks[0], group) if (use_tp and len(draft_ranks) != len(rank_group)) else None
 
     def iteration(next_double, forced):
         """One speculative iteration across the TP group (draft sub-group drafts, tokens broadcast, all verify)."""
@@ -319,7 +332,7 @@ def run(args, dev):
 
     traffic = None
     pmc_path = os.path.join(ROOT, "profiles", "r01_verify_attn_pmc.json")
-    if args.workload == "cfg3" and world == 1 and args.kv_dtype == "bf16" and os.path.exists(pmc_path):
+    if args.workload == "cfg3" and not use_tp and args.kv_dtype == "bf16" and os.path.exists(pmc_path):
         # HBM bytes per launch from the committed rocprofv3 PMC passes of this kernel at this layer shape
         # (FETCH_SIZE x2 + WRITE_SIZE, see the file); PMC collection cannot run inside bench.py itself
         with open(pmc_path) as f:
@@ -341,6 +354,7 @@ def run(args, dev):
                    "acceptance": f"fixed replay alpha={args.alpha} (E[tokens/iter]={tok_replay / args.steps / B:.3f})",
                    "weights": "seeded random init (no checkpoints on the box)",
                    "hip_graphs": bool(engine._use_graphs),
+                   **({"emulated_tp_rank0_of": emu} if emu > 1 else {}),
                    "allreduce": (None if not use_tp else
                                  "oneshot-ipc" if getattr(engine.model, "_oneshot", None) is not None else "rccl"),
                    "allreduce_timeouts": ar_timeouts},

@@ -92,7 +92,10 @@ def run_captured(backend, key, fn, input_ids):
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
         try:
-            with torch.cuda.graph(g):
+            # thread_local: the RCCL watchdog thread of torch.distributed polls hipEventQuery concurrently; in the
+            # default "global" capture mode such a call from ANY thread invalidates the capture and kills the process
+            # ("operation not permitted when stream is capturing", seen intermittently with a TP group)
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
                 ent.static_out = fn(ent.static_in)
         except Exception as e:  # noqa: BLE001 -- e.g. a collective this RCCL build cannot capture
             # Capture executes nothing and the warm-up runs above are idempotent, so the step can still be run

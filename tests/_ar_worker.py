@@ -66,7 +66,7 @@ def main():
     torch.cuda.synchronize()
     dist.barrier()
     g = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g):
+    with torch.cuda.graph(g, capture_error_mode="thread_local"):
         for t in static:
             ar.all_reduce_(t)
     for it in range(5):
