@@ -353,3 +353,26 @@ def test_tp2_on_one_gpu(ckpt_dir, graphs=False):
     # agreeing prefix is reported, not gated (the logits above are the gate)
     print(f"[TP2 vs TP1] free-running agreeing prefix {agree}/{total} generated tokens")
     assert total > 0
+
+
+def test_bench_tp_code_path_with_rccl_graphs_one_rank():
+    """bench.py on the tensor-parallel code path (RCCL process group of one rank, models sharded as rank 0 of 2,
+    per-layer all-reduces and the TP argmax merge captured inside the hipGraph steps): runs to completion, the JSON
+    line is the LAST line of stdout (RCCL's stdio banner must not trail it) and the steps really were graphs.
+    Guards two multi-GPU-only failures found this round: the RCCL watchdog's event queries killing a global-mode
+    capture, and the buffered RCCL banner landing after the JSON line."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29800 + os.getpid() % 100))
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--workload", "tiny", "--emulate-tp", "2",
+                        "--no-cpu-baseline", "--steps", "8", "--warmup", "2"], env=env, cwd=root,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    last = [l for l in p.stdout.splitlines() if l.strip()][-1]
+    line = json.loads(last)
+    assert line["config"]["hip_graphs"] is True and line["config"]["allreduce"] == "rccl"
+    assert line["config"]["emulated_tp_rank0_of"] == 2 and line["value"] > 0 and line["roofline"]["traffic"] is None
