@@ -88,11 +88,14 @@ __global__ __launch_bounds__(256) void silu_mul_kernel(const bf16_t* __restrict_
     }
 }
 
-// one workgroup per row; lowest index among equal maxima
-__global__ __launch_bounds__(256) void argmax_kernel(const bf16_t* __restrict__ logits, int64_t row_stride, int vocab,
-                                                     int64_t index_offset, bf16_t* max_val_out, int64_t* idx_out) {
-    __shared__ float sv[4];
-    __shared__ int si[4];
+// one workgroup of NT threads per row; lowest index among equal maxima.  Decode steps have few rows (64..256) of a
+// 128K vocabulary: with NT = 1024 (16 waves, 4 loads in flight each) a row is limited by its CU's load issue rate
+// instead of by one wave's memory latency (49 -> ~15 us for 64 rows)
+template <int NT>
+__global__ __launch_bounds__(NT) void argmax_kernel(const bf16_t* __restrict__ logits, int64_t row_stride, int vocab,
+                                                    int64_t index_offset, bf16_t* max_val_out, int64_t* idx_out) {
+    __shared__ float sv[NT / 64];
+    __shared__ int si[NT / 64];
     const int64_t row = blockIdx.x;
     const bf16_t* p = logits + row * row_stride;
     float best = -INFINITY;
@@ -100,7 +103,8 @@ __global__ __launch_bounds__(256) void argmax_kernel(const bf16_t* __restrict__ 
     const int nvec = vocab / 8;
     const bool vec_ok = (((uintptr_t)p) & 15) == 0;
     if (vec_ok) {
-        for (int i = threadIdx.x; i < nvec; i += 256) {
+#pragma unroll 4
+        for (int i = threadIdx.x; i < nvec; i += NT) {
             const f32x8 f = __builtin_convertvector(reinterpret_cast<const bf16x8*>(p)[i], f32x8);
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
@@ -112,7 +116,7 @@ __global__ __launch_bounds__(256) void argmax_kernel(const bf16_t* __restrict__ 
                 }
             }
         }
-        for (int id = nvec * 8 + threadIdx.x; id < vocab; id += 256) {
+        for (int id = nvec * 8 + threadIdx.x; id < vocab; id += NT) {
             const float v = bf16_to_f32(p[id]);
             if (v > best || (v == best && id < bi)) {
                 best = v;
@@ -120,7 +124,7 @@ __global__ __launch_bounds__(256) void argmax_kernel(const bf16_t* __restrict__ 
             }
         }
     } else {
-        for (int id = threadIdx.x; id < vocab; id += 256) {
+        for (int id = threadIdx.x; id < vocab; id += NT) {
             const float v = bf16_to_f32(p[id]);
             if (v > best || (v == best && id < bi)) {
                 best = v;
@@ -144,7 +148,7 @@ __global__ __launch_bounds__(256) void argmax_kernel(const bf16_t* __restrict__ 
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        for (int w = 1; w < 4; ++w)
+        for (int w = 1; w < NT / 64; ++w)
             if (sv[w] > best || (sv[w] == best && si[w] < bi)) {
                 best = sv[w];
                 bi = si[w];
@@ -215,8 +219,12 @@ extern "C" int md_argmax(const void* logits, int64_t row_stride, int rows, int v
                          void* max_val_out, int64_t* idx_out, md_stream_t stream) {
     MD_CHECK_ARG(logits && idx_out, "md_argmax: null pointer argument");
     MD_CHECK_ARG(rows > 0 && vocab > 0, "md_argmax: bad shape rows=%d vocab=%d", rows, vocab);
-    hipLaunchKernelGGL(argmax_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)logits, row_stride,
-                       vocab, index_offset, (bf16_t*)max_val_out, idx_out);
+    if (rows <= 512 && vocab >= 16384)
+        hipLaunchKernelGGL((argmax_kernel<1024>), dim3(rows), dim3(1024), 0, (hipStream_t)stream, (const bf16_t*)logits,
+                           row_stride, vocab, index_offset, (bf16_t*)max_val_out, idx_out);
+    else
+        hipLaunchKernelGGL((argmax_kernel<256>), dim3(rows), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)logits,
+                           row_stride, vocab, index_offset, (bf16_t*)max_val_out, idx_out);
     MD_CHECK_LAUNCH("md_argmax");
     return MD_OK;
 }

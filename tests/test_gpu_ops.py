@@ -267,12 +267,15 @@ def test_silu_mul(ops):
     assert _ulp_close(y, ref)
 
 
-def test_argmax_lowest_index_and_tp_merge(ops):
+@pytest.mark.parametrize("vocab", [16032, 128256, 32003])      # 256-thread, 1024-thread, unaligned-row kernels
+def test_argmax_lowest_index_and_tp_merge(ops, vocab):
     g = torch.Generator().manual_seed(6)
-    logits = torch.randn(9, 16032, generator=g).to(BF)
+    logits = torch.randn(9, vocab, generator=g).to(BF)
     logits[3, 100] = logits[3].max()
     logits[3, 7000] = logits[3, 100]                   # exact tie -> lowest index
+    logits[4, vocab - 1] = logits[4].max() + 1         # maximum in the last element (tail loop)
     logits[5] = 0                                      # all equal -> index 0
+    logits[6, vocab - 3] = logits[6].max()             # tie between an early wave's element and the tail
     ref = torch.tensor([int(torch.nonzero(row == row.max())[0]) for row in logits.float()])
     vals, idx = ops.argmax(logits.to(DEV), index_offset=16032 * 2, return_values=True)
     assert torch.equal(idx.cpu(), ref + 16032 * 2)
