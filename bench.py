@@ -46,6 +46,11 @@ WORKLOADS = {
     "tiny": ("llama-68m-gqa", "llama-68m-gqa", 4, 416, 512, 129, 3),
     # configs[1] of BASELINE.json: self-speculation, StreamingLLM draft cache (one model, two caches)
     "cfg2": ("Meta-Llama-3.1-8B", None, 32, 8065, 8192, 257, 3),
+    # configs[3] / configs[4]: TP8 configurations -- on one GPU only as `--emulate-tp 8` (one rank's compute)
+    "cfg4": ("Meta-Llama-3.1-70B", "Llama-3.2-1B", 32, 32641, 32768, 513, 3, "longspec-stream"),
+    "cfg5": ("Qwen2.5-32B", None, 128, 65440, 65536, 257, 3, "selfspec-snapkv"),
+    "tiny-selfspec-snapkv": ("llama-68m-gqa", None, 4, 416, 512, 129, 3, "selfspec-snapkv"),
+    "tiny-longspec-stream": ("llama-68m-gqa", "llama-68m-gqa", 4, 416, 512, 129, 3, "longspec-stream"),
 }
 
 
@@ -156,7 +161,11 @@ def run(args, dev):
         "llama-68m-gqa", dict(block_size=2048, n_layer=2, n_head=16, n_local_heads=4, dim=1024, intermediate_size=2048,
                               vocab_size=32000))
 
-    tgt_name, drf_name, B, S, ML, BUDGET, G = WORKLOADS[args.workload]
+    wl = WORKLOADS[args.workload]
+    tgt_name, drf_name, B, S, ML, BUDGET, G = wl[:7]
+    kind = wl[7] if len(wl) > 7 else ("selfspec-stream" if drf_name is None else "longspec-snapkv")
+    if args.workload == "cfg5" and "--kv-dtype" not in sys.argv:
+        args.kv_dtype = "fp8"                       # BASELINE configs[4] names the fp8 KV cache
     emu = getattr(args, "emulate_tp", 0)
     use_tp = world > 1 or getattr(args, "force_tp", False) or emu > 1
     group = draft_group = None
@@ -172,23 +181,37 @@ def run(args, dev):
     # message at N=8 (14 MiB inbound per rank) -- and it has only been exercised with processes sharing one GPU.
     setup_seed(123)
 
-    selfspec = drf_name is None
+    selfspec = kind.startswith("selfspec")
+    streaming = kind.endswith("stream")            # the draft-side cache: StreamingLLM ring, else SnapKV select
     t_load = time.time()
-    if selfspec:
+    if selfspec and streaming:
         from magicdec_amd.Engine.StreamingLLM.backend import LMBackend as SelfSpecBackend
         engine = SelfSpecBackend(dtype=torch.bfloat16, device=dev, dec_len=G + 1)
         engine.load_model(args.checkpoints / tgt_name / "model.pth", use_tp=use_tp, rank_group=rank_group, group=group)
         engine.setup_caches(max_batch_size=B, max_seq_length=ML, draft_budget=BUDGET, kv_dtype=args.kv_dtype)
+    elif selfspec:
+        engine = LMBackend(dtype=torch.bfloat16, device=dev, dec_len=G + 1, draft_dec_len=1)
+        engine.load_model(args.checkpoints / tgt_name / "model.pth", use_tp=use_tp, rank_group=rank_group, group=group)
+        engine.setup_caches(max_batch_size=B, max_seq_length=ML, draft_budget=BUDGET, window_size=32,
+                            kv_dtype=args.kv_dtype)
     else:
         engine = LMBackend(dtype=torch.bfloat16, device=dev, dec_len=G + 1)
         engine.load_model(args.checkpoints / tgt_name / "model.pth", use_tp=use_tp, rank_group=rank_group, group=group)
         engine.setup_caches(max_batch_size=B, max_seq_length=ML, kv_dtype=args.kv_dtype)
     draft = None
     if in_draft and not selfspec:
-        draft = LMBackend_Draft(dtype=torch.bfloat16, device=dev, draft_budget=BUDGET)
-        draft.load_model(args.checkpoints / drf_name / "model.pth", use_tp=len(draft_ranks) > 1 or getattr(args, "force_tp", False),
-                         rank_group=draft_ranks, group=draft_group)
-        draft.setup_caches(max_batch_size=B, max_seq_length=ML, draft_budget=BUDGET)
+        draft_tp = len(draft_ranks) > 1 or getattr(args, "force_tp", False)
+        if streaming:
+            from magicdec_amd.Engine.StreamingLLM.backend_draft import LMBackend_Draft as StreamDraft
+            draft = StreamDraft(dtype=torch.bfloat16, device=dev)
+            draft.load_model(args.checkpoints / drf_name / "model.pth", use_tp=draft_tp, rank_group=draft_ranks,
+                             group=draft_group)
+            draft.setup_caches(max_batch_size=B, draft_budget=BUDGET)
+        else:
+            draft = LMBackend_Draft(dtype=torch.bfloat16, device=dev, draft_budget=BUDGET)
+            draft.load_model(args.checkpoints / drf_name / "model.pth", use_tp=draft_tp, rank_group=draft_ranks,
+                             group=draft_group)
+            draft.setup_caches(max_batch_size=B, max_seq_length=ML, draft_budget=BUDGET)
     if args.graphs is None:
         # Also under TP: the per-layer RCCL all-reduces are captured with the step (validated with a 1-rank RCCL
         # group on the development box, profiles/r01_tp1rank_rccl_graphs.log; a capture failure falls back to
@@ -219,7 +242,7 @@ def run(args, dev):
     st.tokens_buffer[:, :1] = engine.encode(input_ids=input_ids)[:, -1:]
     if draft is not None:
         draft.encode(input_ids=input_ids)
-    if selfspec:
+    if selfspec and streaming:
         engine.draft_encode(input_ids=input_ids)
     _sync(dev)
     t_pf = time.time() - t_pf
@@ -228,7 +251,7 @@ def run(args, dev):
         snap["s"] = (engine.draft_cachelens.clone(), engine.draft_paged_kv_last_page_len.clone())
     if draft is not None:
         snap["d"] = (draft.cachelens.clone(), draft.paged_kv_last_page_len.clone(),
-                     draft.draft_paged_kv_last_page_len.clone())
+                     draft.draft_paged_kv_last_page_len.clone() if not streaming else None)
     first_tok = st.tokens_buffer[:, :1].clone()
 
     def restore():
@@ -240,7 +263,8 @@ def run(args, dev):
         if draft is not None:
             draft.cachelens.copy_(snap["d"][0])
             draft.paged_kv_last_page_len.copy_(snap["d"][1])
-            draft.draft_paged_kv_last_page_len.copy_(snap["d"][2])
+            if not streaming:
+                draft.draft_paged_kv_last_page_len.copy_(snap["d"][2])
         st.num_nodes.fill_(S)
         st.tokens_buffer.zero_()
         st.tokens_buffer[:, :1] = first_tok
@@ -255,7 +279,7 @@ def run(args, dev):
     def iteration(next_double, forced):
         """One speculative iteration across the TP group (draft sub-group drafts, tokens broadcast, all verify)."""
         if selfspec:
-            return harness.selfspec_iteration(engine, st, G, eot_1, eot_2, S + 80, next_double, True, forced)
+            return harness.selfspec_iteration(engine, st, G, eot_1, eot_2, S + 80, next_double, streaming, forced)
         return harness.longspec_iteration(engine, draft, st, G, eot_1, eot_2, S + 80, next_double, forced, bcast)
 
     def run_spec(n_warm, n_steps, forced_table):
@@ -347,9 +371,11 @@ def run(args, dev):
         "value": round(value, 2), "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(dt_replay / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong",
         "vs_baseline": None, "dtype": "bf16", "kv_cache_dtype": args.kv_dtype, "data": "synthetic",
-        "config": {"workload": (f"{args.workload}: {tgt_name} self-speculation TP{world}, StreamingLLM draft cache "
+        "config": {"workload": (f"{args.workload}: {tgt_name} self-speculation TP{len(rank_group)}, "
+                                f"{'StreamingLLM' if streaming else 'SnapKV'} draft cache "
                                 f"budget {BUDGET} gamma {G}, B={B} prefix={S} max_len={ML}") if selfspec else
-                               (f"{args.workload}: {tgt_name} target TP{world} + {drf_name} SnapKV draft "
+                               (f"{args.workload}: {tgt_name} target TP{len(rank_group)} + {drf_name} "
+                                f"{'StreamingLLM' if streaming else 'SnapKV'} draft "
                                 f"TP{len(draft_ranks)} budget {BUDGET} gamma {G}, B={B} prefix={S} max_len={ML}"),
                    "acceptance": f"fixed replay alpha={args.alpha} (E[tokens/iter]={tok_replay / args.steps / B:.3f})",
                    "weights": "seeded random init (no checkpoints on the box)",

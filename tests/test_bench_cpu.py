@@ -18,7 +18,8 @@ sys.path.insert(0, os.environ["MD_ROOT"])
 from tests import cpu_ops
 cpu_ops.install()
 import bench
-sys.argv = ["bench.py", "--gpus", os.environ["WORLD_SIZE"], "--steps", "6", "--warmup", "2", "--workload", "tiny",
+sys.argv = ["bench.py", "--gpus", os.environ["WORLD_SIZE"], "--steps", "6", "--warmup", "2",
+            "--workload", os.environ.get("MD_WORKLOAD", "tiny"),
             "--no-cpu-baseline", "--draft-tp", os.environ["MD_DRAFT_TP"]]
 args = bench.parse()
 line = bench.run(args, "cpu")
@@ -27,19 +28,20 @@ if line is not None:
 '''
 
 
-@pytest.mark.parametrize("world,draft_tp", [(1, 4), (2, 4), (2, 1)])
-def test_bench_control_flow_on_cpu(world, draft_tp):
+@pytest.mark.parametrize("world,draft_tp,workload", [(1, 4, "tiny"), (2, 4, "tiny"), (2, 1, "tiny"),
+                                                    (1, 4, "tiny-selfspec-snapkv"), (2, 1, "tiny-longspec-stream")])
+def test_bench_control_flow_on_cpu(world, draft_tp, workload):
     """(2,1): the draft runs on rank 0 only -> rank 1 has no draft model and receives the tokens by broadcast, the
     8-GPU layout of the reference's README (target TP8, draft TP4) in miniature."""
     out = tempfile.mkdtemp(prefix="md_bench_")
     script = os.path.join(out, "w.py")
     Path(script).write_text(WORKER)
-    port = 29700 + (os.getpid() % 1500) + world * 3 + draft_tp
+    port = 29700 + (os.getpid() % 1500) + world * 3 + draft_tp + 11 * len(workload)
     procs = []
     for r in range(world):
         env = dict(os.environ, LOCAL_RANK=str(r), LOCAL_WORLD_SIZE=str(world), RANK=str(r), WORLD_SIZE=str(world),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), MD_ROOT=str(ROOT), MD_OUT=os.path.join(out, "line.json"), MD_DRAFT_TP=str(draft_tp),
-                   OMP_NUM_THREADS="2")
+                   MD_WORKLOAD=workload, OMP_NUM_THREADS="2")
         procs.append(subprocess.Popen([sys.executable, script], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
                                       cwd=out))
     logs = [p.communicate(timeout=1200)[0].decode() for p in procs]
