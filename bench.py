@@ -391,8 +391,9 @@ def run(args, dev):
                                     "tokens_per_iter_per_seq": round(tok_meas / meas_steps / B, 3),
                                     "ms_per_step": round(dt_meas / meas_steps * 1e3, 4)},
         "prefill_s": round(t_pf, 2), "load_s": round(t_load, 2),
-        "roofline": {"kernel": f"paged_attn_kernel<128,1,false,{'true' if args.kv_dtype == 'fp8' else 'false'}> "
-                               "(verify attention, md_paged_attn)", "bound": "hbm",
+        "roofline": {"kernel": f"paged_attn_kernel<{D},{1 if (G + 1) * (H_loc // KH_loc) <= 16 else 2},false,"
+                               f"{'true' if args.kv_dtype == 'fp8' else 'false'}> (verify attention, md_paged_attn)",
+                     "bound": "hbm",
                      "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                      "bytes_per_launch": attn_bytes, "avg_launch_ms": round(attn_ms, 4), "launches_timed": n_attn},
