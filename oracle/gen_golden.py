@@ -355,9 +355,24 @@ def synthetic_dataset(prefix_len, n_seq, vocab, seed=123):
     return TensorDataset(ids)
 
 
+def _tp_cpu_shims():
+    """The reference's init_dist (Engine/tp.py:54-64) hard-codes torch.cuda.set_device + backend "nccl"; on the CPU
+    of this container the same code runs over gloo (nothing in the checkout is touched)."""
+    import torch.distributed as dist
+    torch.cuda.set_device = lambda *a, **k: None
+    orig = dist.init_process_group
+
+    def init_pg(backend=None, **kw):
+        kw.pop("device_id", None)
+        return orig(backend="gloo", **kw)
+    dist.init_process_group = init_pg
+
+
 def run_script(script, argv, classes, vocab, prefix_len, n_seq, tag):
     """Run a reference benchmark script unmodified under runpy, tracing Engine method calls."""
     inject_configs()
+    if tag.endswith("_tp2"):
+        _tp_cpu_shims()
     import transformers
     transformers.AutoTokenizer = StubTokenizer
     dc = ref_import.module("Data.data_converter")
@@ -411,7 +426,9 @@ def run_script(script, argv, classes, vocab, prefix_len, n_seq, tag):
     for key in ("output", "num_nodes"):
         if key in g and torch.is_tensor(g[key]):
             final[key] = g[key].tolist()
-    (GOLD / f"{tag}.json").write_text(json.dumps(dict(argv=argv, trace=trace, final=final, snapkv_topk=topk_calls)))
+    if int(os.environ.get("LOCAL_RANK", "0")) == 0:          # TP runs: the replicated state is identical on every rank
+        (GOLD / f"{tag}.json").write_text(json.dumps(dict(argv=argv, trace=trace, final=final,
+                                                          snapkv_topk=topk_calls)))
 
 
 def scen_run(tag):
@@ -442,6 +459,14 @@ def scen_run(tag):
                    [("Engine.SnapKV.backend", "LMBackend", ["encode", "inference"]),
                     ("Engine.StreamingLLM.backend_draft", "LMBackend_Draft", ["encode", "inference"])], vocab, S, 6 * B,
                    tag)
+    elif tag == "run_longspec_stream_tp2":    # target TP2 + draft TP2 over gloo (2 processes, see main())
+        common2 = [c for c in common[:-2]] + ["--rank_group", "0", "1"]
+        run_script("tests/StreamingLLM/longspec_benchmark.py",
+                   ["--target", str(ck["tinytgt"]), "--model", str(ck["tinytgt"]), "--draft_budget", "129",
+                    "--draft_rank_group", "0", "1"] + common2,
+                   [("Engine.SnapKV.backend", "LMBackend", ["encode", "inference"]),
+                    ("Engine.StreamingLLM.backend_draft", "LMBackend_Draft", ["encode", "inference"])], vocab, S, 6 * B,
+                   tag)
     elif tag == "run_selfspec_snapkv":
         run_script("tests/SnapKV/selfspec_benchmark.py",
                    ["--model", str(ck["tinytgt"]), "--draft_budget", "129"] + common,
@@ -463,7 +488,21 @@ def scen_run(tag):
 SCENARIOS = {"snapkv_select": scen_snapkv_select, "stream_prefill": scen_stream_prefill,
              "accept_loop": scen_accept_loop, "tp_shapes": scen_tp_shapes}
 RUNS = ["run_longspec_snapkv", "run_longspec_snapkv_rej", "run_longspec_stream", "run_selfspec_snapkv",
-        "run_selfspec_stream", "run_baseline"]
+        "run_selfspec_stream", "run_baseline", "run_longspec_stream_tp2"]
+
+
+def _spawn_tp(scenario, world=2):
+    """torchrun-style launch of `world` CPU processes of one scenario (rendezvous on 127.0.0.1)."""
+    port = 29900 + os.getpid() % 90
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, LOCAL_RANK=str(r), RANK=str(r), LOCAL_WORLD_SIZE=str(world), WORLD_SIZE=str(world),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="2", MD_GOLDEN_CHILD="1")
+        procs.append(subprocess.Popen([sys.executable, "-m", "oracle.gen_golden", "--scenario", scenario],
+                                      cwd=str(ROOT), env=env))
+    for p in procs:
+        if p.wait() != 0:
+            raise SystemExit(f"{scenario}: a rank failed")
 
 
 def main():
@@ -475,6 +514,9 @@ def main():
         for s in list(SCENARIOS) + RUNS:
             print("==", s, flush=True)
             subprocess.run([sys.executable, "-m", "oracle.gen_golden", "--scenario", s], cwd=str(ROOT), check=True)
+        return
+    if a.scenario.endswith("_tp2") and os.environ.get("MD_GOLDEN_CHILD") != "1":
+        _spawn_tp(a.scenario)
         return
     torch.manual_seed(0)
     with torch.inference_mode():

@@ -271,6 +271,25 @@ if o_d is not None and len(draft_ranks) == world:
     ref = hr.longspec_batch(o_t, o_d, ids, gc.GAMMA, gc.MAX_LEN, gc.EOT_1, gc.EOT_2)
     res["oracle_output"] = ref["output"].tolist()
     res["oracle_num_nodes"] = ref["num_nodes"].tolist()
+if os.environ.get("MD_GOLDEN") == "1":
+    # all batches, traced like the reference's own TP=2 run (tests/golden/run_longspec_stream_tp2.json)
+    from tests.test_host_cpu import Tracer
+    log = []
+    te = Tracer(eng, "SnapKV.LMBackend", log, ("encode", "inference"))
+    td = Tracer(drf, "StreamingLLM.LMBackend_Draft", log, ("encode", "inference"))
+    last = None
+    for b_ids in gc.synthetic_batches():
+        last, _ = harness.run_longspec_batch(te, td, b_ids, gc.GAMMA, gc.MAX_LEN, gc.EOT_1, gc.EOT_2, barrier=dist.barrier)
+    res["golden_trace"] = log
+    res["golden_final"] = dict(output=last.output.tolist(), num_nodes=last.num_nodes.tolist())
+    # the oracle, sharded the same way, over the same batches
+    o_t2 = mr.RefEngine("target", lcfg, ssd, gc.B, gc.MAX_LEN, group=group, rank=rank, world=world)
+    dsd2, dcfg2 = mr.shard_state_dict(sd, cfg, rank, world)
+    o_d2 = mr.RefEngine("stream_draft", dcfg2, dsd2, gc.B, 0, gc.BUDGET, group=dgroup, rank=rank, world=world)
+    ref_last = None
+    for b_ids in gc.synthetic_batches():
+        ref_last = hr.longspec_batch(o_t2, o_d2, b_ids, gc.GAMMA, gc.MAX_LEN, gc.EOT_1, gc.EOT_2)
+    res["oracle_golden_final"] = dict(output=ref_last["output"].tolist(), num_nodes=ref_last["num_nodes"].tolist())
 json.dump(res, open(os.path.join(os.environ["MD_OUT"], f"rank{rank}.json"), "w"))
 dist.barrier()
 dist.destroy_process_group()
@@ -280,7 +299,8 @@ dist.destroy_process_group()
 @pytest.mark.parametrize("draft_ranks", ["0,1", "0"])
 def test_tensor_parallel_gloo_world2(draft_ranks, ckpt_dir):
     """TP=2 over gloo: both ranks end with identical replicated state; with draft TP == target TP the run equals the
-    oracle sharded the same way (same gloo bf16 sum all-reduce) bit for bit; with a 1-rank draft sub-group the
+    oracle sharded the same way (same gloo bf16 sum all-reduce) bit for bit, and both equal the trace of the real
+    reference run at TP=2 (golden fixture); with a 1-rank draft sub-group the
     gamma tokens are broadcast (tests/SnapKV/longspec_benchmark.py:189)."""
     import json
     out = tempfile.mkdtemp(prefix="md_tp_")
@@ -291,7 +311,7 @@ def test_tensor_parallel_gloo_world2(draft_ranks, ckpt_dir):
     for r in range(2):
         env = dict(os.environ, LOCAL_RANK=str(r), LOCAL_WORLD_SIZE="2", RANK=str(r), WORLD_SIZE="2",
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), MD_ROOT=str(ROOT), MD_CKPT=str(ckpt_dir), MD_OUT=out,
-                   MD_DRAFT_RANKS=draft_ranks, OMP_NUM_THREADS="2")
+                   MD_DRAFT_RANKS=draft_ranks, MD_GOLDEN="1" if draft_ranks == "0,1" else "0", OMP_NUM_THREADS="2")
         procs.append(subprocess.Popen([sys.executable, script], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
     logs = [p.communicate(timeout=900)[0].decode() for p in procs]
     assert all(p.returncode == 0 for p in procs), "\n".join(logs)
@@ -301,6 +321,12 @@ def test_tensor_parallel_gloo_world2(draft_ranks, ckpt_dir):
     assert r0["iters"] == r1["iters"] and r0["iters"] > 3
     if draft_ranks == "0,1":
         assert r0["output"] == r0["oracle_output"] and r0["num_nodes"] == r0["oracle_num_nodes"]
+        # ... and both equal the REAL reference run at TP=2 over gloo (oracle/gen_golden.py run_longspec_stream_tp2):
+        # every Engine call's tokens and page-table state, and the final output, bit for bit
+        j = gc.load_json("run_longspec_stream_tp2.json")
+        _compare(r0["golden_trace"], j["trace"])
+        assert r0["golden_final"] == j["final"] and r0["oracle_golden_final"] == j["final"]
+        assert r1["golden_final"] == j["final"]
 
 
 # ------------------------------------------------------------------ checkpoint ingestion
