@@ -426,9 +426,12 @@ def run_script(script, argv, classes, vocab, prefix_len, n_seq, tag):
     for key in ("output", "num_nodes"):
         if key in g and torch.is_tensor(g[key]):
             final[key] = g[key].tolist()
-    if int(os.environ.get("LOCAL_RANK", "0")) == 0:          # TP runs: the replicated state is identical on every rank
+    lr = int(os.environ.get("LOCAL_RANK", "0"))
+    if lr == 0:          # TP runs: the replicated state is identical on every rank
         (GOLD / f"{tag}.json").write_text(json.dumps(dict(argv=argv, trace=trace, final=final,
                                                           snapkv_topk=topk_calls)))
+    elif topk_calls:     # ... but each rank resolves the top-k ties of ITS kv heads: needed to replay rank r
+        (GOLD / f"{tag}_topk_rank{lr}.json").write_text(json.dumps(dict(snapkv_topk=topk_calls)))
 
 
 def scen_run(tag):
@@ -467,6 +470,13 @@ def scen_run(tag):
                    [("Engine.SnapKV.backend", "LMBackend", ["encode", "inference"]),
                     ("Engine.StreamingLLM.backend_draft", "LMBackend_Draft", ["encode", "inference"])], vocab, S, 6 * B,
                    tag)
+    elif tag == "run_longspec_snapkv_tp2":    # the headline layout in miniature: target TP2 + SnapKV draft TP2
+        common2 = [c for c in common[:-2]] + ["--rank_group", "0", "1"]
+        run_script("tests/SnapKV/longspec_benchmark.py",
+                   ["--target", str(ck["tinytgt"]), "--model", str(ck["tinytgt"]), "--draft_budget", "129",
+                    "--draft_rank_group", "0", "1"] + common2,
+                   [("Engine.SnapKV.backend", "LMBackend", ["encode", "inference"]),
+                    ("Engine.SnapKV.backend_draft", "LMBackend_Draft", ["encode", "inference"])], vocab, S, 6 * B, tag)
     elif tag == "run_selfspec_snapkv":
         run_script("tests/SnapKV/selfspec_benchmark.py",
                    ["--model", str(ck["tinytgt"]), "--draft_budget", "129"] + common,
@@ -488,7 +498,7 @@ def scen_run(tag):
 SCENARIOS = {"snapkv_select": scen_snapkv_select, "stream_prefill": scen_stream_prefill,
              "accept_loop": scen_accept_loop, "tp_shapes": scen_tp_shapes}
 RUNS = ["run_longspec_snapkv", "run_longspec_snapkv_rej", "run_longspec_stream", "run_selfspec_snapkv",
-        "run_selfspec_stream", "run_baseline", "run_longspec_stream_tp2"]
+        "run_selfspec_stream", "run_baseline", "run_longspec_stream_tp2", "run_longspec_snapkv_tp2"]
 
 
 def _spawn_tp(scenario, world=2):

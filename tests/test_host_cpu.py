@@ -329,6 +329,73 @@ def test_tensor_parallel_gloo_world2(draft_ranks, ckpt_dir):
         assert r1["golden_final"] == j["final"]
 
 
+TP_SNAPKV_WORKER = r'''
+import os, sys, json, torch
+sys.path.insert(0, os.environ["MD_ROOT"])
+import torch.distributed as dist
+from pathlib import Path
+from tests import cpu_ops, golden_cfg as gc
+cpu_ops.install()
+from magicdec_amd import harness
+from magicdec_amd.Engine import model_core
+from magicdec_amd.Engine.tp import init_dist
+from magicdec_amd.Engine.SnapKV.backend import LMBackend
+from magicdec_amd.Engine.SnapKV.backend_draft import LMBackend_Draft
+from tests.test_host_cpu import Tracer
+ck = Path(os.environ["MD_CKPT"])
+for name in gc.TINY:
+    cfg, _ = gc.tiny(name)
+    model_core.transformer_configs[name] = dict(block_size=4096, n_layer=cfg.n_layer, n_head=cfg.n_head,
+        n_local_heads=cfg.n_local_heads, dim=cfg.dim, intermediate_size=cfg.intermediate_size, vocab_size=cfg.vocab_size,
+        rope_base=cfg.rope_base, scaling_factor=cfg.scaling_factor, high_freq_factor=cfg.high_freq_factor,
+        low_freq_factor=cfg.low_freq_factor, original_max_position_embeddings=cfg.original_max_position_embeddings)
+rank, group, dgroup = init_dist([0, 1])
+# each rank replays the reference's tie resolution for ITS kv heads (torch.topk's tie order is implementation-defined)
+name = "run_longspec_snapkv_tp2.json" if rank == 0 else f"run_longspec_snapkv_tp2_topk_rank{rank}.json"
+cpu_ops.TOPK_REPLAY.update(table=gc.load_json(name)["snapkv_topk"], pos=0)
+eng = LMBackend(dtype=torch.bfloat16, device="cpu", dec_len=gc.GAMMA + 1)
+eng.load_model(ck / "tinytgt" / "model.pth", use_tp=True, rank_group=[0, 1], group=group)
+eng.setup_caches(max_batch_size=gc.B, max_seq_length=gc.MAX_LEN)
+drf = LMBackend_Draft(dtype=torch.bfloat16, device="cpu", draft_budget=gc.BUDGET)
+drf.load_model(ck / "tinytgt" / "model.pth", use_tp=True, rank_group=[0, 1], group=dgroup)
+drf.setup_caches(max_batch_size=gc.B, max_seq_length=gc.MAX_LEN, draft_budget=gc.BUDGET)
+log = []
+te = Tracer(eng, "SnapKV.LMBackend", log, ("encode", "inference"))
+td = Tracer(drf, "SnapKV.LMBackend_Draft", log, ("encode", "inference"))
+last = None
+for b_ids in gc.synthetic_batches():
+    last, _ = harness.run_longspec_batch(te, td, b_ids, gc.GAMMA, gc.MAX_LEN, gc.EOT_1, gc.EOT_2, barrier=dist.barrier)
+json.dump(dict(trace=log, final=dict(output=last.output.tolist(), num_nodes=last.num_nodes.tolist())),
+          open(os.path.join(os.environ["MD_OUT"], f"rank{rank}.json"), "w"))
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+def test_tensor_parallel_snapkv_draft_matches_reference_tp2_trace(ckpt_dir):
+    """The headline layout in miniature -- target TP2 + SnapKV draft TP2 (kv-head-sharded select/gather) -- over
+    gloo: every Engine call's tokens and page-table state and the final output equal the REAL reference's TP=2 run
+    (oracle/gen_golden.py run_longspec_snapkv_tp2) bit for bit, on both ranks."""
+    import json
+    out = tempfile.mkdtemp(prefix="md_tp_snap_")
+    script = os.path.join(out, "worker.py")
+    Path(script).write_text(TP_SNAPKV_WORKER)
+    port = 29400 + (os.getpid() % 500)
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, LOCAL_RANK=str(r), LOCAL_WORLD_SIZE="2", RANK=str(r), WORLD_SIZE="2",
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), MD_ROOT=str(ROOT), MD_CKPT=str(ckpt_dir), MD_OUT=out,
+                   OMP_NUM_THREADS="2")
+        procs.append(subprocess.Popen([sys.executable, script], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    logs = [p.communicate(timeout=900)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(logs)
+    j = gc.load_json("run_longspec_snapkv_tp2.json")
+    for r in range(2):
+        got = json.load(open(os.path.join(out, f"rank{r}.json")))
+        _compare(got["trace"], j["trace"])
+        assert got["final"] == j["final"]
+
+
 # ------------------------------------------------------------------ checkpoint ingestion (SURVEY 8f-3)
 def test_hf_checkpoint_conversion_roundtrip():
     """An HF-layout (half-split RoPE rows, separate q/k/v, sharded safetensors) copy of a tiny model converts to
