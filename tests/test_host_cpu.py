@@ -350,21 +350,30 @@ for name in gc.TINY:
         rope_base=cfg.rope_base, scaling_factor=cfg.scaling_factor, high_freq_factor=cfg.high_freq_factor,
         low_freq_factor=cfg.low_freq_factor, original_max_position_embeddings=cfg.original_max_position_embeddings)
 rank, group, dgroup = init_dist([0, 1])
+kind = os.environ["MD_KIND"]                      # fixture name: run_longspec_snapkv_tp2 | run_selfspec_snapkv_tp2
 # each rank replays the reference's tie resolution for ITS kv heads (torch.topk's tie order is implementation-defined)
-name = "run_longspec_snapkv_tp2.json" if rank == 0 else f"run_longspec_snapkv_tp2_topk_rank{rank}.json"
+name = f"{kind}.json" if rank == 0 else f"{kind}_topk_rank{rank}.json"
 cpu_ops.TOPK_REPLAY.update(table=gc.load_json(name)["snapkv_topk"], pos=0)
-eng = LMBackend(dtype=torch.bfloat16, device="cpu", dec_len=gc.GAMMA + 1)
-eng.load_model(ck / "tinytgt" / "model.pth", use_tp=True, rank_group=[0, 1], group=group)
-eng.setup_caches(max_batch_size=gc.B, max_seq_length=gc.MAX_LEN)
-drf = LMBackend_Draft(dtype=torch.bfloat16, device="cpu", draft_budget=gc.BUDGET)
-drf.load_model(ck / "tinytgt" / "model.pth", use_tp=True, rank_group=[0, 1], group=dgroup)
-drf.setup_caches(max_batch_size=gc.B, max_seq_length=gc.MAX_LEN, draft_budget=gc.BUDGET)
 log = []
-te = Tracer(eng, "SnapKV.LMBackend", log, ("encode", "inference"))
-td = Tracer(drf, "SnapKV.LMBackend_Draft", log, ("encode", "inference"))
 last = None
-for b_ids in gc.synthetic_batches():
-    last, _ = harness.run_longspec_batch(te, td, b_ids, gc.GAMMA, gc.MAX_LEN, gc.EOT_1, gc.EOT_2, barrier=dist.barrier)
+if kind.startswith("run_longspec"):
+    eng = LMBackend(dtype=torch.bfloat16, device="cpu", dec_len=gc.GAMMA + 1)
+    eng.load_model(ck / "tinytgt" / "model.pth", use_tp=True, rank_group=[0, 1], group=group)
+    eng.setup_caches(max_batch_size=gc.B, max_seq_length=gc.MAX_LEN)
+    drf = LMBackend_Draft(dtype=torch.bfloat16, device="cpu", draft_budget=gc.BUDGET)
+    drf.load_model(ck / "tinytgt" / "model.pth", use_tp=True, rank_group=[0, 1], group=dgroup)
+    drf.setup_caches(max_batch_size=gc.B, max_seq_length=gc.MAX_LEN, draft_budget=gc.BUDGET)
+    te = Tracer(eng, "SnapKV.LMBackend", log, ("encode", "inference"))
+    td = Tracer(drf, "SnapKV.LMBackend_Draft", log, ("encode", "inference"))
+    for b_ids in gc.synthetic_batches():
+        last, _ = harness.run_longspec_batch(te, td, b_ids, gc.GAMMA, gc.MAX_LEN, gc.EOT_1, gc.EOT_2, barrier=dist.barrier)
+else:
+    eng = LMBackend(dtype=torch.bfloat16, device="cpu", dec_len=gc.GAMMA + 1, draft_dec_len=1)
+    eng.load_model(ck / "tinytgt" / "model.pth", use_tp=True, rank_group=[0, 1], group=group)
+    eng.setup_caches(max_batch_size=gc.B, max_seq_length=gc.MAX_LEN, draft_budget=gc.BUDGET)
+    te = Tracer(eng, "SnapKV.LMBackend", log, ("encode", "draft_encode", "speculate", "verify"))
+    for b_ids in gc.synthetic_batches():
+        last, _ = harness.run_selfspec_batch(te, b_ids, gc.GAMMA, gc.MAX_LEN, gc.EOT_1, gc.EOT_2, False)
 json.dump(dict(trace=log, final=dict(output=last.output.tolist(), num_nodes=last.num_nodes.tolist())),
           open(os.path.join(os.environ["MD_OUT"], f"rank{rank}.json"), "w"))
 dist.barrier()
@@ -372,24 +381,26 @@ dist.destroy_process_group()
 '''
 
 
-def test_tensor_parallel_snapkv_draft_matches_reference_tp2_trace(ckpt_dir):
-    """The headline layout in miniature -- target TP2 + SnapKV draft TP2 (kv-head-sharded select/gather) -- over
-    gloo: every Engine call's tokens and page-table state and the final output equal the REAL reference's TP=2 run
-    (oracle/gen_golden.py run_longspec_snapkv_tp2) bit for bit, on both ranks."""
+@pytest.mark.parametrize("kind", ["run_longspec_snapkv_tp2", "run_selfspec_snapkv_tp2"])
+def test_tensor_parallel_snapkv_matches_reference_tp2_trace(kind, ckpt_dir):
+    """The TP layouts of BASELINE configs[2] and configs[4] in miniature -- target TP2 + SnapKV draft TP2, and TP2
+    self-speculation with the SnapKV cache (kv-head-sharded select/gather) -- over gloo: every Engine call's tokens
+    and page-table state and the final output equal the REAL reference's TP=2 runs (oracle/gen_golden.py
+    run_{longspec,selfspec}_snapkv_tp2) bit for bit, on both ranks."""
     import json
     out = tempfile.mkdtemp(prefix="md_tp_snap_")
     script = os.path.join(out, "worker.py")
     Path(script).write_text(TP_SNAPKV_WORKER)
-    port = 29400 + (os.getpid() % 500)
+    port = 29400 + (os.getpid() % 500) + (0 if "longspec" in kind else 1)
     procs = []
     for r in range(2):
         env = dict(os.environ, LOCAL_RANK=str(r), LOCAL_WORLD_SIZE="2", RANK=str(r), WORLD_SIZE="2",
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), MD_ROOT=str(ROOT), MD_CKPT=str(ckpt_dir), MD_OUT=out,
-                   OMP_NUM_THREADS="2")
+                   MD_KIND=kind, OMP_NUM_THREADS="2")
         procs.append(subprocess.Popen([sys.executable, script], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
     logs = [p.communicate(timeout=900)[0].decode() for p in procs]
     assert all(p.returncode == 0 for p in procs), "\n".join(logs)
-    j = gc.load_json("run_longspec_snapkv_tp2.json")
+    j = gc.load_json(f"{kind}.json")
     for r in range(2):
         got = json.load(open(os.path.join(out, f"rank{r}.json")))
         _compare(got["trace"], j["trace"])
