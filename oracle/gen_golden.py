@@ -52,6 +52,13 @@ TINY = {
                      original_max_position_embeddings=8192), 11, 0.1),
     "tinydrf": (dict(block_size=4096, n_layer=1, n_head=8, n_local_heads=2, dim=512, intermediate_size=1024,
                      vocab_size=2048, rope_base=10000.0), 12, 0.1),
+    # other families of the reference's zoo: Qwen2.5-style (qkv bias, g = 5, eps 1e-6, theta 1e6) and
+    # Llama-3.1-70B-style (g = 8, D = 128)
+    "tinyqwen": (dict(block_size=4096, n_layer=2, n_head=10, n_local_heads=2, dim=640, intermediate_size=1280,
+                      vocab_size=2048, rope_base=1000000.0, norm_eps=1e-6, qkv_bias=True), 21, 0.1),
+    "tiny70b": (dict(block_size=4096, n_layer=2, n_head=16, n_local_heads=2, dim=2048, intermediate_size=2048,
+                     vocab_size=2048, rope_base=500000.0, scaling_factor=8, high_freq_factor=4, low_freq_factor=1,
+                     original_max_position_embeddings=8192), 22, 0.1),
 }
 
 
@@ -66,7 +73,8 @@ def ref_cfg(name):
                      intermediate_size=kw["intermediate_size"], vocab_size=kw["vocab_size"],
                      rope_base=kw.get("rope_base", 10000.0), scaling_factor=kw.get("scaling_factor", 1.0),
                      low_freq_factor=kw.get("low_freq_factor"), high_freq_factor=kw.get("high_freq_factor"),
-                     original_max_position_embeddings=kw.get("original_max_position_embeddings")), seed, wo_scale
+                     original_max_position_embeddings=kw.get("original_max_position_embeddings"),
+                     norm_eps=kw.get("norm_eps", 1e-5), qkv_bias=kw.get("qkv_bias", False)), seed, wo_scale
 
 
 def write_checkpoints(tmp):
@@ -481,6 +489,11 @@ def scen_run(tag):
         run_script("tests/SnapKV/selfspec_benchmark.py",
                    ["--model", str(ck["tinytgt"]), "--draft_budget", "129"] + common[:-2] + ["--rank_group", "0", "1"],
                    [("Engine.SnapKV.backend", "LMBackend", ["encode", "speculate", "verify"])], vocab, S, 6 * B, tag)
+    elif tag in ("run_selfspec_snapkv_qwen", "run_selfspec_snapkv_70b"):
+        name = "tinyqwen" if tag.endswith("qwen") else "tiny70b"
+        run_script("tests/SnapKV/selfspec_benchmark.py",
+                   ["--model", str(ck[name]), "--draft_budget", "129"] + common,
+                   [("Engine.SnapKV.backend", "LMBackend", ["encode", "speculate", "verify"])], vocab, S, 6 * B, tag)
     elif tag == "run_selfspec_snapkv":
         run_script("tests/SnapKV/selfspec_benchmark.py",
                    ["--model", str(ck["tinytgt"]), "--draft_budget", "129"] + common,
@@ -503,7 +516,7 @@ SCENARIOS = {"snapkv_select": scen_snapkv_select, "stream_prefill": scen_stream_
              "accept_loop": scen_accept_loop, "tp_shapes": scen_tp_shapes}
 RUNS = ["run_longspec_snapkv", "run_longspec_snapkv_rej", "run_longspec_stream", "run_selfspec_snapkv",
         "run_selfspec_stream", "run_baseline", "run_longspec_stream_tp2", "run_longspec_snapkv_tp2",
-        "run_selfspec_snapkv_tp2"]
+        "run_selfspec_snapkv_tp2", "run_selfspec_snapkv_qwen", "run_selfspec_snapkv_70b"]
 
 
 def _spawn_tp(scenario, world=2):

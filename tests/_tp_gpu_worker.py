@@ -21,13 +21,7 @@ def main():
     from magicdec_amd.Engine.SnapKV.backend_draft import LMBackend_Draft
     from magicdec_amd.Engine.tp import init_dist
     ck = Path(os.environ["MD_CKPT"])
-    for name in gc.TINY:
-        cfg, _ = gc.tiny(name)
-        model_core.transformer_configs[name] = dict(
-            block_size=4096, n_layer=cfg.n_layer, n_head=cfg.n_head, n_local_heads=cfg.n_local_heads, dim=cfg.dim,
-            intermediate_size=cfg.intermediate_size, vocab_size=cfg.vocab_size, rope_base=cfg.rope_base,
-            scaling_factor=cfg.scaling_factor, high_freq_factor=cfg.high_freq_factor,
-            low_freq_factor=cfg.low_freq_factor, original_max_position_embeddings=cfg.original_max_position_embeddings)
+    gc.register_tiny(model_core)
     rank, group, dgroup = init_dist([0, 1])
     dev = "cuda:0"
     use_graphs = os.environ.get("MD_GRAPHS", "0") == "1"

@@ -15,6 +15,14 @@ TINY = {
                           original_max_position_embeddings=8192), 11, 0.1),
     "tinydrf": (RefConfig(n_layer=1, n_head=8, n_local_heads=2, dim=512, intermediate_size=1024, vocab_size=2048,
                           rope_base=10000.0), 12, 0.1),
+    # other families of the reference's zoo (oracle/gen_golden.py holds the same numbers):
+    # Qwen2.5-style: qkv bias, g = 5 (padded MFMA M tile, mis-aligned SnapKV mask), eps 1e-6, plain RoPE theta 1e6
+    "tinyqwen": (RefConfig(n_layer=2, n_head=10, n_local_heads=2, dim=640, intermediate_size=1280, vocab_size=2048,
+                           rope_base=1000000.0, norm_eps=1e-6, qkv_bias=True), 21, 0.1),
+    # Llama-3.1-70B-style: g = 8 -> two MFMA M tiles per (request, kv head) in the verify kernel, D = 128
+    "tiny70b": (RefConfig(n_layer=2, n_head=16, n_local_heads=2, dim=2048, intermediate_size=2048, vocab_size=2048,
+                          rope_base=500000.0, scaling_factor=8, high_freq_factor=4, low_freq_factor=1,
+                          original_max_position_embeddings=8192), 22, 0.1),
 }
 B, S, MAX_LEN, GAMMA, BUDGET, EOT_1, EOT_2 = 2, 416, 512, 3, 129, 2, 0
 
@@ -22,6 +30,20 @@ B, S, MAX_LEN, GAMMA, BUDGET, EOT_1, EOT_2 = 2, 416, 512, 3, 129, 2, 0
 def tiny(name):
     cfg, seed, wo = TINY[name]
     return cfg, init_state_dict(cfg, seed, wo_scale=wo)
+
+
+def config_kwargs(cfg):
+    """RefConfig -> kwargs of magicdec_amd.Engine.model_core.transformer_configs (the reference's ModelArgs names)."""
+    return dict(block_size=4096, n_layer=cfg.n_layer, n_head=cfg.n_head, n_local_heads=cfg.n_local_heads, dim=cfg.dim,
+                intermediate_size=cfg.intermediate_size, vocab_size=cfg.vocab_size, rope_base=cfg.rope_base,
+                norm_eps=cfg.norm_eps, scaling_factor=cfg.scaling_factor, high_freq_factor=cfg.high_freq_factor,
+                low_freq_factor=cfg.low_freq_factor,
+                original_max_position_embeddings=cfg.original_max_position_embeddings, qkv_bias=cfg.qkv_bias)
+
+
+def register_tiny(model_core):
+    for name in TINY:
+        model_core.transformer_configs[name] = config_kwargs(TINY[name][0])
 
 
 def synthetic_batches(n_seq=12, vocab=2048, prefix=S, seed=123):

@@ -38,11 +38,7 @@ def ckpt_dir():
         cfg, sd = gc.tiny(name)
         os.makedirs(os.path.join(d, name), exist_ok=True)
         torch.save(sd, os.path.join(d, name, "model.pth"))
-        model_core.transformer_configs[name] = dict(
-            block_size=4096, n_layer=cfg.n_layer, n_head=cfg.n_head, n_local_heads=cfg.n_local_heads, dim=cfg.dim,
-            intermediate_size=cfg.intermediate_size, vocab_size=cfg.vocab_size, rope_base=cfg.rope_base,
-            scaling_factor=cfg.scaling_factor, high_freq_factor=cfg.high_freq_factor,
-            low_freq_factor=cfg.low_freq_factor, original_max_position_embeddings=cfg.original_max_position_embeddings)
+        model_core.transformer_configs[name] = gc.config_kwargs(cfg)
     return d
 
 

@@ -83,11 +83,7 @@ def ckpt_dir():
         cfg, sd = gc.tiny(name)
         os.makedirs(os.path.join(d, name), exist_ok=True)
         torch.save(sd, os.path.join(d, name, "model.pth"))
-        model_core.transformer_configs[name] = dict(
-            block_size=4096, n_layer=cfg.n_layer, n_head=cfg.n_head, n_local_heads=cfg.n_local_heads, dim=cfg.dim,
-            intermediate_size=cfg.intermediate_size, vocab_size=cfg.vocab_size, rope_base=cfg.rope_base,
-            scaling_factor=cfg.scaling_factor, high_freq_factor=cfg.high_freq_factor,
-            low_freq_factor=cfg.low_freq_factor, original_max_position_embeddings=cfg.original_max_position_embeddings)
+        model_core.transformer_configs[name] = gc.config_kwargs(cfg)
     return Path(d)
 
 
@@ -163,10 +159,11 @@ def test_product_longspec_host_logic_matches_reference_trace(kind, gamma, cpu_op
     assert last.num_nodes.tolist() == j["final"]["num_nodes"]
 
 
-@pytest.mark.parametrize("kind", ["selfspec_snapkv", "selfspec_stream"])
+@pytest.mark.parametrize("kind", ["selfspec_snapkv", "selfspec_stream", "selfspec_snapkv_qwen", "selfspec_snapkv_70b"])
 def test_product_selfspec_host_logic_matches_reference_trace(kind, cpu_ops_patched, ckpt_dir):
     from magicdec_amd import harness
     j = gc.load_json(f"run_{kind}.json")
+    model = "tinyqwen" if kind.endswith("qwen") else "tiny70b" if kind.endswith("70b") else "tinytgt"
     streaming = kind.endswith("stream")
     if streaming:
         from magicdec_amd.Engine.StreamingLLM.backend import LMBackend
@@ -177,7 +174,7 @@ def test_product_selfspec_host_logic_matches_reference_trace(kind, cpu_ops_patch
         eng = LMBackend(dtype=torch.bfloat16, device="cpu", dec_len=gc.GAMMA + 1, draft_dec_len=1)
         cls = "SnapKV.LMBackend"
         cpu_ops.TOPK_REPLAY.update(table=j["snapkv_topk"], pos=0)
-    eng.load_model(ckpt_dir / "tinytgt" / "model.pth", use_tp=False)
+    eng.load_model(ckpt_dir / model / "model.pth", use_tp=False)
     eng.setup_caches(max_batch_size=gc.B, max_seq_length=gc.MAX_LEN, draft_budget=gc.BUDGET)
     log = []
     te = Tracer(eng, cls, log, ("encode", "draft_encode", "speculate", "verify"))
@@ -233,12 +230,7 @@ from magicdec_amd.Engine.tp import init_dist
 from magicdec_amd.Engine.SnapKV.backend import LMBackend
 from magicdec_amd.Engine.StreamingLLM.backend_draft import LMBackend_Draft
 ck = Path(os.environ["MD_CKPT"])
-for name in gc.TINY:
-    cfg, _ = gc.tiny(name)
-    model_core.transformer_configs[name] = dict(block_size=4096, n_layer=cfg.n_layer, n_head=cfg.n_head,
-        n_local_heads=cfg.n_local_heads, dim=cfg.dim, intermediate_size=cfg.intermediate_size, vocab_size=cfg.vocab_size,
-        rope_base=cfg.rope_base, scaling_factor=cfg.scaling_factor, high_freq_factor=cfg.high_freq_factor,
-        low_freq_factor=cfg.low_freq_factor, original_max_position_embeddings=cfg.original_max_position_embeddings)
+gc.register_tiny(model_core)
 draft_ranks = [int(x) for x in os.environ["MD_DRAFT_RANKS"].split(",")]
 rank, group, dgroup = init_dist(draft_ranks)
 world = dist.get_world_size()
@@ -343,12 +335,7 @@ from magicdec_amd.Engine.SnapKV.backend import LMBackend
 from magicdec_amd.Engine.SnapKV.backend_draft import LMBackend_Draft
 from tests.test_host_cpu import Tracer
 ck = Path(os.environ["MD_CKPT"])
-for name in gc.TINY:
-    cfg, _ = gc.tiny(name)
-    model_core.transformer_configs[name] = dict(block_size=4096, n_layer=cfg.n_layer, n_head=cfg.n_head,
-        n_local_heads=cfg.n_local_heads, dim=cfg.dim, intermediate_size=cfg.intermediate_size, vocab_size=cfg.vocab_size,
-        rope_base=cfg.rope_base, scaling_factor=cfg.scaling_factor, high_freq_factor=cfg.high_freq_factor,
-        low_freq_factor=cfg.low_freq_factor, original_max_position_embeddings=cfg.original_max_position_embeddings)
+gc.register_tiny(model_core)
 rank, group, dgroup = init_dist([0, 1])
 kind = os.environ["MD_KIND"]                      # fixture name: run_longspec_snapkv_tp2 | run_selfspec_snapkv_tp2
 # each rank replays the reference's tie resolution for ITS kv heads (torch.topk's tie order is implementation-defined)

@@ -172,10 +172,12 @@ def test_longspec_matches_reference_script(kind, gamma):
     assert last["num_nodes"].tolist() == j["final"]["num_nodes"]
 
 
-@pytest.mark.parametrize("kind", ["selfspec_snapkv", "selfspec_stream"])
+@pytest.mark.parametrize("kind", ["selfspec_snapkv", "selfspec_stream", "selfspec_snapkv_qwen", "selfspec_snapkv_70b"])
 def test_selfspec_matches_reference_script(kind):
+    """_qwen / _70b: the reference run on a Qwen2.5-like (qkv bias, g=5, eps 1e-6) and a Llama-70B-like (g=8, D=128)
+    tiny model -- pins the oracle's bias handling and the g != 4 SnapKV paths at the engine level."""
     j = gc.load_json(f"run_{kind}.json")
-    cfg, sd = gc.tiny("tinytgt")
+    cfg, sd = gc.tiny("tinyqwen" if kind.endswith("qwen") else "tiny70b" if kind.endswith("70b") else "tinytgt")
     streaming = kind == "selfspec_stream"
     eng = mr.RefEngine("stream_self" if streaming else "snapkv_self", cfg, sd, gc.B, gc.MAX_LEN, gc.BUDGET)
     mod = "StreamingLLM" if streaming else "SnapKV"
