@@ -485,6 +485,19 @@ def scen_run(tag):
                     "--draft_rank_group", "0", "1"] + common2,
                    [("Engine.SnapKV.backend", "LMBackend", ["encode", "inference"]),
                     ("Engine.SnapKV.backend_draft", "LMBackend_Draft", ["encode", "inference"])], vocab, S, 6 * B, tag)
+    elif tag == "run_longspec_stream_70b":    # configs[3]'s layout in miniature: 70B-like target (g=8) + a different,
+        # smaller draft model with the StreamingLLM cache (rejections exercise the cachelen_update / rollback paths)
+        run_script("tests/StreamingLLM/longspec_benchmark.py",
+                   ["--target", str(ck["tiny70b"]), "--model", str(ck["tinydrf"]), "--draft_budget", "129",
+                    "--draft_rank_group", "0"] + common,
+                   [("Engine.SnapKV.backend", "LMBackend", ["encode", "inference"]),
+                    ("Engine.StreamingLLM.backend_draft", "LMBackend_Draft", ["encode", "inference"])], vocab, S, 6 * B,
+                   tag)
+    elif tag == "run_selfspec_stream_tp2":
+        run_script("tests/StreamingLLM/selfspec_benchmark.py",
+                   ["--model", str(ck["tinytgt"]), "--draft_budget", "129"] + common[:-2] + ["--rank_group", "0", "1"],
+                   [("Engine.StreamingLLM.backend", "LMBackend", ["encode", "draft_encode", "speculate", "verify"])],
+                   vocab, S, 6 * B, tag)
     elif tag == "run_selfspec_snapkv_tp2":    # BASELINE configs[4]'s layout in miniature: TP self-speculation, SnapKV cache
         run_script("tests/SnapKV/selfspec_benchmark.py",
                    ["--model", str(ck["tinytgt"]), "--draft_budget", "129"] + common[:-2] + ["--rank_group", "0", "1"],
@@ -516,7 +529,8 @@ SCENARIOS = {"snapkv_select": scen_snapkv_select, "stream_prefill": scen_stream_
              "accept_loop": scen_accept_loop, "tp_shapes": scen_tp_shapes}
 RUNS = ["run_longspec_snapkv", "run_longspec_snapkv_rej", "run_longspec_stream", "run_selfspec_snapkv",
         "run_selfspec_stream", "run_baseline", "run_longspec_stream_tp2", "run_longspec_snapkv_tp2",
-        "run_selfspec_snapkv_tp2", "run_selfspec_snapkv_qwen", "run_selfspec_snapkv_70b"]
+        "run_selfspec_snapkv_tp2", "run_selfspec_snapkv_qwen", "run_selfspec_snapkv_70b",
+        "run_longspec_stream_70b", "run_selfspec_stream_tp2"]
 
 
 def _spawn_tp(scenario, world=2):

@@ -127,13 +127,14 @@ def _compare(trace, ref):
                 assert a.get(key) == b[key], (a["cls"], a["fn"], key, a.get(key), b[key])
 
 
-@pytest.mark.parametrize("kind,gamma", [("longspec_snapkv", 3), ("longspec_snapkv_rej", 1), ("longspec_stream", 3)])
+@pytest.mark.parametrize("kind,gamma", [("longspec_snapkv", 3), ("longspec_snapkv_rej", 1), ("longspec_stream", 3),
+                                        ("longspec_stream_70b", 3)])
 def test_product_longspec_host_logic_matches_reference_trace(kind, gamma, cpu_ops_patched, ckpt_dir):
     from magicdec_amd import harness
     from magicdec_amd.Engine.SnapKV.backend import LMBackend
     j = gc.load_json(f"run_{kind}.json")
     eng = LMBackend(dtype=torch.bfloat16, device="cpu", dec_len=gamma + 1)
-    eng.load_model(ckpt_dir / "tinytgt" / "model.pth", use_tp=False)
+    eng.load_model(ckpt_dir / ("tiny70b" if kind.endswith("70b") else "tinytgt") / "model.pth", use_tp=False)
     eng.setup_caches(max_batch_size=gc.B, max_seq_length=gc.MAX_LEN)
     if "snapkv" in kind:
         from magicdec_amd.Engine.SnapKV.backend_draft import LMBackend_Draft
@@ -145,7 +146,7 @@ def test_product_longspec_host_logic_matches_reference_trace(kind, gamma, cpu_op
     else:
         from magicdec_amd.Engine.StreamingLLM.backend_draft import LMBackend_Draft
         drf = LMBackend_Draft(dtype=torch.bfloat16, device="cpu")
-        drf.load_model(ckpt_dir / "tinytgt" / "model.pth", use_tp=False)
+        drf.load_model(ckpt_dir / ("tinydrf" if kind.endswith("70b") else "tinytgt") / "model.pth", use_tp=False)
         drf.setup_caches(max_batch_size=gc.B, draft_budget=gc.BUDGET)
         dcls = "StreamingLLM.LMBackend_Draft"
     log = []
@@ -339,8 +340,9 @@ gc.register_tiny(model_core)
 rank, group, dgroup = init_dist([0, 1])
 kind = os.environ["MD_KIND"]                      # fixture name: run_longspec_snapkv_tp2 | run_selfspec_snapkv_tp2
 # each rank replays the reference's tie resolution for ITS kv heads (torch.topk's tie order is implementation-defined)
-name = f"{kind}.json" if rank == 0 else f"{kind}_topk_rank{rank}.json"
-cpu_ops.TOPK_REPLAY.update(table=gc.load_json(name)["snapkv_topk"], pos=0)
+if "snapkv" in kind:
+    name = f"{kind}.json" if rank == 0 else f"{kind}_topk_rank{rank}.json"
+    cpu_ops.TOPK_REPLAY.update(table=gc.load_json(name)["snapkv_topk"], pos=0)
 log = []
 last = None
 if kind.startswith("run_longspec"):
@@ -354,13 +356,21 @@ if kind.startswith("run_longspec"):
     td = Tracer(drf, "SnapKV.LMBackend_Draft", log, ("encode", "inference"))
     for b_ids in gc.synthetic_batches():
         last, _ = harness.run_longspec_batch(te, td, b_ids, gc.GAMMA, gc.MAX_LEN, gc.EOT_1, gc.EOT_2, barrier=dist.barrier)
-else:
+elif "snapkv" in kind:
     eng = LMBackend(dtype=torch.bfloat16, device="cpu", dec_len=gc.GAMMA + 1, draft_dec_len=1)
     eng.load_model(ck / "tinytgt" / "model.pth", use_tp=True, rank_group=[0, 1], group=group)
     eng.setup_caches(max_batch_size=gc.B, max_seq_length=gc.MAX_LEN, draft_budget=gc.BUDGET)
     te = Tracer(eng, "SnapKV.LMBackend", log, ("encode", "draft_encode", "speculate", "verify"))
     for b_ids in gc.synthetic_batches():
         last, _ = harness.run_selfspec_batch(te, b_ids, gc.GAMMA, gc.MAX_LEN, gc.EOT_1, gc.EOT_2, False)
+else:
+    from magicdec_amd.Engine.StreamingLLM.backend import LMBackend as StreamSelf
+    eng = StreamSelf(dtype=torch.bfloat16, device="cpu", dec_len=gc.GAMMA + 1)
+    eng.load_model(ck / "tinytgt" / "model.pth", use_tp=True, rank_group=[0, 1], group=group)
+    eng.setup_caches(max_batch_size=gc.B, max_seq_length=gc.MAX_LEN, draft_budget=gc.BUDGET)
+    te = Tracer(eng, "StreamingLLM.LMBackend", log, ("encode", "draft_encode", "speculate", "verify"))
+    for b_ids in gc.synthetic_batches():
+        last, _ = harness.run_selfspec_batch(te, b_ids, gc.GAMMA, gc.MAX_LEN, gc.EOT_1, gc.EOT_2, True)
 json.dump(dict(trace=log, final=dict(output=last.output.tolist(), num_nodes=last.num_nodes.tolist())),
           open(os.path.join(os.environ["MD_OUT"], f"rank{rank}.json"), "w"))
 dist.barrier()
@@ -368,7 +378,7 @@ dist.destroy_process_group()
 '''
 
 
-@pytest.mark.parametrize("kind", ["run_longspec_snapkv_tp2", "run_selfspec_snapkv_tp2"])
+@pytest.mark.parametrize("kind", ["run_longspec_snapkv_tp2", "run_selfspec_snapkv_tp2", "run_selfspec_stream_tp2"])
 def test_tensor_parallel_snapkv_matches_reference_tp2_trace(kind, ckpt_dir):
     """The TP layouts of BASELINE configs[2] and configs[4] in miniature -- target TP2 + SnapKV draft TP2, and TP2
     self-speculation with the SnapKV cache (kv-head-sharded select/gather) -- over gloo: every Engine call's tokens
@@ -378,7 +388,7 @@ def test_tensor_parallel_snapkv_matches_reference_tp2_trace(kind, ckpt_dir):
     out = tempfile.mkdtemp(prefix="md_tp_snap_")
     script = os.path.join(out, "worker.py")
     Path(script).write_text(TP_SNAPKV_WORKER)
-    port = 29400 + (os.getpid() % 500) + (0 if "longspec" in kind else 1)
+    port = 29400 + (os.getpid() % 500) + ["run_longspec_snapkv_tp2", "run_selfspec_snapkv_tp2", "run_selfspec_stream_tp2"].index(kind)
     procs = []
     for r in range(2):
         env = dict(os.environ, LOCAL_RANK=str(r), LOCAL_WORLD_SIZE="2", RANK=str(r), WORLD_SIZE="2",

@@ -149,10 +149,16 @@ def _engines(kind):
     if kind == "longspec_stream":
         return (mr.RefEngine("target", cfg_t, sd_t, gc.B, gc.MAX_LEN),
                 mr.RefEngine("stream_draft", cfg_t, sd_t, gc.B, 0, gc.BUDGET))
+    if kind == "longspec_stream_70b":          # configs[3] in miniature: g=8 target + a different, smaller draft
+        cfg_7, sd_7 = gc.tiny("tiny70b")
+        cfg_d, sd_d = gc.tiny("tinydrf")
+        return (mr.RefEngine("target", cfg_7, sd_7, gc.B, gc.MAX_LEN),
+                mr.RefEngine("stream_draft", cfg_d, sd_d, gc.B, 0, gc.BUDGET))
     raise KeyError(kind)
 
 
-@pytest.mark.parametrize("kind,gamma", [("longspec_snapkv", 3), ("longspec_snapkv_rej", 1), ("longspec_stream", 3)])
+@pytest.mark.parametrize("kind,gamma", [("longspec_snapkv", 3), ("longspec_snapkv_rej", 1), ("longspec_stream", 3),
+                                        ("longspec_stream_70b", 3)])
 def test_longspec_matches_reference_script(kind, gamma):
     j = gc.load_json(f"run_{kind}.json")
     eng, drf = _engines(kind)
