@@ -66,6 +66,30 @@ def test_ops_refuse_cpu_tensors_and_bad_arguments():
     assert lib.md_allreduce_oneshot(None, p, p, 8, None) == -1
 
 
+def test_every_entry_point_rejects_null_arguments():
+    """Error behaviour of the C ABI: every entry point called with all-zero / NULL arguments returns a negative
+    MD_ERR_* code (or 0 bytes for the size queries) and leaves a message naming itself -- validation happens before
+    anything touches the device, so this runs without a GPU."""
+    import ctypes
+    from magicdec_amd import _lib
+    lib = _lib.load()
+    skip = {"md_abi_version", "md_last_error_string", "md_debug_set_attn_target_wgs", "md_ar_destroy"}
+    for name, (restype, argtypes) in _lib._SIGNATURES.items():
+        if name in skip:
+            continue
+        args = []
+        for t in argtypes:
+            args.append(None if t is ctypes.c_void_p else (0.0 if t in (ctypes.c_float, ctypes.c_double) else 0))
+        rc = getattr(lib, name)(*args)
+        if restype is ctypes.c_size_t:
+            assert rc == 0, name
+        else:
+            assert rc < 0, (name, rc)
+            msg = lib.md_last_error_string().decode()
+            assert name.replace("md_allreduce_oneshot", "md_allreduce") in msg or name in msg, (name, msg)
+    assert lib.md_ar_destroy(None) == 0          # destroying nothing is fine
+
+
 # ------------------------------------------------------------------ host logic vs the reference's own traces
 @pytest.fixture()
 def cpu_ops_patched(monkeypatch):
