@@ -63,7 +63,8 @@ def parse():
     ap.add_argument("--alpha", type=float, default=0.8, help="acceptance rate of the fixed-acceptance replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graphs", dest="graphs", action="store_true", default=None,
-                    help="capture decode steps into hipGraphs (engine.compile()); default: on for 1 GPU")
+                    help="capture decode steps into hipGraphs (engine.compile()); default: on (also under TP: the RCCL "
+                         "all-reduces are captured with the step)")
     ap.add_argument("--no-graphs", dest="graphs", action="store_false")
     ap.add_argument("--checkpoints", type=Path, default=Path("checkpoints"))
     ap.add_argument("--force-tp", action="store_true",
