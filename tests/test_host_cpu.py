@@ -66,6 +66,24 @@ def test_ops_refuse_cpu_tensors_and_bad_arguments():
     assert lib.md_allreduce_oneshot(None, p, p, 8, None) == -1
 
 
+def test_product_fails_loudly_without_the_hip_library(monkeypatch):
+    """No CPU fallback: with the shared library missing every device op raises MagicDecHipError naming the build
+    command (not a silent PyTorch path), and the error is sticky."""
+    from magicdec_amd import _lib, ops
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "_err", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libmagicdec_hip.so")
+    with pytest.raises(_lib.MagicDecHipError, match="no CPU fallback"):
+        _lib.load()
+    with pytest.raises(_lib.MagicDecHipError, match="__graft_entry__"):
+        ops.RopeTable(64, 64, 10000.0, 1.0, device="cpu")
+    # nothing under the product imports the oracle
+    import subprocess
+    out = subprocess.run(["grep", "-rln", "-E", r"^\s*(from|import) oracle", str(ROOT / "magicdec_amd")],
+                         capture_output=True, text=True).stdout.strip()
+    assert out == "", out
+
+
 def test_every_entry_point_rejects_null_arguments():
     """Error behaviour of the C ABI: every entry point called with all-zero / NULL arguments returns a negative
     MD_ERR_* code (or 0 bytes for the size queries) and leaves a message naming itself -- validation happens before
