@@ -69,6 +69,12 @@ int md_append_paged_kv(const void* k, const void* v, int64_t k_row_stride, int64
                        int KH, int D, int page_size, int kv_dtype, const float* k_scale,
                        const float* v_scale, md_stream_t stream);
 
+/* Number of KV rows the append kernels (md_append_paged_kv, md_rope_append, md_snapkv_select's gather) dropped
+ * since the last reset because their position lay beyond the request's mapped pages (last_page_len > page_size:
+ * the reference's page tables never grow during decode, Engine/SnapKV/backend.py:147, and flashinfer would have
+ * written into the next request's page).  Host call, synchronises with the device; `reset` != 0 zeroes it. */
+int md_page_overflow_count(unsigned int* count_host, int reset);
+
 /* ------------------------------------------------------------------------
  * K5  mylib::rope / mylib::draft_rope -> flashinfer.rope.apply_rope /
  *     apply_llama31_rope (interleave=True)

@@ -101,6 +101,11 @@ class _BackendBase:
     def _qo(self, n):
         return self.qo_indptr * n
 
+    def _reset_kv_calibration(self):
+        """fp8 caches re-calibrate their static scales on the first prefill chunk of every encode()."""
+        for b in self.model.layers:
+            b.attention.kv_cache.calibrated = False
+
     def _run_step(self, key, fn, *tensors):
         if self._use_graphs:
             from .graph import run_captured
@@ -152,6 +157,7 @@ class SnapKVTargetBackend(_BackendBase):
             b.attention.kv_cache.kv_cache.zero_()
             if self.is_spec:
                 b.attention.kv_cache.draft_cache.zero_()
+        self._reset_kv_calibration()
         self.cachelens.zero_()
         self.qo_indptr = torch.arange(self.batch_size + 1, dtype=torch.int32, device=self.device)
         self._t.reset()
@@ -182,6 +188,9 @@ class SnapKVTargetBackend(_BackendBase):
             done += n
         self.model.skip_head = False
         if self.is_spec:
+            if not is_last:
+                raise ValueError("SnapKV self-speculation: prefix_len is a multiple of 128, so no last chunk ran the "
+                                 "select and the draft cache is empty (need (prefix_len - window_size) % 128 == 0)")
             self.draft_cachelens.copy_(self.cachelens)
         return tokens
 
@@ -267,6 +276,7 @@ class SnapKVDraftBackend(_BackendBase):
             b.attention.kv_cache.kv_cache.zero_()
             if self.is_compress:
                 b.attention.kv_cache.draft_cache.zero_()
+        self._reset_kv_calibration()
         self.cachelens.zero_()
         self.qo_indptr = torch.arange(self.batch_size + 1, dtype=torch.int32, device=self.device)
         self._t.reset()
@@ -295,6 +305,9 @@ class SnapKVDraftBackend(_BackendBase):
             self.cachelens += n
             done += n
         self.model.skip_head = False
+        if self.is_compress and not is_last:
+            raise ValueError("SnapKV draft: prefix_len is a multiple of 128, so no last chunk ran the select and the "
+                             "draft cache is empty (need (prefix_len - window_size) % 128 == 0)")
         return tokens
 
     @torch.no_grad()
@@ -380,6 +393,7 @@ class StreamingDraftBackend(_BackendBase, _StreamingMixin):
     def clear_kv(self):
         for b in self.model.layers:
             b.attention.kv_cache.kv_cache.zero_()
+        self._reset_kv_calibration()
         self.cachelens.zero_()
         self.qo_indptr = torch.arange(self.batch_size + 1, dtype=torch.int32, device=self.device)
         self._t.reset()
@@ -441,6 +455,7 @@ class StreamingSelfSpecBackend(_BackendBase, _StreamingMixin):
         for b in self.model.layers:
             b.attention.kv_cache.kv_cache.zero_()
             b.attention.kv_cache.draft_cache.zero_()
+        self._reset_kv_calibration()
         self.cachelens.zero_()
         self.draft_cachelens.zero_()
         self.qo_indptr = torch.arange(self.batch_size + 1, dtype=torch.int32, device=self.device)

@@ -242,6 +242,9 @@ class Transformer(nn.Module):
         self.process_group = None
         self._ready = False
         self.skip_head = False
+        # optional static fp8 KV scales [(k_scale[KH], v_scale[KH]) per layer], e.g. from an offline calibration;
+        # when set they replace the first-chunk calibration of every encode()
+        self.kv_scale_override = None
 
     @classmethod
     def from_name(cls, name: str):
@@ -377,7 +380,12 @@ class Transformer(nn.Module):
             cache2 = kvc.draft_cache if tab2 is not None else None
             scales = kvc.scales(which)
             if scales is not None and calibrate and not kvc.calibrated:
-                kvc.calibrate(k, v)
+                if self.kv_scale_override is not None:
+                    kvc.k_scale.copy_(self.kv_scale_override[i][0])
+                    kvc.v_scale.copy_(self.kv_scale_override[i][1])
+                    kvc.calibrated = True
+                else:
+                    kvc.calibrate(k, v)
             q_rot = ops.rope_append(q, k, v, qo_indptr, offsets, self.rope_table, cache, tab.indices, tab.indptr,
                                     tab.last_page_len, cache2, tab2.indices if tab2 else None,
                                     tab2.indptr if tab2 else None, tab2.last_page_len if tab2 else None, n_max=n,
@@ -405,6 +413,11 @@ class Transformer(nn.Module):
         """Chunked prefill; on the last chunk of a SnapKV engine also runs the select (model.py:371-387).
         ctx_len = offsets[0]+seqlen is passed by the back-end (host-known, no device read)."""
         snap = draft_tab if (is_last and self.spec and not self.streaming and draft_tab is not None) else None
+        if snap is not None and idx.shape[1] != self.window_size:
+            # the reference takes the whole last chunk as the observation window (Engine/SnapKV/model.py:389-395),
+            # which is `window_size` rows only under its CLI assert (prefix_len - window_size) % 128 == 0
+            raise ValueError(f"SnapKV select needs the last prefill chunk to be exactly window_size="
+                             f"{self.window_size} tokens, got {idx.shape[1]} ((prefix_len - window_size) % 128 != 0)")
         self._snap_ctx_len = ctx_len
         return self._std_step(idx, input_pos, kv_append_indptr, tab, snap_tab=snap, calibrate=True)
 

@@ -11,7 +11,7 @@ from ctypes import c_char_p, c_double, c_float, c_int, c_int64, c_size_t, c_void
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmagicdec_hip.so")
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 _lib = None
 _err = None
@@ -23,6 +23,7 @@ L = c_int64
 _SIGNATURES = {
     "md_abi_version": (c_int, []),
     "md_last_error_string": (c_char_p, []),
+    "md_page_overflow_count": (c_int, [P, I]),
     "md_append_paged_kv": (c_int, [P, P, L, L, P, P, P, P, P, I, I, I, I, I, I, P, P, P]),
     "md_rope": (c_int, [P, P, L, L, P, P, P, P, I, I, I, I, I, P, I, P]),
     "md_rope_fill_table_host": (c_int, [P, I, I, c_double, c_double, c_double, c_double, c_double]),

@@ -124,12 +124,13 @@ def longspec_main(kind: str, argv=None):
     barrier = dist.barrier if use_tp else None
 
     total_time, num_gen_tokens, target_steps = 0.0, 0, 0
+    timers = harness.PhaseTimers(DEVICE) if args.benchmark else None
     for step, batch in enumerate(dataloader):
         if step >= num_eval_steps:
             break
         input_ids = batch[0].to(DEVICE)
         st, dt = harness.run_longspec_batch(engine, draft, input_ids, args.gamma, MAX_LEN_TARGET, eot_1, eot_2,
-                                            bcast=bcast, barrier=barrier)
+                                            bcast=bcast, barrier=barrier, timers=timers)
         total_time += dt
         target_steps += st.iters
         num_gen_tokens += int(st.num_nodes.sum() - (input_ids.shape[1] + 1) * BATCH_SIZE)
@@ -139,10 +140,14 @@ def longspec_main(kind: str, argv=None):
                 print_(tokenizer.decode(st.output[i, args.prefix_len:st.num_nodes[i]]))
         print_("total time :{:.5f}s, time per iter :{:.5f}s, decoding step: {}, large model step: {}, avg latency: {}".format(
             total_time, total_time / target_steps, num_gen_tokens, target_steps, total_time / num_gen_tokens * BATCH_SIZE))
-        if args.benchmark:
-            print_("avg generate len per sentence: {}".format(num_gen_tokens / target_steps / BATCH_SIZE))
+        if args.benchmark:     # tests/SnapKV/longspec_benchmark.py:305-307
+            print_("target time :{:.5f}s, draft time :{:.5f}s, verify loop : {}, avg generate len per sentence: {}".format(
+                timers.target / target_steps, timers.draft / target_steps, timers.verify_loop / target_steps,
+                num_gen_tokens / target_steps / BATCH_SIZE))
         if step < 5:
             total_time, num_gen_tokens, target_steps = 0.0, 0, 0
+            if timers is not None:
+                timers.reset()
         if use_tp:
             dist.barrier()
     print_(f"Final tokens per second :{num_gen_tokens / total_time}")
@@ -196,11 +201,13 @@ def selfspec_main(kind: str, argv=None):
     dataloader = DataLoader(dataset, batch_size=BATCH_SIZE, shuffle=False, drop_last=True)
     num_eval_steps = min(10, len(dataloader))
     total_time, num_gen_tokens, target_steps = 0.0, 0, 0
+    timers = harness.PhaseTimers(DEVICE) if args.benchmark else None
     for step, batch in enumerate(dataloader):
         if step >= num_eval_steps:
             break
         input_ids = batch[0].to(DEVICE)
-        st, dt = harness.run_selfspec_batch(engine, input_ids, args.gamma, MAX_LEN_TARGET, eot_1, eot_2, streaming)
+        st, dt = harness.run_selfspec_batch(engine, input_ids, args.gamma, MAX_LEN_TARGET, eot_1, eot_2, streaming,
+                                            timers=timers)
         total_time += dt
         target_steps += st.iters
         num_gen_tokens += int(st.num_nodes.sum() - (input_ids.shape[1] + 1) * BATCH_SIZE)
@@ -210,10 +217,14 @@ def selfspec_main(kind: str, argv=None):
                 print_(tokenizer.decode(st.output[i, args.prefix_len:st.num_nodes[i]]))
         print_("total time :{:.5f}s, time per iter :{:.5f}s, decoding step: {}, large model step: {}".format(
             total_time, total_time / target_steps, num_gen_tokens, target_steps))
-        if args.benchmark:
-            print_("avg generate len per sentence: {}".format(num_gen_tokens / target_steps / BATCH_SIZE))
+        if args.benchmark:     # tests/SnapKV/selfspec_benchmark.py (same line as the longspec script)
+            print_("target time :{:.5f}s, draft time :{:.5f}s, verify loop : {}, avg generate len per sentence: {}".format(
+                timers.target / target_steps, timers.draft / target_steps, timers.verify_loop / target_steps,
+                num_gen_tokens / target_steps / BATCH_SIZE))
         if step < 5:
             total_time, num_gen_tokens, target_steps = 0.0, 0, 0
+            if timers is not None:
+                timers.reset()
         if use_tp:
             dist.barrier()
     print_(f"Final tokens per second :{num_gen_tokens / total_time}")
@@ -225,6 +236,7 @@ def baseline_main(argv=None):
     parser = argparse.ArgumentParser(description='Process model configuration and partitions.')
     _common(parser, spec=False)
     args = parser.parse_args(argv)
+    assert args.prefix_len < args.max_len          # tests/baseline_benchmark.py:30-31
     assert args.max_len % 128 == 0
     DEVICE = _device()
     use_tp = len(args.rank_group) > 1

@@ -163,7 +163,8 @@ __global__ __launch_bounds__(256, 2) void paged_attn_kernel(const AttnParams p) 
     const int n_b = p.qo_indptr[b + 1] - q0;
     const int pg0 = p.page_indptr[b];
     const int npages = p.page_indptr[b + 1] - pg0;
-    const int kv_len = npages > 0 ? (npages - 1) * p.page_size + p.last_page_len[b] : 0;
+    // clamped to the mapped pages: an over-long last_page_len must not walk past the request's page list
+    const int kv_len = npages > 0 ? min((npages - 1) * p.page_size + p.last_page_len[b], npages * p.page_size) : 0;
     const int nrows = n_b * g;
     const int tile_base = SPLITQ ? (qg * 4 + wave) * QT : qg * QT;
 
@@ -615,7 +616,8 @@ __global__ __launch_bounds__(64 * NW, 2) void prefill_attn_kernel(const AttnPara
     const int n_b = p.qo_indptr[b + 1] - q0;
     const int pg0 = p.page_indptr[b];
     const int npages = p.page_indptr[b + 1] - pg0;
-    const int kv_len = npages > 0 ? (npages - 1) * p.page_size + p.last_page_len[b] : 0;
+    // clamped to the mapped pages: an over-long last_page_len must not walk past the request's page list
+    const int kv_len = npages > 0 ? min((npages - 1) * p.page_size + p.last_page_len[b], npages * p.page_size) : 0;
     const int nrows = n_b * g;
     const int tile_base = (qg * NW + wave) * QT;
 

@@ -13,7 +13,14 @@
 #include "md_common.h"
 #include <math.h>
 
+// rows dropped by an append because they fell beyond the request's mapped pages (md_page_overflow_count)
+__device__ unsigned int g_md_page_overflow = 0;
+
 namespace {
+
+__device__ __forceinline__ void note_overflow() {
+    if (threadIdx.x == 0) atomicAdd(&g_md_page_overflow, 1u);
+}
 
 __device__ __forceinline__ int req_len(const int32_t* indptr, const int32_t* last, int b, int page_size,
                                        int* pg0) {
@@ -21,6 +28,13 @@ __device__ __forceinline__ int req_len(const int32_t* indptr, const int32_t* las
     const int np = indptr[b + 1] - p0;
     *pg0 = p0;
     return np > 0 ? (np - 1) * page_size + last[b] : 0;
+}
+
+// Rows a request may hold: an over-long last_page_len (> page_size: the caller never mapped the next page -- the
+// reference's page tables do not grow during decode, Engine/SnapKV/backend.py:147) must not index past the
+// request's own page list; such rows are dropped (the host raises, harness.check_page_bounds).
+__device__ __forceinline__ int req_capacity(const int32_t* indptr, int b, int page_size) {
+    return (indptr[b + 1] - indptr[b]) * page_size;
 }
 
 // destination (element offset) of row `pos` of request b in a paged cache, K half
@@ -73,6 +87,10 @@ __global__ __launch_bounds__(256) void append_kernel(const bf16_t* __restrict__ 
     const int len = req_len(indptr, last, b, page_size, &pg0);
     const int pos = len - n_b + j;
     if (pos < 0) return;
+    if (pos >= req_capacity(indptr, b, page_size)) {
+        note_overflow();
+        return;
+    }
     const int64_t dst = page_row_offset(indices, pg0, pos, page_size, KH, D);
     const int64_t half = (int64_t)page_size * KH * D;
     const int nvec = KH * D / 8;
@@ -165,12 +183,16 @@ __global__ __launch_bounds__(256) void rope_append_kernel(const bf16_t* __restri
     int pg0;
     const int len1 = req_len(t1.indptr, t1.last, b, page_size, &pg0);
     const int p1 = len1 - n_b + j;
-    const int64_t d1 = p1 >= 0 ? page_row_offset(t1.indices, pg0, p1, page_size, KH, D) : -1;
+    const bool over1 = p1 >= req_capacity(t1.indptr, b, page_size);
+    const int64_t d1 = (p1 >= 0 && !over1) ? page_row_offset(t1.indices, pg0, p1, page_size, KH, D) : -1;
+    if (over1) note_overflow();
     int64_t d2 = -1;
     if (t2.cache) {
         const int len2 = req_len(t2.indptr, t2.last, b, page_size, &pg0);
         const int p2 = len2 - n_b + j;
-        d2 = p2 >= 0 ? page_row_offset(t2.indices, pg0, p2, page_size, KH, D) : -1;
+        const bool over2 = p2 >= req_capacity(t2.indptr, b, page_size);
+        d2 = (p2 >= 0 && !over2) ? page_row_offset(t2.indices, pg0, p2, page_size, KH, D) : -1;
+        if (over2) note_overflow();
     }
     for (int i = threadIdx.x; i < nq + 2 * nk; i += blockDim.x) {
         if (i < nq) {
@@ -197,6 +219,20 @@ __global__ __launch_bounds__(256) void rope_append_kernel(const bf16_t* __restri
 bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
 }  // namespace
+
+extern "C" int md_page_overflow_count(unsigned int* count_host, int reset) {
+    MD_CHECK_ARG(count_host, "md_page_overflow_count: null pointer argument");
+    hipError_t e = hipMemcpyFromSymbol(count_host, HIP_SYMBOL(g_md_page_overflow), sizeof(unsigned int));
+    if (e == hipSuccess && reset && *count_host) {
+        const unsigned int z = 0;
+        e = hipMemcpyToSymbol(HIP_SYMBOL(g_md_page_overflow), &z, sizeof(z));
+    }
+    if (e != hipSuccess) {
+        md_set_error("md_page_overflow_count: %s", hipGetErrorString(e));
+        return MD_ERR_LAUNCH;
+    }
+    return MD_OK;
+}
 
 extern "C" int md_append_paged_kv(const void* k, const void* v, int64_t k_row_stride, int64_t v_row_stride,
                                   const int32_t* append_indptr, void* cache, const int32_t* page_indices,

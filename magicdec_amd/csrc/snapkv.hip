@@ -374,7 +374,7 @@ __global__ __launch_bounds__(64) void snapkv_gather_kernel(const GatherParams p)
     const int dnp = p.dindptr[b + 1] - dp0;
     const int dlen = dnp > 0 ? (dnp - 1) * p.page_size + p.dlast[b] : 0;
     const int pos = dlen - p.budget + j;
-    if (pos < 0) return;
+    if (pos < 0 || pos >= dnp * p.page_size) return;
     const int dpg = pos / p.page_size, dsl = pos - dpg * p.page_size;
     const int64_t dpid = p.dindices[dp0 + dpg];
     const int64_t doff = (dpid * 2 * p.page_size + dsl) * row_elems + kvh * p.D;

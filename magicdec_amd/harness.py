@@ -69,6 +69,46 @@ def _read_flags(st: LoopState):
     return bool(st.flags_host[0]), bool(st.flags_host[1])
 
 
+class PhaseTimers:
+    """--benchmark of the reference scripts (tests/SnapKV/longspec_benchmark.py:159-203,305-307): synchronise around
+    the draft phase, the target verification and the verify loop and accumulate their wall times."""
+
+    def __init__(self, device):
+        self.device = device
+        self.draft = self.target = self.verify_loop = 0.0
+        self._t = 0.0
+
+    def reset(self):
+        self.draft = self.target = self.verify_loop = 0.0
+
+    def start(self):
+        _sync_dev(self.device)
+        self._t = time.time()
+
+    def lap(self, what):
+        _sync_dev(self.device)
+        now = time.time()
+        setattr(self, what, getattr(self, what) + now - self._t)
+        self._t = now
+
+
+def _sync_dev(device):
+    if torch.device(device).type == "cuda":
+        torch.cuda.synchronize(device)
+
+
+def warn_on_page_overflow(where):
+    """Rows dropped by the append kernels because a request's last page was full (the reference's page tables do not
+    grow during decode; there flashinfer would have written into the next request's page).  Read once per batch."""
+    n = ops.page_overflow_count(reset=True)
+    if n:
+        import warnings
+        warnings.warn(f"{where}: {n} KV rows fell beyond their request's mapped pages and were dropped "
+                      f"(last_page_len grew past the page size -- the decode loop outran the page table)",
+                      RuntimeWarning, stacklevel=2)
+    return n
+
+
 def _draft_round(step_fn, st: LoopState, gamma, next_double):
     """gamma draft steps; after an all-accept iteration the first step consumes two tokens
     (tests/SnapKV/longspec_benchmark.py:165-188)."""
@@ -81,19 +121,25 @@ def _draft_round(step_fn, st: LoopState, gamma, next_double):
 
 
 def longspec_iteration(engine, draft, st: LoopState, gamma, eot_1, eot_2, max_nodes, next_double,
-                       forced_accept=None, bcast=None):
+                       forced_accept=None, bcast=None, timers: PhaseTimers = None):
     """One iteration of the longspec loop: gamma draft steps, one verify, the fused accept/rollback.
     Returns (terminal, next_double).
 
     Tensor parallel (tests/SnapKV/longspec_benchmark.py:163-189): `draft` is None on ranks outside the draft
     sub-group; when the draft group is smaller than the target group the gamma draft tokens are broadcast from
     `bcast = (src_rank, group)` before the verify.  Every rank runs the (replicated, all-integer) accept kernel."""
+    if timers is not None:
+        timers.start()
     if draft is not None:
         _draft_round(lambda ids, cu: draft.inference(ids, cachelen_update=cu), st, gamma, next_double)
     if bcast is not None:
         import torch.distributed as dist
         dist.broadcast(st.tokens_buffer, src=bcast[0], group=bcast[1])
+    if timers is not None:
+        timers.lap("draft")
     target_tokens = engine.inference(st.tokens_buffer)
+    if timers is not None:
+        timers.lap("target")
     if forced_accept is not None:
         target_tokens = _force_accept(st.tokens_buffer, target_tokens, forced_accept, gamma)
     ops.accept_rollback(st.tokens_buffer, target_tokens, st.output, st.num_nodes, engine.cachelens,
@@ -102,18 +148,27 @@ def longspec_iteration(engine, draft, st: LoopState, gamma, eot_1, eot_2, max_no
                         gamma, gamma, eot_1, eot_2, max_nodes, st.accept_nums, st.bonus, st.double_buffer,
                         st.cachelens_update, st.flags)
     st.iters += 1
-    return _read_flags(st)
+    res = _read_flags(st)
+    if timers is not None:
+        timers.lap("verify_loop")
+    return res
 
 
 def selfspec_iteration(engine, st: LoopState, gamma, eot_1, eot_2, max_nodes, next_double, streaming,
-                       forced_accept=None):
+                       forced_accept=None, timers: PhaseTimers = None):
     """One iteration of tests/SnapKV/selfspec_benchmark.py:121-211 (streaming=False: draft rolled back by
     gamma+1 and advanced by accept_nums, no two-token step) or tests/StreamingLLM/selfspec_benchmark.py:121-238."""
+    if timers is not None:
+        timers.start()
     if streaming:
         _draft_round(lambda ids, cu: engine.speculate(ids, cachelen_update=cu), st, gamma, next_double)
     else:
         _draft_round(lambda ids, cu: engine.speculate(ids), st, gamma, False)
+    if timers is not None:
+        timers.lap("draft")
     target_tokens = engine.verify(st.tokens_buffer)
+    if timers is not None:
+        timers.lap("target")
     if forced_accept is not None:
         target_tokens = _force_accept(st.tokens_buffer, target_tokens, forced_accept, gamma)
     if streaming:
@@ -127,7 +182,10 @@ def selfspec_iteration(engine, st: LoopState, gamma, eot_1, eot_2, max_nodes, ne
                             engine.draft_paged_kv_last_page_len, gamma, gamma + 1, gamma + 1, eot_1, eot_2, max_nodes,
                             st.accept_nums, st.bonus, None, None, st.flags)
     st.iters += 1
-    return _read_flags(st)
+    res = _read_flags(st)
+    if timers is not None:
+        timers.lap("verify_loop")
+    return res
 
 
 def _force_accept(tokens_buffer, target_tokens, forced_accept, gamma):
@@ -143,7 +201,7 @@ def _force_accept(tokens_buffer, target_tokens, forced_accept, gamma):
 
 
 def run_longspec_batch(engine, draft, input_ids, gamma, max_len, eot_1, eot_2, forced_accept_fn=None,
-                       trace_fn=None, bcast=None, barrier=None):
+                       trace_fn=None, bcast=None, barrier=None, timers: PhaseTimers = None):
     """A whole batch: prefill both models, loop until termination.  Returns (state, seconds in the loop)."""
     B, S = input_ids.shape
     st = new_state(B, gamma, max_len + 1, input_ids.device, input_ids)
@@ -157,15 +215,18 @@ def run_longspec_batch(engine, draft, input_ids, gamma, max_len, eot_1, eot_2, f
     terminal, nd = False, False
     while not terminal:
         fa = forced_accept_fn(st) if forced_accept_fn is not None else None
-        terminal, nd = longspec_iteration(engine, draft, st, gamma, eot_1, eot_2, S + 80, nd, fa, bcast)
+        terminal, nd = longspec_iteration(engine, draft, st, gamma, eot_1, eot_2, S + 80, nd, fa, bcast, timers)
         if trace_fn is not None:
             trace_fn(st)
     _sync(input_ids)
-    return st, time.perf_counter() - t0
+    dt = time.perf_counter() - t0
+    if input_ids.is_cuda:
+        warn_on_page_overflow("longspec batch")
+    return st, dt
 
 
 def run_selfspec_batch(engine, input_ids, gamma, max_len, eot_1, eot_2, streaming, forced_accept_fn=None,
-                       trace_fn=None):
+                       trace_fn=None, timers: PhaseTimers = None):
     B, S = input_ids.shape
     st = new_state(B, gamma, max_len + 1, input_ids.device, input_ids)
     st.tokens_buffer[:, :1] = engine.encode(input_ids=input_ids)[:, -1:]
@@ -176,11 +237,14 @@ def run_selfspec_batch(engine, input_ids, gamma, max_len, eot_1, eot_2, streamin
     terminal, nd = False, False
     while not terminal:
         fa = forced_accept_fn(st) if forced_accept_fn is not None else None
-        terminal, nd = selfspec_iteration(engine, st, gamma, eot_1, eot_2, S + 80, nd, streaming, fa)
+        terminal, nd = selfspec_iteration(engine, st, gamma, eot_1, eot_2, S + 80, nd, streaming, fa, timers)
         if trace_fn is not None:
             trace_fn(st)
     _sync(input_ids)
-    return st, time.perf_counter() - t0
+    dt = time.perf_counter() - t0
+    if input_ids.is_cuda:
+        warn_on_page_overflow("selfspec batch")
+    return st, dt
 
 
 def run_baseline_batch(engine, input_ids, max_len, eot_1, eot_2, check_eot_every=1):
@@ -200,4 +264,7 @@ def run_baseline_batch(engine, input_ids, max_len, eot_1, eot_2, check_eot_every
             last = next_tokens[:, -1]
             terminate = bool(((last == eot_1) | (last == eot_2)).any())
     _sync(input_ids)
-    return output, steps, time.perf_counter() - t0
+    dt = time.perf_counter() - t0
+    if input_ids.is_cuda:
+        warn_on_page_overflow("baseline batch")
+    return output, steps, dt

@@ -87,6 +87,14 @@ def update_kv(k, v, kv_append_indptr, kv_cache, kv_page_indices, kv_page_indptr,
           "md_append_paged_kv")
 
 
+def page_overflow_count(reset=True):
+    """KV rows dropped by the append kernels because their request's last page was full (see
+    md_page_overflow_count).  Synchronises with the device: call it per batch, not per step."""
+    n = ctypes.c_uint(0)
+    check(_lib.load().md_page_overflow_count(ctypes.byref(n), 1 if reset else 0), "md_page_overflow_count")
+    return int(n.value)
+
+
 # ----------------------------------------------------------------------------- K5
 class RopeTable:
     """Host-precomputed cos/sin table on the device (float32 [max_pos, D/2, 2])."""
@@ -151,9 +159,11 @@ class AttnWorkspace:
     def __init__(self, device="cuda"):
         self.device = device
         self.buf = torch.empty(1 << 20, dtype=torch.uint8, device=device)
+        self._retired = []     # outgrown buffers stay allocated: captured hipGraphs have their addresses baked in
 
     def get(self, nbytes):
         if self.buf.numel() < nbytes:
+            self._retired.append(self.buf)
             self.buf = torch.empty(int(nbytes * 1.25) + 256, dtype=torch.uint8, device=self.device)
         return self.buf
 

@@ -124,6 +124,23 @@ def shard_state_dict(sd, cfg: RefConfig, rank: int, world: int):
 
 
 # --------------------------------------------------------------------------- small ops
+LINEAR_MODE = "fp32"     # "fp32": torch CPU bf16 linear (fp32 accumulation in the library's own order, one rounding);
+#                          "fp64": products and sums in float64, ONE rounding to bf16 -- the correctly rounded result
+#                          of the same bf16 operands.  Tests run the oracle in both modes: the distance between the two
+#                          is the noise floor of "a valid bf16 implementation with another summation order", the
+#                          yardstick the HIP engine's logits are gated with (tests/test_gpu_engine.py).
+
+
+def linear(x, w, b=None):
+    """F.linear at the reference's rounding points (bf16 in, bf16 out), see LINEAR_MODE."""
+    if LINEAR_MODE == "fp64":
+        y = x.double() @ w.double().t()
+        if b is not None:
+            y = y + b.double()
+        return y.to(x.dtype)
+    return F.linear(x, w, b)
+
+
 def rmsnorm(x, weight, eps):
     """Engine/SnapKV/model.py:458-469: fp32 norm -> cast -> * weight (bf16 multiply)."""
     xf = x.float()
@@ -133,7 +150,20 @@ def rmsnorm(x, weight, eps):
 
 def feed_forward(x, w1, w3, w2):
     """Engine/SnapKV/model.py:451-455."""
-    return F.linear(F.silu(F.linear(x, w1)) * F.linear(x, w3), w2)
+    return linear(F.silu(linear(x, w1)) * linear(x, w3), w2)
+
+
+FP8_MAX, FP8_MARGIN = 448.0, 1.5
+
+
+def calibrate_fp8_scales(k, v, margin=FP8_MARGIN):
+    """Static per-kv-head scales of the fp8 cache from the first prefill chunk's UN-rotated k [rows, KH, D] and v:
+    K's bound is the largest rotary-pair norm (what a rotation can put into one component), V's the largest |v|;
+    scale = bound * margin / 448, floored at 2^-20.  (Specification of the product's KVCache.calibrate.)"""
+    rows, KH, D = k.shape
+    kb = k.float().view(rows, KH, D // 2, 2).square().sum(-1).amax(dim=(0, 2)).sqrt()
+    vb = v.float().abs().amax(dim=(0, 2))
+    return ((kb * (margin / FP8_MAX)).clamp_min(2.0 ** -20), (vb * (margin / FP8_MAX)).clamp_min(2.0 ** -20))
 
 
 def tp_argmax_merge(vals, idx):
@@ -311,7 +341,7 @@ class RefModel:
         p = f"layers.{i}.attention."
         B, n, _ = x.shape
         kv = c.n_local_heads * c.head_dim
-        y = F.linear(x, self.sd[p + "wqkv.weight"], self.sd.get(p + "wqkv.bias"))
+        y = linear(x, self.sd[p + "wqkv.weight"], self.sd.get(p + "wqkv.bias"))
         q, k, v = y.split([c.n_head * c.head_dim, kv, kv], dim=-1)
         return (q.reshape(B * n, c.n_head, c.head_dim), k.reshape(B * n, c.n_local_heads, c.head_dim),
                 v.reshape(B * n, c.n_local_heads, c.head_dim))
@@ -329,7 +359,7 @@ class RefModel:
         p = f"layers.{i}."
         B, n, _ = x.shape
         y = attn_fn(rmsnorm(x, self.sd[p + "attention_norm.weight"], self.cfg.norm_eps), i)
-        y = self._all_reduce(F.linear(y.reshape(B, n, -1), self.sd[p + "attention.wo.weight"]))
+        y = self._all_reduce(linear(y.reshape(B, n, -1), self.sd[p + "attention.wo.weight"]))
         h = x + y
         f = feed_forward(rmsnorm(h, self.sd[p + "ffn_norm.weight"], self.cfg.norm_eps),
                          self.sd[p + "feed_forward.w1.weight"], self.sd[p + "feed_forward.w3.weight"],
@@ -339,7 +369,7 @@ class RefModel:
     def head(self, x, return_logits=False):
         """:175-188 final norm -> lm head -> argmax (TP: merge of per-rank maxima)."""
         x = rmsnorm(x, self.sd["norm.weight"], self.cfg.norm_eps)
-        logits = F.linear(x, self.sd["output.weight"])
+        logits = linear(x, self.sd["output.weight"])
         self.last_logits = logits          # kept for tie-aware token comparisons in tests
         if return_logits:
             return logits
@@ -380,8 +410,13 @@ class RefEngine:
     """
 
     def __init__(self, mode, cfg: RefConfig, sd, B, max_len=0, draft_budget=0, window=32, group=None, rank=0,
-                 world=1, max_pos=1 << 15):
+                 world=1, max_pos=1 << 15, kv_fp8=False):
+        """kv_fp8: emulate the product's e4m3fn full-context cache (not a reference feature; specification =
+        flashinfer_ref.quantize_fp8 / dequantize_cache_fp8 + calibrate_fp8_scales below).  The full cache then
+        holds the EXACT float32 products byte * scale; compressed draft caches stay bf16."""
         assert mode in ("target", "snapkv_self", "snapkv_draft", "stream_draft", "stream_self")
+        self.kv_fp8 = kv_fp8
+        self.kv_scales = [None] * cfg.n_layer
         self.mode, self.cfg, self.B = mode, cfg, B
         self.model = RefModel(cfg, sd, max_pos=max_pos, group=group, rank=rank, world=world)
         self.budget, self.window = draft_budget, window
@@ -396,7 +431,8 @@ class RefEngine:
             if npages * PAGE < B * max_len:
                 npages += B
             self.ppr = npages // B
-        self.caches = [torch.zeros(B * self.ppr, 2, PAGE, KH, D, dtype=BF16) for _ in range(cfg.n_layer)]
+        self.caches = [torch.zeros(B * self.ppr, 2, PAGE, KH, D, dtype=torch.float32 if kv_fp8 else BF16)
+                       for _ in range(cfg.n_layer)]
         if self.has_draft:
             self.dppr = draft_budget // PAGE + 1
             self.draft_caches = [torch.zeros(B * self.dppr, 2, PAGE, KH, D, dtype=BF16) for _ in range(cfg.n_layer)]
@@ -409,6 +445,7 @@ class RefEngine:
         B = self.B
         for c in self.caches:
             c.zero_()
+        self.kv_scales = [None] * self.cfg.n_layer      # re-calibrated by every encode (first prefill chunk)
         self.cachelens = torch.zeros(B, dtype=torch.int32)
         self.qo_indptr = torch.arange(B + 1, dtype=torch.int32)
         self.paged_kv_indptr = torch.arange(B + 1, dtype=torch.int32)
@@ -464,8 +501,16 @@ class RefEngine:
 
         def fn(xn, i):
             q, k, v = m.qkv(xn, i)
+            if self.kv_fp8 and caches is self.caches and self.kv_scales[i] is None:
+                self.kv_scales[i] = calibrate_fp8_scales(k, v)
             q, k = m.rope(q, k, qo, offsets)
-            fr.append_paged_kv_cache(k, v, qo, caches[i], tab["indices"], tab["indptr"], tab["last"])
+            if self.kv_fp8 and caches is self.caches:
+                ks, vs = self.kv_scales[i]
+                k8 = fr.quantize_fp8(k, ks).float() * ks.view(1, -1, 1)      # exact byte * scale products
+                v8 = fr.quantize_fp8(v, vs).float() * vs.view(1, -1, 1)
+                fr.append_paged_kv_cache(k8, v8, qo, caches[i], tab["indices"], tab["indptr"], tab["last"])
+            else:
+                fr.append_paged_kv_cache(k, v, qo, caches[i], tab["indices"], tab["indptr"], tab["last"])
             if caches2 is not None:
                 fr.append_paged_kv_cache(k, v, qo, caches2[i], tab2["indices"], tab2["indptr"], tab2["last"])
             y = m.attn(q, caches[i], qo, tab)
