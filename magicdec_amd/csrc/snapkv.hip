@@ -13,7 +13,7 @@
 //   draft rows = K,V[indices] ++ K,V[S-W:S]
 //
 // Four small launches, none on the timed decode path (once per prefill per layer):
-//   stats   : row max / sum-exp partials per 1024-column chunk   (MFMA scores)
+//   stats   : row max / sum-exp partials per 1024-column chunk   (MFMA scores; float64 sums)
 //   accum   : recompute scores, p, 8-row group sums, bf16 chunk accumulation
 //   select  : pool + group sum + exact radix select + bitonic sort (one WG per b,kvh)
 //   gather  : copy the selected rows into the draft pages
@@ -29,7 +29,7 @@ struct SnapParams {
     const float* k_scale;
     const int32_t* page_indices;
     const int32_t* page_indptr;
-    float* partials;        // [B*KH][L][nch][2]
+    double* partials;       // [B*KH][L][nch][2] = (row max, sum of exp) per 1024-column chunk, float64
     unsigned short* aws;    // [B][H][S-W] bf16 bits
     int B, H, KH, g, W, S, L, nch, page_size;
     int64_t page_stride;
@@ -106,13 +106,18 @@ __device__ __forceinline__ f32x4 score_tile(const SnapParams& p, int b, int kvh,
 
 template <int D, bool FP8>
 __global__ __launch_bounds__(256) void snapkv_stats_kernel(const SnapParams p) {
-    extern __shared__ __attribute__((aligned(16))) float sm[];  // [4 waves][L][2]
+    // The softmax denominator and the normalised probabilities are evaluated in float64 so that p = bf16(softmax)
+    // is the CORRECTLY ROUNDED value: the reference's fp32 CPU softmax agrees with the correctly rounded one on every
+    // element of the fixtures (tests/test_gpu_ops.py measures both), an fp32 GPU evaluation with another sum order
+    // does not (a ~1e-7 relative error of Z flips ~1e-4 of the bf16 roundings, which the 8-row sums, the pooling and
+    // the group sum then spread over ~1 % of the final scores).  Runs once per prefill: the float64 cost is nil.
+    extern __shared__ __attribute__((aligned(16))) double smd[];  // [4 waves][L][2]
     const int chunk = blockIdx.x, kvh = blockIdx.y, b = blockIdx.z;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lq = lane & 15, lc = lane >> 4;
-    float* ms = sm + wave * p.L * 2;
+    double* ms = smd + wave * p.L * 2;
     for (int i = lane; i < p.L; i += 64) {
         ms[i * 2] = -INFINITY;
-        ms[i * 2 + 1] = 0.f;
+        ms[i * 2 + 1] = 0.0;
     }
     const int RT = p.L / 16;
     for (int cg = wave; cg < kChunkCols / 16; cg += 4) {
@@ -126,33 +131,33 @@ __global__ __launch_bounds__(256) void snapkv_stats_kernel(const SnapParams p) {
             float mx = fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3]));
             mx = fmaxf(mx, __shfl_xor(mx, 16));
             mx = fmaxf(mx, __shfl_xor(mx, 32));
-            float sum = 0.f;
+            double sum = 0.0;
             if (mx > -INFINITY) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) sum += expf(s[j] - mx);
+                for (int j = 0; j < 4; ++j) sum += exp((double)s[j] - (double)mx);
             }
             sum += __shfl_xor(sum, 16);
             sum += __shfl_xor(sum, 32);
             if (lc == 0 && mx > -INFINITY) {
                 const int row = rt * 16 + lq;
-                const float mo = ms[row * 2], zo = ms[row * 2 + 1];
-                const float mn = fmaxf(mo, mx);
+                const double mo = ms[row * 2], zo = ms[row * 2 + 1];
+                const double mn = fmax(mo, (double)mx);
                 ms[row * 2] = mn;
-                ms[row * 2 + 1] = zo * expf(mo - mn) + sum * expf(mx - mn);
+                ms[row * 2 + 1] = (mo > -INFINITY ? zo * exp(mo - mn) : 0.0) + sum * exp((double)mx - mn);
             }
         }
     }
     __syncthreads();
     for (int row = tid; row < p.L; row += 256) {
-        float M = -INFINITY;
-        for (int w = 0; w < 4; ++w) M = fmaxf(M, sm[(w * p.L + row) * 2]);
-        float Z = 0.f;
+        double M = -INFINITY;
+        for (int w = 0; w < 4; ++w) M = fmax(M, smd[(w * p.L + row) * 2]);
+        double Z = 0.0;
         if (M > -INFINITY)
             for (int w = 0; w < 4; ++w) {
-                const float mw = sm[(w * p.L + row) * 2];
-                if (mw > -INFINITY) Z += sm[(w * p.L + row) * 2 + 1] * expf(mw - M);
+                const double mw = smd[(w * p.L + row) * 2];
+                if (mw > -INFINITY) Z += smd[(w * p.L + row) * 2 + 1] * exp(mw - M);
             }
-        float* out = p.partials + (((int64_t)(b * p.KH + kvh) * p.L + row) * p.nch + chunk) * 2;
+        double* out = p.partials + (((int64_t)(b * p.KH + kvh) * p.L + row) * p.nch + chunk) * 2;
         out[0] = M;
         out[1] = Z;
     }
@@ -160,20 +165,20 @@ __global__ __launch_bounds__(256) void snapkv_stats_kernel(const SnapParams p) {
 
 template <int D, bool FP8>
 __global__ __launch_bounds__(256) void snapkv_accum_kernel(const SnapParams p) {
-    extern __shared__ __attribute__((aligned(16))) float sm[];  // [L][2] row stats, then [4][g][16] accumulators
+    extern __shared__ __attribute__((aligned(16))) double smd[];  // [L][2] row stats (f64), then [4][g][16] f32 accumulators
     const int ctile = blockIdx.x, kvh = blockIdx.y, b = blockIdx.z;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lq = lane & 15, lc = lane >> 4;
-    float* MZ = sm;
-    float* accs = sm + p.L * 2 + wave * p.g * 16;
+    double* MZ = smd;
+    float* accs = reinterpret_cast<float*>(smd + p.L * 2) + wave * p.g * 16;
     for (int row = tid; row < p.L; row += 256) {
-        const float* pp = p.partials + ((int64_t)(b * p.KH + kvh) * p.L + row) * p.nch * 2;
-        float M = -INFINITY;
-        for (int c = 0; c < p.nch; ++c) M = fmaxf(M, pp[c * 2]);
-        float Z = 0.f;
+        const double* pp = p.partials + ((int64_t)(b * p.KH + kvh) * p.L + row) * p.nch * 2;
+        double M = -INFINITY;
+        for (int c = 0; c < p.nch; ++c) M = fmax(M, pp[c * 2]);
+        double Z = 0.0;
         for (int c = 0; c < p.nch; ++c)
-            if (pp[c * 2] > -INFINITY) Z += pp[c * 2 + 1] * expf(pp[c * 2] - M);
+            if (pp[c * 2] > -INFINITY) Z += pp[c * 2 + 1] * exp(pp[c * 2] - M);
         MZ[row * 2] = M;
-        MZ[row * 2 + 1] = Z;
+        MZ[row * 2 + 1] = 1.0 / Z;
     }
     for (int i = lane; i < p.g * 16; i += 64) accs[i] = 0.f;
     __syncthreads();
@@ -187,12 +192,13 @@ __global__ __launch_bounds__(256) void snapkv_accum_kernel(const SnapParams p) {
     for (int rt = 0; rt < RT; ++rt) {
         const f32x4 s = score_tile<D>(p, b, kvh, rt, col0, lq, lc, kf, kscale);
         const int row = rt * 16 + lq;
-        const float M = MZ[row * 2], Z = MZ[row * 2 + 1];
+        const double M = MZ[row * 2], rZ = MZ[row * 2 + 1];
         f32x4 gs;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            // softmax in fp32 -> bf16 (model.py:416), then the 8-row group sum in fp32 -> bf16 (:418)
-            float pj = expf(s[j] - M) / Z;
+            // softmax -> bf16 (model.py:416; float64 here, see the stats kernel), then the 8-row group sum in
+            // fp32 -> bf16 (:418)
+            float pj = (float)(exp((double)s[j] - M) * rZ);
             pj = bf16_to_f32(f32_to_bf16(pj));
             pj += __shfl_xor(pj, 1);
             pj += __shfl_xor(pj, 2);
@@ -413,7 +419,7 @@ extern "C" size_t md_snapkv_workspace_bytes(int B, int H, int KH, int ctx_len, i
     const int g = H / KH;
     const size_t L = (size_t)g * window;
     const size_t nch = (ctx_len + kChunkCols - 1) / kChunkCols;
-    const size_t partials = align_up((size_t)B * KH * L * nch * 2 * 4, 256);
+    const size_t partials = align_up((size_t)B * KH * L * nch * 2 * 8, 256);
     const size_t aws = align_up((size_t)B * H * (ctx_len - window) * 2, 256);
     const size_t scores = align_up((size_t)B * KH * (ctx_len - window) * 2, 256);
     return partials + aws + scores + 256;
@@ -424,7 +430,7 @@ extern "C" size_t md_snapkv_scores_offset(int B, int H, int KH, int ctx_len, int
     const int g = H / KH;
     const size_t L = (size_t)g * window;
     const size_t nch = (ctx_len + kChunkCols - 1) / kChunkCols;
-    return align_up((size_t)B * KH * L * nch * 2 * 4, 256) + align_up((size_t)B * H * (ctx_len - window) * 2, 256);
+    return align_up((size_t)B * KH * L * nch * 2 * 8, 256) + align_up((size_t)B * H * (ctx_len - window) * 2, 256);
 }
 
 extern "C" int md_snapkv_select(const void* q_win, const void* cache, const int32_t* page_indices,
@@ -478,14 +484,14 @@ extern "C" int md_snapkv_select(const void* q_win, const void* cache, const int3
     p.slot_stride = KH * D;
     p.page_stride = 2 * (int64_t)page_size * KH * D;
     unsigned char* ws = (unsigned char*)workspace;
-    p.partials = (float*)ws;
-    const size_t partials_b = align_up((size_t)B * KH * L * p.nch * 2 * 4, 256);
+    p.partials = (double*)ws;
+    const size_t partials_b = align_up((size_t)B * KH * L * p.nch * 2 * 8, 256);
     p.aws = (unsigned short*)(ws + partials_b);
     const size_t aws_b = align_up((size_t)B * H * N * 2, 256);
     unsigned short* scores = (unsigned short*)(ws + partials_b + aws_b);
 
-    const size_t lds1 = (size_t)4 * L * 2 * 4;
-    const size_t lds2 = (size_t)L * 2 * 4 + (size_t)4 * g * 16 * 4;
+    const size_t lds1 = (size_t)4 * L * 2 * 8;
+    const size_t lds2 = (size_t)L * 2 * 8 + (size_t)4 * g * 16 * 4;
 #define MD_SNAP_LAUNCH(DD, FP)                                                                                   \
     do {                                                                                                         \
         hipLaunchKernelGGL((snapkv_stats_kernel<DD, FP>), dim3(p.nch, KH, B), dim3(256), lds1, st, p);            \

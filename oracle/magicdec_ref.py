@@ -191,9 +191,15 @@ def snapkv_scores(q_win, k_ctx, g, window, kernel=POOL_KERNEL):
         Q = q_win[:, h * g:(h + 1) * g].permute(1, 0, 2).reshape(L, D).float()   # rows (r,l)  :395
         acc = torch.zeros(g, S - W, dtype=BF16)                       # :409
         for c in range((L + cr - 1) // cr):
-            s = (Q[c * cr:(c + 1) * cr] @ K.T).to(BF16)               # :414 bf16 einsum, UNSCALED
+            if LINEAR_MODE == "fp64":     # correctly rounded scores (yardstick of the summation-order noise)
+                s = (Q[c * cr:(c + 1) * cr].double() @ K.double().T).to(BF16)
+            else:
+                s = (Q[c * cr:(c + 1) * cr] @ K.T).to(BF16)           # :414 bf16 einsum, UNSCALED
             s[-W:, -W:] = (s[-W:, -W:].float() + mask).to(BF16)       # :415 last W rows x last W cols
-            p = torch.softmax(s.float(), dim=-1).to(BF16)             # :416
+            if LINEAR_MODE == "fp64":     # correctly rounded softmax (no dependence on expf / the sum order)
+                p = torch.softmax(s.double(), dim=-1).to(BF16)
+            else:
+                p = torch.softmax(s.float(), dim=-1).to(BF16)         # :416
             gs = p.view(g, 8, S)[:, :, :S - W].float().sum(dim=1).to(BF16)   # :417-418 rows -> (r'=g, l'=8)
             acc = (acc.float() + gs.float()).to(BF16)
         xp = F.pad(acc.float(), (kernel // 2, kernel // 2))           # :421 avg_pool1d, count_include_pad
@@ -417,6 +423,7 @@ class RefEngine:
         assert mode in ("target", "snapkv_self", "snapkv_draft", "stream_draft", "stream_self")
         self.kv_fp8 = kv_fp8
         self.kv_scales = [None] * cfg.n_layer
+        self.kv_scale_override = None     # [(k_scale, v_scale)] per layer: replaces the first-chunk calibration
         self.mode, self.cfg, self.B = mode, cfg, B
         self.model = RefModel(cfg, sd, max_pos=max_pos, group=group, rank=rank, world=world)
         self.budget, self.window = draft_budget, window
@@ -502,7 +509,8 @@ class RefEngine:
         def fn(xn, i):
             q, k, v = m.qkv(xn, i)
             if self.kv_fp8 and caches is self.caches and self.kv_scales[i] is None:
-                self.kv_scales[i] = calibrate_fp8_scales(k, v)
+                self.kv_scales[i] = (self.kv_scale_override[i] if self.kv_scale_override is not None
+                                     else calibrate_fp8_scales(k, v))
             q, k = m.rope(q, k, qo, offsets)
             if self.kv_fp8 and caches is self.caches:
                 ks, vs = self.kv_scales[i]

@@ -4,6 +4,7 @@ Bars (stated per test): bit-exact for integer / byte / index work (KV append, Ro
 accept loop, argmax, top-k given equal scores); bf16-rounding-level tolerance for floating-point kernels
 (attention, norms, SiLU)."""
 import math
+import zlib
 
 import numpy as np
 import pytest
@@ -12,6 +13,8 @@ import torch
 from oracle import flashinfer_ref as fr
 from oracle import magicdec_ref as mr
 from tests import golden_cfg as gc
+from tests.conftest import parity_report
+from tests.parity_util import check_attention, dense_attention_f64
 
 pytestmark = pytest.mark.gpu
 
@@ -28,6 +31,11 @@ def ops():
 
 def bits(t):
     return t.contiguous().view(torch.int16)
+
+
+def case_seed(name):
+    """Fixed per-case seed (crc32 of the case name; independent of PYTHONHASHSEED)."""
+    return zlib.crc32(name.encode()) % 1000
 
 
 def make_paged(B, lens, KH, D, seed, page_size=128, scatter=False, extra_pages=2):
@@ -69,20 +77,19 @@ ATTN_CASES = [
 
 @pytest.mark.parametrize("name,B,n,H,KH,D,lens,causal,scatter", ATTN_CASES, ids=[c[0] for c in ATTN_CASES])
 def test_paged_attention_vs_oracle(ops, name, B, n, H, KH, D, lens, causal, scatter):
-    """fp32-softmax attention, bf16 in/out: |err| <= 2e-2 * max(1, |ref|max)  (bf16 P and output rounding;
-    flashinfer itself is unpinned, see oracle/flashinfer_ref.py)."""
-    cache, indices, indptr, last, max_pages = make_paged(B, lens, KH, D, seed=hash(name) % 1000, scatter=scatter)
+    """fp32-softmax attention, bf16 in/out, against a float64 dense reference on the same inputs: every element within
+    the forward-error bound (u_P + u_O) * sum_i p_i |v_i| of the bf16-P algorithm (tests/parity_util.py); the achieved
+    error (in units of the bound and in bf16 ulps, next to the oracle's) goes to the parity report."""
+    cache, indices, indptr, last, max_pages = make_paged(B, lens, KH, D, seed=case_seed(name), scatter=scatter)
     g = torch.Generator().manual_seed(1)
     q = torch.randn(B * n, H, D, generator=g).to(BF)
     qo = torch.arange(B + 1, dtype=torch.int32) * n
-    ref = fr.batch_prefill_paged(q, cache, qo, indices, indptr, last, H, KH, D, causal=causal).float()
+    oracle = fr.batch_prefill_paged(q, cache, qo, indices, indptr, last, H, KH, D, causal=causal)
+    ref64, bnd = dense_attention_f64(q, cache, qo, indices, indptr, last, H, KH, D, causal=causal)
     ws = ops.AttnWorkspace(DEV)
     out = ops.paged_attention(q.to(DEV), cache.to(DEV), qo.to(DEV), indices.to(DEV), indptr.to(DEV), last.to(DEV), n,
                               max_pages, ws, causal=causal)
-    o = out.float().cpu()
-    assert not torch.isnan(o).any()
-    tol = 2e-2 * max(1.0, ref.abs().max().item())
-    assert (o - ref).abs().max().item() <= tol
+    check_attention(name, out, oracle, ref64, bnd)
 
 
 @pytest.mark.parametrize("name,H,KH,D,ns,lens,fp8", [
@@ -111,15 +118,14 @@ def test_paged_attention_ragged_query_counts(ops, name, H, KH, D, ns, lens, fp8)
         c8[:, 0] = fr.quantize_fp8(cache[:, 0].reshape(-1, KH, D), ks).view(P, ps, KH, D)
         c8[:, 1] = fr.quantize_fp8(cache[:, 1].reshape(-1, KH, D), vs).view(P, ps, KH, D)
         ref_cache, dev_cache, scales = fr.dequantize_cache_fp8(c8, ks, vs), c8.to(DEV), (ks.to(DEV), vs.to(DEV))
-    ref = fr.batch_prefill_paged(q, ref_cache, qo, indices, indptr, last, H, KH, D, causal=True).float()
+    oracle = fr.batch_prefill_paged(q, ref_cache, qo, indices, indptr, last, H, KH, D, causal=True)
+    ref64, bnd = dense_attention_f64(q, ref_cache, qo, indices, indptr, last, H, KH, D, causal=True)
     ws = ops.AttnWorkspace(DEV)
     out = torch.full((tot + 2, H, D), 7.0, dtype=BF, device=DEV)          # 2 guard rows
     ops.paged_attention(q.to(DEV), dev_cache, qo.to(DEV), indices.to(DEV), indptr.to(DEV), last.to(DEV), max(ns),
                         max_pages, ws, causal=True, out=out[:tot], kv_scales=scales)
-    o = out.float().cpu()
-    assert (o[tot:] == 7.0).all(), "wrote past the last query row"
-    tol = 2e-2 * max(1.0, ref.abs().max().item())
-    assert not torch.isnan(o).any() and (o[:tot] - ref).abs().max().item() <= tol
+    assert (out[tot:].float() == 7.0).all(), "wrote past the last query row"
+    check_attention(name, out[:tot], oracle, ref64, bnd)
 
 
 def test_paged_attention_ignores_garbage_beyond_length(ops):
@@ -130,7 +136,7 @@ def test_paged_attention_ignores_garbage_beyond_length(ops):
     for b, ln in enumerate([200, 130]):
         pg = int(indices[int(indptr[b]) + ln // 128])
         dirty[pg, :, ln % 128:] = float("nan")
-    q = torch.randn(B * n, H, D).to(BF)
+    q = torch.randn(B * n, H, D, generator=torch.Generator().manual_seed(7)).to(BF)
     qo = torch.arange(B + 1, dtype=torch.int32) * n
     ws = ops.AttnWorkspace(DEV)
     a = ops.paged_attention(q.to(DEV), cache.to(DEV), qo.to(DEV), indices.to(DEV), indptr.to(DEV), last.to(DEV), n,
@@ -158,19 +164,23 @@ def test_verify_attention_full_size_properties(ops):
     ones = cache.clone()
     ones[:, 1] = 1.0
     o1 = ops.paged_attention(q, ones, qo, indices, indptr, last, n, mp, ws)
-    assert (o1.float() - 1.0).abs().max().item() <= 1e-2
+    e1 = (o1.float() - 1.0).abs().max().item()
+    parity_report(f"[attn] full-size B=64 S=16K: V==1 -> max |o-1| = {e1:.3e} (bound (u_P+u_O)*1 = {2 ** -8:.3e})")
+    assert e1 <= 1.05 * 2 ** -8
     v2 = cache.clone()
     v2[:, 1] = (cache[:, 1].float() * 0.5).to(BF)
     oa = ops.paged_attention(q, cache, qo, indices, indptr, last, n, mp, ws).float()
     ob = ops.paged_attention(q, v2, qo, indices, indptr, last, n, mp, ws).float()
-    assert (oa * 0.5 - ob).abs().max().item() <= 4e-3 * max(1.0, oa.abs().max().item())
+    # halving V is an exact bf16 scaling: every product, partial sum and rounding scales with it -> bit-exact
+    assert torch.equal(oa * 0.5, ob), (oa * 0.5 - ob).abs().max().item()
     # request 5 alone against the CPU oracle
     b = 5
     sub = cache[b * mp:(b + 1) * mp].cpu()
-    ref = fr.batch_prefill_paged(q[b * n:(b + 1) * n].cpu(), sub, torch.tensor([0, n], dtype=torch.int32),
-                                 torch.arange(mp, dtype=torch.int32), torch.tensor([0, mp], dtype=torch.int32),
-                                 last[b:b + 1].cpu(), H, KH, D).float()
-    assert (oa[b * n:(b + 1) * n].cpu() - ref).abs().max().item() <= 2e-2 * max(1.0, ref.abs().max().item())
+    args = (q[b * n:(b + 1) * n].cpu(), sub, torch.tensor([0, n], dtype=torch.int32),
+            torch.arange(mp, dtype=torch.int32), torch.tensor([0, mp], dtype=torch.int32), last[b:b + 1].cpu(), H, KH, D)
+    oracle = fr.batch_prefill_paged(*args)
+    ref64, bnd = dense_attention_f64(*args)
+    check_attention("verify-full-size B=64 S=16K (req 5)", oa[b * n:(b + 1) * n].to(BF), oracle, ref64, bnd)
 
 
 # ----------------------------------------------------------------------------------------- rope / append
@@ -357,12 +367,34 @@ def test_streaming_shift_and_rotate_match_reference_cache_bytes(ops, golden_dir)
 
 
 # ----------------------------------------------------------------------------------------- SnapKV select
+def _snapkv_alt_oracle(q, k, v, g, W, budget):
+    """The oracle with correctly rounded (float64-accumulated) QK^T scores: a second valid implementation of the
+    reference's arithmetic with another summation order.  Returns (scores [B,KH,S-W] bf16, idx [B,KH,topk])."""
+    old = mr.LINEAR_MODE
+    mr.LINEAR_MODE = "fp64"
+    try:
+        sc, idx = [], []
+        for b in range(q.shape[0] // W):
+            i, _, _, s_ = mr.snapkv_select(q[b * W:(b + 1) * W], k[b], v[b], g, W, budget)
+            sc.append(s_)
+            idx.append(i)
+    finally:
+        mr.LINEAR_MODE = old
+    return torch.stack(sc), torch.stack(idx)
+
+
 @pytest.mark.parametrize("tag", ["g4", "g5", "g8", "g4d128"])
 def test_snapkv_select_vs_reference_fixture(ops, tag, golden_dir):
-    """Scores: equal to the reference's bf16 scores except isolated 1-ulp flips (MFMA vs CPU fp32 summation order
-    and exp implementation) -- asserted <= 2 ulp and >= 99% exactly equal.  Indices: descending-score order with
-    lowest-index tie-break; the selected set equals the reference's except positions whose score is within
-    2 ulp of the threshold (score ties are implementation-defined in torch.topk)."""
+    """Against the reference's own gen_draft_kv output (fixture).  The index work is exact GIVEN the scores (stable
+    descending top-k, lowest index among equals; gathered rows bit-equal).  The bf16 scores themselves depend on the
+    fp32 summation order inside QK^T (oneDNN's on the reference's CPU run, the MFMA's here): a product that lands on
+    a bf16 rounding boundary flips one ulp and the flip propagates through softmax / pooling.  That noise is
+    MEASURED, not assumed: the oracle re-run with correctly rounded (float64) QK^T is a second valid implementation,
+    and the HIP kernel must sit no further from the reference than twice that yardstick --
+      * fraction of pooled scores differing from the reference:  hip <= 2 * alt + 0.2 %,  never more than 2 ulp;
+      * selected-index set per (request, kv head): |hip ^ ref| <= 2 * max|alt ^ ref| + 2, and every differing
+        position's reference score lies within 2 ulp of the reference's selection threshold.
+    All counts go to the parity report."""
     z = np.load(f"{golden_dir}/snapkv_select.npz")
     g, KH, D, S, budget, B, W = [int(x) for x in z[f"{tag}_meta"]]
     H = g * KH
@@ -389,10 +421,13 @@ def test_snapkv_select_vs_reference_fixture(ops, tag, golden_dir):
                                 torch.ones(B, dtype=torch.int32, device=DEV), ws, return_scores=True)
     idx, sc = idx.cpu().long(), sc.cpu()
     topk = budget - W
-    exact = (bits(sc) == bits(ref_scores)).float().mean().item()
-    assert exact >= 0.99, exact
+    alt_sc, alt_idx = _snapkv_alt_oracle(q, k, v, g, W, budget)
+    mism_hip = 1.0 - (bits(sc) == bits(ref_scores)).float().mean().item()
+    mism_alt = 1.0 - (bits(alt_sc) == bits(ref_scores)).float().mean().item()
     assert _ulp_close(sc, ref_scores, ulps=2)
+    assert mism_hip <= 2 * mism_alt + 2e-3, (mism_hip, mism_alt)
     dk = dcache.cpu()
+    nd_hip, nd_alt = [], []
     for b in range(B):
         for h in range(KH):
             s = sc[b, h].float()
@@ -400,6 +435,8 @@ def test_snapkv_select_vs_reference_fixture(ops, tag, golden_dir):
             assert torch.equal(mine, torch.sort(s, descending=True, stable=True).indices[:topk]), "order / tie-break"
             theirs = set(ref_idx[b, h].tolist())
             diff = set(mine.tolist()) ^ theirs
+            nd_hip.append(len(diff))
+            nd_alt.append(len(set(alt_idx[b, h].tolist()) ^ theirs))
             thr = ref_scores[b, h].float()[ref_idx[b, h]].min()
             for p in diff:
                 assert abs(ref_scores[b, h, p].float() - thr) <= 2 * thr * 2 ** -8 + 1e-30, (b, h, p)
@@ -410,6 +447,10 @@ def test_snapkv_select_vs_reference_fixture(ops, tag, golden_dir):
             assert torch.equal(bits(rows_v[:topk]), bits(v[b][mine, h]))
             assert torch.equal(bits(rows_k[topk:]), bits(k[b][S - W:, h]))
             assert torch.equal(bits(rows_v[topk:]), bits(v[b][S - W:, h]))
+    parity_report(f"[snapkv] {tag:7s} scores != reference: hip {100 * mism_hip:.3f}%  fp64-oracle {100 * mism_alt:.3f}%"
+                  f"  | index-set symmetric difference per (b,kvh) of top-{topk}: hip max {max(nd_hip)} "
+                  f"sum {sum(nd_hip)}  fp64-oracle max {max(nd_alt)} sum {sum(nd_alt)}  ({B * KH} sets)")
+    assert max(nd_hip) <= 2 * max(nd_alt) + 2, (nd_hip, nd_alt)
 
 
 def test_snapkv_select_full_size_properties(ops):
