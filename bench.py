@@ -78,6 +78,11 @@ def parse():
                     help="full-context KV cache storage (fp8 = OCP e4m3fn, BASELINE configs[4]; default bf16 = the "
                          "reference's)")
     ap.add_argument("--draft-tp", type=int, default=4, help="size of the draft sub-group (reference README: 4 of 8)")
+    ap.add_argument("--pmc", dest="pmc", action="store_true", default=None,
+                    help="measure roofline.traffic live: two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of the "
+                         "verify-attention launch at this run's shard shape in a subprocess (tools/attn_bench.py); "
+                         "default: on for the cfg* workloads on rank 0")
+    ap.add_argument("--no-pmc", dest="pmc", action="store_false")
     return ap.parse_args()
 
 
@@ -322,6 +327,16 @@ def run(args, dev):
     n_attn = len(timer.pairs)
     dt_meas, tok_meas = run_spec(min(args.warmup, 2), max(args.steps // 4, 4), None)
     meas_steps = max(args.steps // 4, 4)
+    # sensitivity of the headline to the assumed acceptance rate: the same loop replayed at other alphas (short runs)
+    sens_steps = max(min(args.steps, 12), 4)
+    sens_raw = {}
+    for al in ((0.5, 0.6, 0.7, 0.8, 0.9) if on_gpu else (args.alpha,)):
+        if abs(al - args.alpha) < 1e-9:
+            sens_raw[al] = (dt_replay / args.steps, tok_replay / args.steps)
+            continue
+        f_al = truncated_geometric(al, G, (2 + sens_steps, B), gen, dev)
+        dt_al, tok_al = run_spec(2, sens_steps, f_al)
+        sens_raw[al] = (dt_al / sens_steps, tok_al / sens_steps)
 
     # ---- autoregressive baseline (tests/baseline_benchmark.py loop: one token per target step)
     target_step = engine.verify if selfspec else engine.inference
@@ -345,6 +360,7 @@ def run(args, dev):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
     dt_replay, dt_meas, dt_base = allmax(dt_replay), allmax(dt_meas), allmax(dt_base)
+    sens_raw = {al: (allmax(dt), tok) for al, (dt, tok) in sens_raw.items()}
 
     value = tok_replay / dt_replay
     base_tps = B * base_steps / dt_base
@@ -355,13 +371,10 @@ def run(args, dev):
     attn_bytes = B * L_kv * KH_loc * D * 2 * kv_elem + 2 * B * (G + 1) * H_loc * D * 2
     achieved = attn_bytes / (attn_ms * 1e-3) / 1e9 if attn_ms > 0 else 0.0
 
-    traffic = None
-    pmc_path = os.path.join(ROOT, "profiles", "r01_verify_attn_pmc.json")
-    if args.workload == "cfg3" and not use_tp and args.kv_dtype == "bf16" and os.path.exists(pmc_path):
-        # HBM bytes per launch from the committed rocprofv3 PMC passes of this kernel at this layer shape
-        # (FETCH_SIZE x2 + WRITE_SIZE, see the file); PMC collection cannot run inside bench.py itself
-        with open(pmc_path) as f:
-            traffic = json.load(f)["traffic_bytes_per_launch"]
+    traffic, traffic_source = None, None
+    want_pmc = args.pmc if getattr(args, "pmc", None) is not None else args.workload.startswith("cfg")
+    if want_pmc and on_gpu and rank == 0:
+        traffic, traffic_source = measure_traffic(B, S + 40 + G + 1, KH_loc, H_loc, D, G + 1, args.kv_dtype == "fp8")
     ar_timeouts = None
     if use_tp:
         ars = [m._oneshot for m in ([engine.model] + ([draft.model] if draft is not None else []))
@@ -386,6 +399,10 @@ def run(args, dev):
                                  "oneshot-ipc" if getattr(engine.model, "_oneshot", None) is not None else "rccl"),
                    "allreduce_timeouts": ar_timeouts},
         "speedup_vs_autoregressive": round(value / base_tps, 4),
+        "alpha_sensitivity": {f"{al:.1f}": {"tokens_per_s": round(tok / dt, 1), "speedup": round(tok / dt / base_tps, 3),
+                                            "tokens_per_iter_per_seq": round(tok / B, 3),
+                                            "ms_per_step": round(dt * 1e3, 3)}
+                              for al, (dt, tok) in sorted(sens_raw.items())},
         "autoregressive_tokens_per_s": round(base_tps, 2),
         "autoregressive_ms_per_step": round(dt_base / base_steps * 1e3, 4),
         "measured_acceptance_run": {"tokens_per_s": round(tok_meas / dt_meas, 2),
@@ -396,7 +413,7 @@ def run(args, dev):
                                f"{'true' if args.kv_dtype == 'fp8' else 'false'}> (verify attention, md_paged_attn)",
                      "bound": "hbm",
                      "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
                      "bytes_per_launch": attn_bytes, "avg_launch_ms": round(attn_ms, 4), "launches_timed": n_attn},
     }
     if rank == 0 and not args.no_cpu_baseline and world == 1 and not selfspec:
@@ -407,66 +424,152 @@ def run(args, dev):
     return line if rank == 0 else None
 
 
-def cpu_baseline(tgt_name, drf_name, S, budget, gamma, alpha):
-    """The oracle (oracle/magicdec_ref.py, a CPU port of the reference path) timed on this host's cores on a
-    bounded sample: ONE decoder layer of each model at the real shapes, B=1, the real prefix length with the KV
-    pre-filled with random values; one speculative iteration = gamma draft steps + one verify.  The per-layer
-    times are scaled to the full depth (32 / 16 layers) -- layer cost is depth-independent -- and to tokens/s
-    with the same replayed acceptance.  A reported baseline, not an optimisation target."""
+def measure_traffic(B, L_kv, KH, H, D, n, fp8):
+    """roofline.traffic measured in THIS invocation: two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE -- they do not
+    fit one pass on gfx950; --kernel-trace only, no other trace domain) over tools/attn_bench.py, which launches
+    md_paged_attn at exactly this run's per-layer shard shape on > 256 MiB of KV per launch (Infinity-Cache cold).
+    Corrections per MI355X_MICROARCH.md (HBM section): both counters are in KiB; on gfx950 FETCH_SIZE tallies 64 B
+    per 128-B request for wide coalesced streaming reads, so read bytes = FETCH_SIZE * 1024 * 2.  The split-KV merge
+    kernel's bytes (when it runs) are added.  Returns (bytes per launch | None, provenance string)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    if shutil.which("rocprofv3") is None:
+        return None, "rocprofv3 not on PATH"
+    res = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="md_pmc_", dir="/tmp")
+        cmd = ["timeout", "150", "rocprofv3", "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d,
+               "-o", "pmc", "--", sys.executable, os.path.join(ROOT, "tools", "attn_bench.py"), "--iters", "4",
+               "--B", str(B), "--S", str(L_kv), "--KH", str(KH), "--H", str(H), "--D", str(D), "--n", str(n),
+               "--fp8", "1" if fp8 else "0"]
+        env = {k: v for k, v in os.environ.items()
+               if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+        env["TMPDIR"] = "/tmp"
+        try:
+            subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=200)
+        except (subprocess.TimeoutExpired, OSError) as e:
+            return None, f"rocprofv3 --pmc {counter} failed: {type(e).__name__}"
+        files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+        if not files:
+            return None, f"rocprofv3 --pmc {counter}: no counter_collection.csv"
+        per_kernel = {}
+        with open(files[0]) as f:
+            for r in csv.DictReader(f):
+                if r.get("Counter_Name") == counter and ("paged_attn_kernel" in r["Kernel_Name"]
+                                                         or "attn_merge" in r["Kernel_Name"]):
+                    key = "merge" if "attn_merge" in r["Kernel_Name"] else "attn"
+                    per_kernel.setdefault(key, []).append(float(r["Counter_Value"]))
+        shutil.rmtree(d, ignore_errors=True)
+        if "attn" not in per_kernel:
+            return None, f"rocprofv3 --pmc {counter}: no md_paged_attn dispatch in the trace"
+        res[counter] = sum(sum(v) / len(v) for v in per_kernel.values())
+        res[counter + "_n"] = len(per_kernel["attn"])
+    traffic = int(res["FETCH_SIZE"] * 1024 * 2 + res["WRITE_SIZE"] * 1024)
+    return traffic, (f"live: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, --kernel-trace) over "
+                     f"tools/attn_bench.py --B {B} --S {L_kv} --KH {KH} --H {H} --D {D} --n {n} --fp8 {int(fp8)}; mean of "
+                     f"{res['FETCH_SIZE_n']} launches; bytes = FETCH_SIZE KiB * 1024 * 2 (gfx950 wide-read correction) "
+                     f"+ WRITE_SIZE KiB * 1024")
+
+
+def cpu_baseline(tgt_name, drf_name, S, budget, gamma, alpha, Bc=4):
+    """The oracle (oracle/magicdec_ref.py + oracle/flashinfer_ref.py: the torch-eager CPU restatement of the reference
+    path) timed on this host's cores on a bounded sample of the same workload: ONE decoder layer of each model at the
+    real shapes with a batch of `Bc` requests at the real prefix length (KV pre-filled with random values), plus ONE
+    final-norm + lm-head pass and ONE embedding lookup per model, each timed separately.  An iteration is assembled as
+
+        gamma * (n_layer_draft * t_layer_draft + t_head_draft + t_embed_draft)
+              + (n_layer_target * t_layer_target(gamma+1 rows) + t_head_target + t_embed_target)
+
+    (layer cost is depth-independent; embedding and head are counted once per forward, not once per layer), and
+    converted to tokens/s with the same replayed acceptance.  The K1 / K2 / K6 micro-benchmarks of SURVEY.md section
+    8d (verify attention, draft attention, SnapKV select at the per-layer shapes, batch Bc) are reported in GB/s of
+    algorithmic bytes.  A reported baseline, not an optimisation target."""
     import torch
+    import torch.nn.functional as F
     from magicdec_amd.Engine.model_core import ModelArgs
+    from oracle import flashinfer_ref as fr
     from oracle import magicdec_ref as mr
     ncores = os.cpu_count() or 1
     torch.set_num_threads(ncores)
+    t_all = time.perf_counter()
 
-    def one_layer(name, mode, max_len, bud):
+    def best(fn, reps=2):
+        fn()                                   # warm (allocations, oneDNN primitive caches)
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            fn()
+            ts.append(time.perf_counter() - t0)
+        return min(ts)
+
+    def model_of(name):
         a = ModelArgs.from_name(name)
         cfg = mr.RefConfig(n_layer=1, n_head=a.n_head, n_local_heads=a.n_local_heads, dim=a.dim,
                            intermediate_size=a.intermediate_size, vocab_size=a.vocab_size, rope_base=a.rope_base,
                            scaling_factor=a.scaling_factor, low_freq_factor=a.low_freq_factor,
                            high_freq_factor=a.high_freq_factor,
                            original_max_position_embeddings=a.original_max_position_embeddings)
-        sd = mr.init_state_dict(cfg, 1)
-        e = mr.RefEngine(mode, cfg, sd, 1, max_len, bud, max_pos=max_len + 256)
-        return e, a.n_layer
+        return cfg, mr.init_state_dict(cfg, 1), a.n_layer
 
-    t_all = time.perf_counter()
-    tgt, n_t = one_layer(tgt_name, "target", S + 96, 0)
-    npg = S // 128 + 1
-    tgt.caches[0][:npg].normal_()
-    tgt.cachelens.fill_(S)
-    tgt.paged_kv_indptr = torch.tensor([0, npg], dtype=torch.int32)
-    tgt.paged_kv_indices = torch.arange(npg, dtype=torch.int32)
-    tgt.paged_kv_last_page_len = torch.tensor([S - (npg - 1) * 128], dtype=torch.int32)
-    drf, n_d = one_layer(drf_name, "snapkv_draft", S + 96, budget)
-    drf.draft_caches[0].normal_()
-    drf.cachelens.fill_(S)
-    tb = torch.randint(0, 1000, (1, gamma + 1))
-    reps = 2
-    t_d = t_v = 0.0
-    for r in range(reps + 1):
-        t0 = time.perf_counter()
-        for i in range(gamma):
-            drf.inference(tb[:, i:i + 1])
-        t1 = time.perf_counter()
-        tgt.inference(tb)
-        t2 = time.perf_counter()
-        tgt.cachelens -= gamma + 1
-        tgt.paged_kv_last_page_len -= gamma + 1
-        drf.cachelens -= gamma
-        drf.draft_paged_kv_last_page_len -= gamma
-        if r > 0:
-            t_d += t1 - t0
-            t_v += t2 - t1
-    t_d, t_v = t_d / reps, t_v / reps
-    # a 1-layer pass = 1 layer + embedding + lm head; scaling by depth over-counts the head slightly (stated)
-    iter_s = t_d * n_d + t_v * n_t
+    def time_model(name, mode, n_rows, kv_len):
+        """(t_layer, t_head, t_embed, t_attention_only, attention bytes) of one forward with n_rows query rows per
+        request over kv_len cached positions (the appended rows included)."""
+        cfg, sd, n_layer = model_of(name)
+        eng = mr.RefEngine(mode, cfg, sd, Bc, S + 96, budget if mode == "snapkv_draft" else 0, max_pos=S + 256)
+        m = eng.model
+        if mode == "target":
+            caches, prefix = eng.caches, ""
+            npg = (kv_len + 127) // 128
+            eng.paged_kv_indptr = torch.arange(Bc + 1, dtype=torch.int32) * npg
+            eng.paged_kv_indices = torch.cat([torch.arange(b * eng.ppr, b * eng.ppr + npg, dtype=torch.int32)
+                                              for b in range(Bc)])
+            eng.paged_kv_last_page_len = torch.full((Bc,), kv_len - (npg - 1) * 128, dtype=torch.int32)
+        else:
+            caches, prefix = eng.draft_caches, "draft_"
+            eng.draft_paged_kv_last_page_len = torch.full((Bc,), kv_len - (eng.dppr - 1) * 128, dtype=torch.int32)
+        caches[0].normal_()
+        eng.cachelens.fill_(S)
+        tab = eng._tab(prefix)
+        attn_fn = eng._attn_std(n_rows, eng.cachelens, caches, tab)
+        x = torch.randn(Bc, n_rows, cfg.dim).to(torch.bfloat16)
+        ids = torch.randint(0, cfg.vocab_size, (Bc, n_rows))
+        t_layer = best(lambda: m.block(x, 0, attn_fn))
+        t_head = best(lambda: m.head(x))
+        t_embed = best(lambda: F.embedding(ids, sd["tok_embeddings.weight"]))
+        q = torch.randn(Bc * n_rows, cfg.n_head, cfg.head_dim).to(torch.bfloat16)
+        qo = torch.arange(Bc + 1, dtype=torch.int32) * n_rows
+        t_attn = best(lambda: m.attn(q, caches[0], qo, tab))
+        nbytes = (Bc * kv_len * cfg.n_local_heads * cfg.head_dim * 2 * 2
+                  + 2 * Bc * n_rows * cfg.n_head * cfg.head_dim * 2)
+        return t_layer, t_head, t_embed, t_attn, nbytes, n_layer, cfg, eng
+
+    tl_t, th_t, te_t, ta_t, nb_t, n_t, _, _ = time_model(tgt_name, "target", gamma + 1, S + gamma + 1)
+    tl_d, th_d, te_d, ta_d, nb_d, n_d, cfg_d, eng_d = time_model(drf_name, "snapkv_draft", 1, budget + 1)
+    # K6: SnapKV select of ONE request of the draft model over the full prefix (the oracle loops over requests)
+    g = cfg_d.n_head // cfg_d.n_local_heads
+    k_ctx = torch.randn(S, cfg_d.n_local_heads, cfg_d.head_dim).to(torch.bfloat16)
+    v_ctx = torch.randn(S, cfg_d.n_local_heads, cfg_d.head_dim).to(torch.bfloat16)
+    q_win = torch.randn(32, cfg_d.n_head, cfg_d.head_dim).to(torch.bfloat16)
+    t0 = time.perf_counter()
+    mr.snapkv_select(q_win, k_ctx, v_ctx, g, 32, budget)
+    t_k6 = time.perf_counter() - t0
+    nb_k6 = S * cfg_d.n_local_heads * cfg_d.head_dim * 2 + 2 * budget * cfg_d.n_local_heads * cfg_d.head_dim * 2
+
+    iter_s = gamma * (n_d * tl_d + th_d + te_d) + (n_t * tl_t + th_t + te_t)
     e_tok = sum(alpha ** j for j in range(gamma + 1))
-    return {"value": round(e_tok / iter_s, 4), "unit": "tokens/s", "cores": ncores, "kind": "port",
-            "sample": f"oracle (CPU port), 1 of {n_t} target layers + 1 of {n_d} draft layers at real shapes, B=1, "
-                      f"prefix {S}, random KV; iteration = {gamma} draft steps ({t_d * 1e3:.1f} ms/layer-pass) + 1 "
-                      f"verify ({t_v * 1e3:.1f} ms/layer-pass), scaled to full depth, replay alpha={alpha}; "
-                      f"CPU throughput is per-sequence (x1 batch)",
+    return {"value": round(Bc * e_tok / iter_s, 4), "unit": "tokens/s", "cores": ncores, "kind": "port",
+            "sample": f"oracle (torch-eager CPU restatement), batch {Bc}, prefix {S}, random KV: 1 of {n_t} target layers "
+                      f"at {gamma + 1} rows/request ({tl_t * 1e3:.1f} ms) + target head ({th_t * 1e3:.1f} ms) + embedding "
+                      f"({te_t * 1e3:.2f} ms); 1 of {n_d} draft layers at 1 row/request over the {budget}-row SnapKV cache "
+                      f"({tl_d * 1e3:.1f} ms) + draft head ({th_d * 1e3:.1f} ms) + embedding ({te_d * 1e3:.2f} ms); iteration = "
+                      f"{gamma} x ({n_d} x layer + head + embedding) + ({n_t} x layer + head + embedding) = {iter_s:.2f} s; "
+                      f"replay alpha={alpha}; best of 2 after a warm-up call",
+            "micro_GBps": {"K1_verify_attention": round(nb_t / ta_t / 1e9, 2),
+                           "K2_draft_attention": round(nb_d / ta_d / 1e9, 3),
+                           "K6_snapkv_select_one_request": round(nb_k6 / t_k6 / 1e9, 3)},
             "wall_s": round(time.perf_counter() - t_all, 1)}
 
 

@@ -525,7 +525,84 @@ def scen_run(tag):
         raise SystemExit(f"unknown scenario {tag}")
 
 
-SCENARIOS = {"snapkv_select": scen_snapkv_select, "stream_prefill": scen_stream_prefill,
+def scen_mylib_schemas():
+    """The operator schemas the reference registers (the inner boundary): the real back-ends are
+    constructed on CPU, their setup_caches() runs the torch.library.define calls, the registered schemas are read
+    back from the dispatcher.  Engine/utils.py:31-34, Engine/SnapKV/backend.py:56-107, backend_draft.py:42-92,
+    Engine/SnapKV/model.py:134-137, model_draft.py (draft_rope)."""
+    inject_configs()
+    tmp = tempfile.mkdtemp(prefix="md_gold_")
+    ck = write_checkpoints(tmp)
+    B = ref_import.module("Engine.SnapKV.backend")
+    BD = ref_import.module("Engine.SnapKV.backend_draft")
+    e = B.LMBackend(dtype=BF16, device="cpu", dec_len=4)       # the longspec pairing: target + stand-alone draft
+    e.load_model(ck["tinytgt"], use_tp=False)
+    e.setup_caches(max_batch_size=2, max_seq_length=512)
+    d = BD.LMBackend_Draft(dtype=BF16, device="cpu", dec_len=[1], draft_budget=129)
+    d.load_model(ck["tinytgt"], use_tp=False)
+    d.setup_caches(max_batch_size=2, max_seq_length=512, draft_budget=129)
+    out = {}
+    for name in ("update_kv", "rope", "draft_rope", "target_decode", "target_prefill", "draft_decode",
+                 "draft_prefill"):
+        out[name] = str(getattr(torch.ops.mylib, name).default._schema)
+    with open(GOLD / "mylib_schemas.json", "w") as f:
+        json.dump(out, f, indent=1)
+    print(out)
+
+
+def scen_convert_hf():
+    """The REAL reference converter (convert_hf_checkpoint.py:79-163) run on seeded tiny HF-layout checkpoints
+    (tests/hf_fixture.py): a sharded-safetensors Llama-style one and a single-file Qwen-style one with q/k/v biases
+    (:94-99) and a tied lm head (:147-149).  Recorded: key list, shapes, dtypes and sha256 of every tensor of the
+    model.pth it writes."""
+    import importlib.util
+    from tests import hf_fixture
+    inject_configs()
+    tmp = tempfile.mkdtemp(prefix="md_gold_hf_")
+    ref_import.install()
+    spec = importlib.util.spec_from_file_location("ref_convert_hf", os.path.join(ref_import.REFERENCE_ROOT,
+                                                                               "convert_hf_checkpoint.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    out = {}
+    for case, (name, tied, sharded) in hf_fixture.CASES.items():
+        cfg, _, _ = ref_cfg(name)
+        d = hf_fixture.write_hf_checkpoint(tmp, case, cfg)
+        mod.convert_hf_checkpoint(checkpoint_dir=Path(d), model_name=name)
+        sd = torch.load(os.path.join(d, "model.pth"), map_location="cpu", weights_only=True)
+        out[case] = hf_fixture.describe(sd)
+    with open(GOLD / "convert_hf.json", "w") as f:
+        json.dump(out, f, indent=0)
+    print({c: len(v) for c, v in out.items()})
+
+
+def scen_pg19():
+    """The REAL Data/data_converter.py:44-58 (convert_pg19_dataset) run on a seeded synthetic corpus with a
+    deterministic stub tokenizer (tests/pg19_fixture.py), once with and once without a BOS id.  Recorded: shape,
+    sha256 of the int64 tensor, its first row and per-book chunk structure (row count)."""
+    import hashlib
+    from tests import pg19_fixture as pf
+    tmp = tempfile.mkdtemp(prefix="md_gold_pg19_")
+    pf.write_corpus(tmp)
+    dc = ref_import.module("Data.data_converter")
+    out = {}
+    cwd = os.getcwd()
+    os.chdir(tmp)          # the reference reads the relative path "Data/pg19/"
+    try:
+        for tag, bos in (("bos", True), ("no_bos", False)):
+            ds = dc.convert_pg19_dataset(tokenizer=pf.WordTokenizer(bos), seq_len=pf.SEQ_LEN, end=pf.END)
+            t = ds.tensors[0]
+            out[tag] = dict(shape=list(t.shape), dtype=str(t.dtype),
+                            sha256=hashlib.sha256(t.contiguous().numpy().tobytes()).hexdigest(),
+                            first_row=t[0].tolist(), col0=sorted(set(t[:, 0].tolist())))
+    finally:
+        os.chdir(cwd)
+    with open(GOLD / "pg19.json", "w") as f:
+        json.dump(out, f)
+    print({k: v["shape"] for k, v in out.items()})
+
+
+SCENARIOS = {"pg19": scen_pg19, "convert_hf": scen_convert_hf, "mylib_schemas": scen_mylib_schemas, "snapkv_select": scen_snapkv_select, "stream_prefill": scen_stream_prefill,
              "accept_loop": scen_accept_loop, "tp_shapes": scen_tp_shapes}
 RUNS = ["run_longspec_snapkv", "run_longspec_snapkv_rej", "run_longspec_stream", "run_selfspec_snapkv",
         "run_selfspec_stream", "run_baseline", "run_longspec_stream_tp2", "run_longspec_snapkv_tp2",

@@ -489,6 +489,49 @@ def test_hf_checkpoint_conversion_roundtrip():
         assert torch.equal(out[k], sd[k]), k
 
 
+@pytest.mark.parametrize("case", ["llama_sharded", "qwen_bias_tied_single"])
+def test_hf_checkpoint_conversion_equals_the_reference_converter(case):
+    """Our converter against what the REFERENCE's convert_hf_checkpoint.py:79-163 wrote for the same seeded HF-layout
+    checkpoint (fixture tests/golden/convert_hf.json, generated by oracle/gen_golden.py:scen_convert_hf running the
+    real converter): same key set, shapes, dtypes, and every tensor byte-identical (sha256) -- sharded safetensors +
+    index for the Llama-style case; q/k/v biases (:94-99) and a tied lm head (:147-149) for the Qwen-style one."""
+    from magicdec_amd.Engine import model_core
+    from magicdec_amd.convert_hf_checkpoint import convert_hf_checkpoint
+    from tests import hf_fixture
+    name, tied, sharded = hf_fixture.CASES[case]
+    cfg, _ = gc.tiny(name)
+    model_core.transformer_configs[name] = gc.config_kwargs(cfg)
+    d = hf_fixture.write_hf_checkpoint(tempfile.mkdtemp(prefix="md_hf_"), case, cfg)
+    got = hf_fixture.describe(torch.load(convert_hf_checkpoint(Path(d), model_name=name), weights_only=True))
+    want = gc.load_json("convert_hf.json")[case]
+    assert set(got) == set(want)
+    for k in want:
+        assert got[k] == want[k], k
+
+
+@pytest.mark.parametrize("tag,bos", [("bos", True), ("no_bos", False)])
+def test_pg19_adapter_equals_the_reference(tag, bos):
+    """magicdec_amd.data.tokenize_pg19 against the tensor the REFERENCE's Data/data_converter.py:44-58 produced for the
+    same seeded corpus and stub tokenizer (fixture tests/golden/pg19.json, oracle/gen_golden.py:scen_pg19): 50 of the
+    52 books, 8000-token skip, last chunk of every book dropped (also when full), BOS (or EOS) in column 0,
+    repeat(end): bit-identical int64 tensor (sha256)."""
+    import hashlib
+    from magicdec_amd.data import convert_pg19_dataset, tokenize_pg19
+    from tests import pg19_fixture as pf
+    root = tempfile.mkdtemp(prefix="md_pg19_")
+    d = pf.write_corpus(root)
+    t = tokenize_pg19(pf.WordTokenizer(bos), seq_len=pf.SEQ_LEN, end=pf.END, data_dir=d + "/")
+    want = gc.load_json("pg19.json")[tag]
+    assert list(t.shape) == want["shape"] and str(t.dtype) == want["dtype"]
+    assert t[0].tolist() == want["first_row"] and sorted(set(t[:, 0].tolist())) == want["col0"]
+    assert hashlib.sha256(t.contiguous().numpy().tobytes()).hexdigest() == want["sha256"]
+    # the dataset entry point picks the corpus up when it is there, and says so when it is not
+    ds = convert_pg19_dataset(tokenizer=pf.WordTokenizer(bos), seq_len=pf.SEQ_LEN, end=pf.END, data_dir=d + "/")
+    assert torch.equal(ds.tensors[0], t)
+    with pytest.raises(IndexError):
+        tokenize_pg19(pf.WordTokenizer(bos), seq_len=pf.SEQ_LEN, end=1, data_dir=d + "/", n_books=60)
+
+
 def test_fp8_kv_cache_host_logic(cpu_ops_patched, ckpt_dir):
     """kv_dtype="fp8" (BASELINE configs[4], not in the reference): the full cache is e4m3fn, scales are calibrated on
     the first prefill chunk, the compressed draft cache stays bf16, and teacher-forced logits stay close to the
