@@ -349,7 +349,8 @@ def test_cfg4_layout_lockstep_70b_target_with_different_streaming_draft():
     """BASELINE.json configs[3] in miniature on the GPU: a Llama-3.1-70B-like target (g = 8 -> two MFMA M tiles in the
     verify kernel) with a DIFFERENT, smaller StreamingLLM draft model (the layout of the reference-generated fixture
     run_longspec_stream_70b, tests/StreamingLLM/longspec_benchmark.py:241-278): the draft disagrees with the target
-    on most steps, so the rejection / cachelen_update (two-token step) / rollback paths run on every iteration."""
+    on most steps, so the rejection / rollback paths run on every iteration (the all-accept two-token step is
+    covered by the same-model longspec tests above)."""
     from magicdec_amd.Engine import model_core
     from magicdec_amd.Engine.SnapKV.backend import LMBackend
     from magicdec_amd.Engine.StreamingLLM.backend_draft import LMBackend_Draft
