@@ -202,6 +202,30 @@ int md_silu_mul(const void* a, const void* b, int64_t a_row_stride, int64_t b_ro
                 int rows, int dim, md_stream_t stream);
 
 /* ------------------------------------------------------------------------
+ * K8  the decode / verify linears: out[M][N] = x[M][K] . W[N][K]^T  (+ epilogue), M <= 256
+ *     reference: nn.Linear calls of a decode step -- Attention.wqkv / wo, FeedForward.w1 / w3 / w2, Transformer.output
+ *     (Engine/SnapKV/model.py:288-289,446-455,175-177) and WeightOnlyInt8Linear.forward (Engine/quantize.py:84-86)
+ * Weight-streaming skinny GEMM (csrc/gemm.hip): W rows go global -> registers in MFMA operand layout, activations
+ * through LDS, fp32 accumulation, split-K with a fixed-order combine (deterministic).
+ *   w_dtype  MD_W_BF16: w is bf16 [N][K];  MD_W_INT8: w is int8 [N][K] with bf16 per-row `scales` [N]
+ *            (out = bf16(bf16(x.w^T) * scale), the reference's rounding points)
+ *   epilogue MD_EPI_NONE: out[M][N] = bf16(acc + bias)   (bias bf16 [N] or NULL)
+ *            MD_EPI_SWIGLU: w = [w1; w3] (N = 2*I rows): out[M][I] = bf16(bf16(silu(bf16(h1))) * bf16(h3))
+ *   x row stride ldx, out row stride ldo (elements).  workspace: md_linear_workspace_bytes() bytes (16-B aligned).
+ * md_linear_supported() == 0 -> use a library GEMM (M > 256, K % 128 != 0, ...).
+ * ---------------------------------------------------------------------- */
+#define MD_W_BF16 0
+#define MD_W_INT8 1
+#define MD_EPI_NONE 0
+#define MD_EPI_SWIGLU 1
+int md_linear_supported(int M, int N, int K, int epilogue);
+size_t md_linear_workspace_bytes(int M, int N, int K, int epilogue);
+void md_debug_set_gemm_target_blocks(int n); /* development: split-K policy (workgroups to aim for) */
+int md_linear(const void* x, int64_t ldx, const void* w, int w_dtype, const void* scales, const void* bias,
+              void* out, int64_t ldo, int M, int N, int K, int epilogue, void* workspace,
+              size_t workspace_bytes, md_stream_t stream);
+
+/* ------------------------------------------------------------------------
  * K10  argmax over a vocab shard / TP merge
  *     reference: Engine/SnapKV/model.py:175-188
  * argmax: per row, max bf16 logit and its lowest index (+index_offset).

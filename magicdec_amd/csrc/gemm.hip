@@ -1,0 +1,356 @@
+// Skinny GEMM for the decode / verify linears of the draft/verify loop (gfx950):  out[M][N] = x[M][K] . W[N][K]^T
+//
+// replaces: the nn.Linear calls of Attention / FeedForward / the lm head in a decode step
+//           (Engine/SnapKV/model.py:288-289,446-455: wqkv, wo, w1|w3, w2, output), M = batch x rows-per-request <= 256.
+//
+// Why not a library GEMM: at M <= 256 these products are WEIGHT-STREAMING problems (the activations are a few hundred
+// KB, the weights 10..500 MB per call and read exactly once), and for the narrow projections (N = 2048..6144) a
+// tile-per-workgroup GEMM has too few workgroups to pull HBM bandwidth (hipBLASLt: 1.0-1.4 TB/s on the 8B qkv / wo at
+// M = 256, profiles/r01_bench_cfg3_iter_breakdown.csv).  This kernel is organised like the verify-attention kernel
+// instead -- W plays the role of K/V:
+//   * a wavefront owns 32 output columns (32 rows of W) and a K range; it streams those rows STRAIGHT from global
+//     memory into registers in the MFMA B-operand layout (lane (j, kh) loads the 16 B  W[n0+j][k + kh*8 .. +8]; the
+//     next instruction takes the next 32 B of the same rows, so every 128-B line is consumed by four consecutive
+//     instructions) with a rolling prefetch ring of RD k-steps -- no LDS round trip and no barrier for W;
+//   * the activations go through LDS once per 128-deep slab (double-buffered, one barrier per slab) and are shared
+//     by the workgroup's 4 wavefronts (4 x 32 = 128 output columns), read as MFMA A fragments with conflict-free
+//     ds_read_b128 (row pitch 272 B);
+//   * v_mfma_f32_32x32x16_bf16, fp32 accumulators: M <= 32*MT rows, MT in {1,2,4,8};
+//   * split-K across workgroups (grid.y) so that even N = 2048 yields >= 256 workgroups; partial sums are written as
+//     fp32 and combined IN A FIXED ORDER by a small second kernel (deterministic: graph replays, eager runs and TP
+//     ranks see the same bits), which also applies the epilogue; with one K slice the epilogue runs in the main kernel.
+// Epilogues: bias add (Qwen wqkv), SwiGLU (w1|w3: a wavefront takes 16 rows of w1 and the matching 16 rows of w3 as
+// its 32 columns, so silu(h1)*h3 needs one cross-lane move; rounding points of the reference: h1, h3 -> bf16,
+// silu -> bf16, product -> bf16), weight-only int8 (Engine/quantize.py:72-86: bf16(acc) * bf16 scale -> bf16).
+#include "md_common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kSlabK = 128;                 // k depth of one LDS activation slab
+constexpr int kStepsPerSlab = kSlabK / 16;  // 8 MFMA k-steps (32x32x16) per slab
+constexpr int kPitch = kSlabK * 2 + 16;     // LDS row pitch in bytes (272: rows start 4 banks apart)
+
+enum { EPI_NONE = 0, EPI_SWIGLU = 1 };
+
+struct GemmParams {
+    const bf16_t* x;      // [M][K], row stride ldx (elements)
+    const void* w;        // [N][K] row-major bf16 (or int8 when W8), N = GEMM columns (2*I for SwiGLU: [w1; w3])
+    const bf16_t* bias;   // [N] or null
+    const bf16_t* scales; // [N] bf16 per-output-channel scales (int8 weights) or null
+    bf16_t* out;          // [M][Nout], row stride ldo
+    float* partial;       // [S][M][N] fp32 when S > 1
+    int64_t ldx, ldo;
+    int M, N, K, kblk, S, Nout;
+};
+
+__device__ __forceinline__ bf16x8 ld_frag(const bf16_t* p) { return *reinterpret_cast<const bf16x8*>(p); }
+
+// 8 int8 -> 8 bf16 (exact)
+__device__ __forceinline__ bf16x8 cvt_i8x8(const u32x2 v) {
+    bf16x8 r;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int b = (int)(signed char)((v[h] >> (8 * e)) & 0xffu);
+            r[h * 4 + e] = f32_to_bf16((float)b);
+        }
+    }
+    return r;
+}
+
+template <bool W8>
+__device__ __forceinline__ bf16x8 ld_w(const void* base, int64_t elem_off) {
+    if constexpr (W8) {
+        const u32x2 v = __builtin_nontemporal_load(
+            reinterpret_cast<const u32x2*>(reinterpret_cast<const signed char*>(base) + elem_off));
+        return cvt_i8x8(v);
+    } else {
+        const u32x4 v = __builtin_nontemporal_load(
+            reinterpret_cast<const u32x4*>(reinterpret_cast<const bf16_t*>(base) + elem_off));
+        return *reinterpret_cast<const bf16x8*>(&v);
+    }
+}
+
+__device__ __forceinline__ float silu_bf16(float h1) {
+    // F.silu on a bf16 tensor: computed in fp32, rounded to bf16 (x * sigmoid(x))
+    return bf16_to_f32(f32_to_bf16(h1 / (1.0f + __expf(-h1))));
+}
+
+// One workgroup: 4 wavefronts x 32 GEMM columns, rows [0, M), k in [blockIdx.y*kblk, +kblk).
+template <int MT, int EPI, bool W8, int RD>
+__global__ __launch_bounds__(256) void skinny_gemm_kernel(const GemmParams p) {
+    constexpr int MP = MT * 32;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];   // 2 x [MP][kPitch]
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 31, kh = lane >> 5;
+    const int k_beg = blockIdx.y * p.kblk;
+    const int nslab = p.kblk / kSlabK;
+
+    // ---- this lane's W row (GEMM column).  SwiGLU: the wave's 32 columns are 16 rows of w1 and the same 16 of w3.
+    int col;            // GEMM column index in [0, N)
+    int out_col = -1;   // output column this lane is responsible for (epilogue), -1: none
+    if constexpr (EPI == EPI_SWIGLU) {
+        const int I = p.N >> 1;
+        const int i = (blockIdx.x * 4 + wave) * 16 + (j & 15);
+        col = (j < 16 ? 0 : I) + (i < I ? i : I - 1);
+        if (j < 16 && i < I) out_col = i;
+    } else {
+        const int n = (blockIdx.x * 4 + wave) * 32 + j;
+        col = n < p.N ? n : p.N - 1;
+        if (n < p.N) out_col = n;
+    }
+    const int64_t w_off = (int64_t)col * p.K + k_beg + kh * 8;   // element offset of this lane's first fragment
+
+    // ---- activation slab staging: MP rows x 16 chunks of 16 B; thread t takes chunks t, t+256, ...
+    constexpr int XCH = MP * 16 / 256;   // chunks per thread (MT * 2)
+    u32x4 xs[XCH];
+    auto x_load = [&](int slab) {
+#pragma unroll
+        for (int q = 0; q < XCH; ++q) {
+            const int c = tid + 256 * q;
+            const int row = c >> 4, c16 = c & 15;
+            if (row < p.M)
+                xs[q] = *reinterpret_cast<const u32x4*>(p.x + (int64_t)row * p.ldx + k_beg + slab * kSlabK + c16 * 8);
+            else
+                xs[q] = u32x4{0u, 0u, 0u, 0u};
+        }
+    };
+    auto x_store = [&](int buf) {
+#pragma unroll
+        for (int q = 0; q < XCH; ++q) {
+            const int c = tid + 256 * q;
+            const int row = c >> 4, c16 = c & 15;
+            *reinterpret_cast<u32x4*>(lds + buf * (MP * kPitch) + row * kPitch + c16 * 16) = xs[q];
+        }
+    };
+
+    f32x16 acc[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
+
+    // ---- prologue: W ring (RD k-steps in flight), first activation slab
+    bf16x8 wr[RD];
+    const int nsteps = nslab * kStepsPerSlab;
+#pragma unroll
+    for (int s = 0; s < RD; ++s) wr[s] = ld_w<W8>(p.w, w_off + (int64_t)(s < nsteps ? s : nsteps - 1) * 16);
+    x_load(0);
+    x_store(0);
+    __syncthreads();
+
+    const unsigned char* a_base = lds + (j * kPitch + kh * 16);
+    static_assert(RD % kStepsPerSlab == 0, "ring depth must be a whole number of slabs");
+    constexpr int SLABS_PER_ITER = RD / kStepsPerSlab;
+    for (int slab0 = 0; slab0 < nslab; slab0 += SLABS_PER_ITER) {
+#pragma unroll
+        for (int ss = 0; ss < SLABS_PER_ITER; ++ss) {
+            const int slab = slab0 + ss;
+            if (slab < nslab) {                                   // wave-uniform
+                const int buf = slab & 1;
+                const bool more = slab + 1 < nslab;
+                if (more) x_load(slab + 1);
+                const unsigned char* a_slab = a_base + buf * (MP * kPitch);
+#pragma unroll
+                for (int st = 0; st < kStepsPerSlab; ++st) {
+                    const int s = ss * kStepsPerSlab + st;        // ring slot (compile time)
+                    const bf16x8 b = wr[s];
+                    const int nxt = slab * kStepsPerSlab + st + RD;   // k-step the slot is refilled with
+                    wr[s] = ld_w<W8>(p.w, w_off + (int64_t)(nxt < nsteps ? nxt : nsteps - 1) * 16);   // tail: re-touch a hot line
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) {
+                        const bf16x8 a = *reinterpret_cast<const bf16x8*>(a_slab + mt * 32 * kPitch + st * 32);
+                        acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[mt], 0, 0, 0);
+                    }
+                }
+                if (more) x_store(buf ^ 1);
+                __syncthreads();
+            }
+        }
+    }
+
+    // ---- epilogue.  acc[mt][r] = D[row = mt*32 + (r&3) + 8*(r>>2) + 4*kh][column j of the wave]
+    if (p.S > 1) {
+        float* pp = p.partial + (int64_t)blockIdx.y * p.M * p.N;
+        const int n = (EPI == EPI_SWIGLU) ? col : out_col;
+        const bool ok = (EPI == EPI_SWIGLU) ? ((blockIdx.x * 4 + wave) * 16 + (j & 15) < (p.N >> 1)) : (out_col >= 0);
+        if (ok) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                    if (row < p.M) pp[(int64_t)row * p.N + n] = acc[mt][r];
+                }
+        }
+        return;
+    }
+    float bias = 0.f, scale = 1.f;
+    if (EPI == EPI_NONE && out_col >= 0) {
+        if (p.bias) bias = bf16_to_f32(p.bias[out_col]);
+        if (p.scales) scale = bf16_to_f32(p.scales[out_col]);
+    }
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+            float v = acc[mt][r];
+            if constexpr (EPI == EPI_SWIGLU) {
+                float h = bf16_to_f32(f32_to_bf16(v));
+                if (W8) h = bf16_to_f32(f32_to_bf16(h * bf16_to_f32(p.scales[col])));
+                const float h3 = __shfl_xor(h, 16);                 // lanes j and j^16 hold w1 / w3 of one column
+                v = silu_bf16(h) * h3;
+            } else {
+                v += bias;
+                if (W8) v = bf16_to_f32(f32_to_bf16(v)) * scale;
+            }
+            if (out_col >= 0 && row < p.M) p.out[(int64_t)row * p.ldo + out_col] = f32_to_bf16(v);
+        }
+}
+
+// Fixed-order combine of the S fp32 partials + epilogue.  One thread per 4 consecutive output columns of one row.
+template <int EPI, bool W8>
+__global__ __launch_bounds__(256) void skinny_reduce_kernel(const GemmParams p) {
+    const int Nout = p.Nout;
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int per_row = Nout / 4;
+    if (t >= (int64_t)p.M * per_row) return;
+    const int row = (int)(t / per_row), c0 = (int)(t % per_row) * 4;
+    const int64_t plane = (int64_t)p.M * p.N;
+    f32x4 a = {0.f, 0.f, 0.f, 0.f}, b3 = {0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < p.S; ++s) {
+        const float* pp = p.partial + s * plane + (int64_t)row * p.N + c0;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(pp);
+        a += v;
+        if constexpr (EPI == EPI_SWIGLU) b3 += *reinterpret_cast<const f32x4*>(pp + (p.N >> 1));
+    }
+    bf16x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        float v = a[e];
+        if constexpr (EPI == EPI_SWIGLU) {
+            float h1 = bf16_to_f32(f32_to_bf16(v)), h3 = bf16_to_f32(f32_to_bf16(b3[e]));
+            if (W8) {
+                h1 = bf16_to_f32(f32_to_bf16(h1 * bf16_to_f32(p.scales[c0 + e])));
+                h3 = bf16_to_f32(f32_to_bf16(h3 * bf16_to_f32(p.scales[(p.N >> 1) + c0 + e])));
+            }
+            v = silu_bf16(h1) * h3;
+        } else {
+            if (p.bias) v += bf16_to_f32(p.bias[c0 + e]);
+            if (W8) v = bf16_to_f32(f32_to_bf16(v)) * bf16_to_f32(p.scales[c0 + e]);
+        }
+        o[e] = f32_to_bf16(v);
+    }
+    *reinterpret_cast<bf16x4*>(p.out + (int64_t)row * p.ldo + c0) = o;
+}
+
+int g_target_blocks = 512;   // split-K is chosen so that about this many workgroups exist (2 per CU)
+
+int pick_splits(int n_blocks, int K) {
+    const int nslab = K / kSlabK;
+    int best = 1;
+    for (int s = 1; s <= nslab && s <= 64; ++s) {
+        if (nslab % s) continue;
+        best = s;
+        if (n_blocks * s >= g_target_blocks) break;
+    }
+    return best;
+}
+
+template <int MT, int EPI, bool W8>
+int launch(const GemmParams& p, int n_blocks, hipStream_t st) {
+    constexpr int RD = 8;
+    const size_t lds = (size_t)2 * MT * 32 * kPitch;
+    auto k = skinny_gemm_kernel<MT, EPI, W8, RD>;
+    if (lds > 64 * 1024) {
+        static bool done = false;     // per (MT, EPI, W8) instantiation; the attribute is per function, not per device
+        if (!done) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)lds) != hipSuccess) {
+                md_set_error("md_linear: hipFuncSetAttribute(%zu B LDS) failed", lds);
+                return MD_ERR_LAUNCH;
+            }
+            done = true;
+        }
+    }
+    hipLaunchKernelGGL(k, dim3(n_blocks, p.S), dim3(256), lds, st, p);
+    if (p.S > 1) {
+        const int64_t threads = (int64_t)p.M * (p.Nout / 4);
+        hipLaunchKernelGGL((skinny_reduce_kernel<EPI, W8>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, p);
+    }
+    return MD_OK;
+}
+
+template <int EPI, bool W8>
+int launch_mt(const GemmParams& p, int n_blocks, hipStream_t st) {
+    if (p.M <= 32) return launch<1, EPI, W8>(p, n_blocks, st);
+    if (p.M <= 64) return launch<2, EPI, W8>(p, n_blocks, st);
+    if (p.M <= 128) return launch<4, EPI, W8>(p, n_blocks, st);
+    return launch<8, EPI, W8>(p, n_blocks, st);
+}
+
+}  // namespace
+
+extern "C" void md_debug_set_gemm_target_blocks(int n) { g_target_blocks = n > 0 ? n : 512; }
+
+extern "C" size_t md_linear_workspace_bytes(int M, int N, int K, int epilogue) {
+    if (M <= 0 || N <= 0 || K <= 0 || K % kSlabK) return 0;
+    const int nout = epilogue == EPI_SWIGLU ? N / 2 : N;
+    const int cols_per_block = epilogue == EPI_SWIGLU ? 64 : 128;
+    const int S = pick_splits((nout + cols_per_block - 1) / cols_per_block, K);
+    return S > 1 ? (size_t)S * M * N * 4 : 0;     // fp32 partial sums of the K slices
+}
+
+extern "C" int md_linear_supported(int M, int N, int K, int epilogue) {
+    if (M < 1 || M > 256 || K < kSlabK || K % kSlabK) return 0;
+    if (epilogue == EPI_SWIGLU) return (N % 32 == 0) ? 1 : 0;     // N = 2*I, I % 16 == 0
+    return (N % 4 == 0) ? 1 : 0;
+}
+
+extern "C" int md_linear(const void* x, int64_t ldx, const void* w, int w_dtype, const void* scales, const void* bias,
+                         void* out, int64_t ldo, int M, int N, int K, int epilogue, void* workspace,
+                         size_t workspace_bytes, md_stream_t stream) {
+    MD_CHECK_ARG(x && w && out, "md_linear: null pointer argument");
+    MD_CHECK_ARG(md_linear_supported(M, N, K, epilogue), "md_linear: unsupported shape M=%d N=%d K=%d epilogue=%d "
+                 "(need 1 <= M <= 256, K %% 128 == 0, N %% 4 == 0)", M, N, K, epilogue);
+    MD_CHECK_ARG(epilogue == EPI_NONE || epilogue == EPI_SWIGLU, "md_linear: unknown epilogue %d", epilogue);
+    MD_CHECK_ARG(w_dtype == MD_W_BF16 || (w_dtype == MD_W_INT8 && scales), "md_linear: w_dtype must be MD_W_BF16 or "
+                 "MD_W_INT8 (with per-channel scales)");
+    MD_CHECK_ARG(!(epilogue == EPI_SWIGLU && bias), "md_linear: SwiGLU epilogue takes no bias");
+    MD_CHECK_ARG((((uintptr_t)x | (uintptr_t)w | (uintptr_t)out) & 15) == 0 && ldx % 8 == 0 && ldo % 4 == 0,
+                 "md_linear: x / w / out must be 16-byte aligned, ldx %% 8 == 0, ldo %% 4 == 0");
+    GemmParams p;
+    p.x = (const bf16_t*)x;
+    p.w = w;
+    p.bias = (const bf16_t*)bias;
+    p.scales = (const bf16_t*)scales;
+    p.out = (bf16_t*)out;
+    p.ldx = ldx;
+    p.ldo = ldo;
+    p.M = M;
+    p.N = N;
+    p.K = K;
+    p.Nout = epilogue == EPI_SWIGLU ? N / 2 : N;
+    const int cols_per_block = epilogue == EPI_SWIGLU ? 64 : 128;      // output columns per workgroup
+    const int n_blocks = (p.Nout + cols_per_block - 1) / cols_per_block;
+    p.S = pick_splits(n_blocks, K);
+    p.kblk = K / p.S;
+    p.partial = (float*)workspace;
+    if (p.S > 1) {
+        MD_CHECK_ARG(workspace && workspace_bytes >= (size_t)p.S * M * N * 4 && (((uintptr_t)workspace) & 15) == 0,
+                     "md_linear: workspace too small (need %zu bytes) or not 16-byte aligned", (size_t)p.S * M * N * 4);
+    }
+    hipStream_t st = (hipStream_t)stream;
+    int rc;
+    const bool w8 = w_dtype == MD_W_INT8;
+    if (epilogue == EPI_SWIGLU)
+        rc = w8 ? launch_mt<EPI_SWIGLU, true>(p, n_blocks, st) : launch_mt<EPI_SWIGLU, false>(p, n_blocks, st);
+    else
+        rc = w8 ? launch_mt<EPI_NONE, true>(p, n_blocks, st) : launch_mt<EPI_NONE, false>(p, n_blocks, st);
+    if (rc != MD_OK) return rc;
+    MD_CHECK_LAUNCH("md_linear");
+    return MD_OK;
+}

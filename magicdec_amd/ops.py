@@ -247,6 +247,54 @@ def streaming_rotate(kv_cache, rot_cache, B, valid_len, pages_per_req, table: Ro
                                   _p(table.table), table.max_pos, _stream()), "md_streaming_rotate")
 
 
+# ----------------------------------------------------------------------------- K8
+MD_W_BF16, MD_W_INT8 = 0, 1
+EPI_NONE, EPI_SWIGLU = 0, 1
+
+
+def linear_supported(M, N, K, swiglu=False):
+    """True when md_linear (the weight-streaming skinny GEMM) takes this shape; otherwise use a library GEMM."""
+    return bool(_lib.load().md_linear_supported(int(M), int(N), int(K), EPI_SWIGLU if swiglu else EPI_NONE))
+
+
+def linear(x, weight, bias=None, scales=None, swiglu=False, workspace: "AttnWorkspace" = None, out=None):
+    """F.linear(x, weight, bias) for M = x.shape[0] <= 256 rows on the hand-written gfx950 skinny GEMM (md_linear).
+    x [M, K] bf16 with unit inner stride (row stride free); weight [N, K] contiguous, bf16 -- or int8 with bf16
+    per-row `scales` (WeightOnlyInt8Linear semantics: bf16(x.w^T) * scales).  swiglu=True: weight = [w1; w3]
+    (N = 2*I rows) and the result is silu(x.w1^T) * (x.w3^T) [M, I] with the reference's bf16 rounding points."""
+    _gpu(x, weight, bias, scales)
+    if x.dim() != 2 or x.stride(1) != 1 or weight.dim() != 2 or not weight.is_contiguous():
+        raise ValueError("linear expects x [M, K] with unit inner stride and a contiguous weight [N, K]")
+    M, K = x.shape
+    N = weight.shape[0]
+    if weight.shape[1] != K:
+        raise ValueError(f"linear: x has K={K}, weight has K={weight.shape[1]}")
+    if weight.dtype == torch.int8:
+        if scales is None:
+            raise ValueError("int8 weights need per-row scales")
+        wd = MD_W_INT8
+    elif weight.dtype == torch.bfloat16:
+        wd = MD_W_BF16
+    else:
+        raise TypeError(f"linear: weight dtype {weight.dtype} unsupported (bf16 or int8)")
+    epi = EPI_SWIGLU if swiglu else EPI_NONE
+    n_out = N // 2 if swiglu else N
+    if out is None:
+        out = torch.empty((M, n_out), dtype=x.dtype, device=x.device)
+    lib = _lib.load()
+    nbytes = lib.md_linear_workspace_bytes(M, N, K, epi)
+    ws = None
+    if nbytes:
+        if workspace is None:
+            raise ValueError("linear: this shape splits K and needs a workspace")
+        ws = workspace.get(nbytes + 256)
+        off = (-ws.data_ptr()) % 256
+    check(lib.md_linear(_p(x), x.stride(0), _p(weight), wd, _p(scales), _p(bias), _p(out), out.stride(0), M, N, K, epi,
+                        ctypes.c_void_p(ws.data_ptr() + off) if ws is not None else None, nbytes, _stream()),
+          "md_linear")
+    return out
+
+
 # ----------------------------------------------------------------------------- K9
 def rmsnorm(x, weight, eps):
     _gpu(x, weight)

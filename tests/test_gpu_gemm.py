@@ -1,0 +1,134 @@
+"""GPU parity of md_linear (the weight-streaming skinny GEMM of the decode / verify linears) -- run with -m gpu.
+
+Reference = float64 matmul of the same bf16 operands, rounded once (the correctly rounded result).  Gate per element:
+    |hip - exact| <= u * |exact| + gamma_K * sum_k |x_k w_k|,   u = 2^-8 (one bf16 rounding), gamma_K = 2 * K * 2^-24
+(the fp32 accumulation bound; the achieved accumulation error is ~1e-7 relative and is reported).  The oracle's own
+torch-CPU F.linear is measured the same way and reported next to it.  Fused epilogues (SwiGLU, int8 scales, bias)
+follow the reference's rounding points and are gated in bf16 ulps.
+"""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tests.conftest import parity_report
+from tests.parity_util import bf16_ulp
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+BF = torch.bfloat16
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from magicdec_amd import ops as _ops
+    _ops._lib.load()
+    return _ops
+
+
+def _exact(x, w, b=None):
+    y = x.double() @ w.double().t()
+    return y + b.double() if b is not None else y
+
+
+SHAPES = [(1, 128, 128), (7, 96, 256), (32, 2048, 1024), (33, 132, 384), (64, 3072, 2048), (64, 100, 3456),
+          (100, 1024, 512), (128, 6144, 1024), (200, 516, 640), (256, 4096, 1024), (256, 36, 128)]
+
+
+@pytest.mark.parametrize("M,N,K", SHAPES, ids=[f"M{m}-N{n}-K{k}" for m, n, k in SHAPES])
+@pytest.mark.parametrize("bias", [False, True], ids=["nobias", "bias"])
+def test_linear_vs_exact(ops, M, N, K, bias):
+    g = torch.Generator().manual_seed(M * 131 + N * 7 + K)
+    xfull = torch.randn(M, K + 64, generator=g).to(BF)
+    x = xfull[:, :K]                                     # row stride != K: a slice of a wider activation tensor
+    w = (torch.randn(N, K, generator=g) * 0.05).to(BF)
+    b = torch.randn(N, generator=g).to(BF) if bias else None
+    ref = _exact(x, w, b)
+    mag = x.double().abs() @ w.double().abs().t() + (b.double().abs() if bias else 0)
+    ws = ops.AttnWorkspace(DEV)
+    assert ops.linear_supported(M, N, K)
+    y = ops.linear(xfull.to(DEV)[:, :K], w.to(DEV), b.to(DEV) if bias else None, workspace=ws)
+    assert y.shape == (M, N) and y.dtype == BF
+    err = (y.cpu().double() - ref).abs()
+    tol = 2.0 ** -8 * ref.abs() + 2 * K * 2.0 ** -24 * mag
+    ora = (F.linear(x, w, b).double() - ref).abs()
+    ulp = bf16_ulp(ref)
+    parity_report(f"[gemm] M={M:3d} N={N:5d} K={K:5d} bias={int(bias)}  max err/tol {float((err / tol).max()):.3f}  "
+                  f"max err {float((err / ulp).max()):.2f} ulp  oracle(torch CPU) {float((ora / ulp).max()):.2f} ulp  "
+                  f"!= correctly rounded: hip {100 * float((y.cpu() != ref.to(BF)).double().mean()):.3f}% "
+                  f"oracle {100 * float((F.linear(x, w, b) != ref.to(BF)).double().mean()):.3f}%")
+    assert bool((err <= tol).all())
+
+
+@pytest.mark.parametrize("M,I,K", [(4, 64, 256), (64, 1024, 512), (100, 176, 384), (256, 2048, 1024)])
+def test_linear_swiglu_epilogue(ops, M, I, K):
+    """silu(x.w1^T) * (x.w3^T) with the reference's rounding points (h1, h3 -> bf16; silu -> bf16; product -> bf16,
+    Engine/SnapKV/model.py:451-455): equal to that sequence evaluated on the correctly rounded h1 / h3 up to 3 bf16
+    ulps (a 1-ulp flip of h1 or h3 where the fp32 sum sits on a rounding boundary), >= 99 % bit-equal."""
+    g = torch.Generator().manual_seed(M + I + K)
+    x = torch.randn(M, K, generator=g).to(BF)
+    w13 = (torch.randn(2 * I, K, generator=g) * 0.08).to(BF)
+    h = _exact(x, w13).to(BF)
+    ref = F.silu(h[:, :I]) * h[:, I:]
+    ws = ops.AttnWorkspace(DEV)
+    y = ops.linear(x.to(DEV), w13.to(DEV), swiglu=True, workspace=ws).cpu()
+    assert y.shape == (M, I)
+    ulp = bf16_ulp(ref.double())
+    d = ((y.double() - ref.double()).abs() / ulp)
+    eq = float((y == ref).double().mean())
+    parity_report(f"[gemm] swiglu M={M} I={I} K={K}: bit-equal {100 * eq:.3f}%  max diff {float(d.max()):.2f} ulp")
+    assert eq >= 0.99 and float(d.max()) <= 3.0
+
+
+@pytest.mark.parametrize("M,N,K,swiglu", [(8, 256, 256, False), (64, 1024, 1024, False), (200, 128, 384, False),
+                                          (64, 512, 512, True)])
+def test_linear_int8_weight_only(ops, M, N, K, swiglu):
+    """WeightOnlyInt8Linear.forward (Engine/quantize.py:84-86): F.linear(x, w_int8.to(bf16)) * scales -- the GEMM output
+    is rounded to bf16, then multiplied by the bf16 per-channel scale in bf16.  Weights convert exactly; gate: equal
+    to that sequence on the correctly rounded GEMM output up to 2 ulps, >= 99 % bit-equal."""
+    g = torch.Generator().manual_seed(M + N + K)
+    x = torch.randn(M, K, generator=g).to(BF)
+    wq = torch.randint(-128, 128, (N, K), generator=g, dtype=torch.int8)
+    sc = (torch.rand(N, generator=g) * 0.01 + 0.001).to(BF)
+    h = _exact(x, wq.to(BF)).to(BF) * sc
+    ref = F.silu(h[:, :N // 2]) * h[:, N // 2:] if swiglu else h
+    ws = ops.AttnWorkspace(DEV)
+    y = ops.linear(x.to(DEV), wq.to(DEV), scales=sc.to(DEV), swiglu=swiglu, workspace=ws).cpu()
+    ulp = bf16_ulp(ref.double())
+    d = ((y.double() - ref.double()).abs() / ulp)
+    eq = float((y == ref).double().mean())
+    parity_report(f"[gemm] int8 M={M} N={N} K={K} swiglu={int(swiglu)}: bit-equal {100 * eq:.3f}%  max diff "
+                  f"{float(d.max()):.2f} ulp")
+    assert eq >= 0.99 and float(d.max()) <= (3.0 if swiglu else 2.0)
+
+
+def test_linear_full_size_and_determinism(ops):
+    """Headline shapes (8B wqkv at the verify M = 256 and the 1B w2 at M = 64) against a float64 GEMM on the GPU;
+    two runs are bit-identical (fixed-order split-K combine)."""
+    for M, N, K in ((256, 6144, 4096), (64, 2048, 8192)):
+        g = torch.Generator(device=DEV).manual_seed(1)
+        x = torch.randn(M, K, device=DEV, generator=g, dtype=torch.float32).to(BF)
+        w = (torch.randn(N, K, device=DEV, generator=g, dtype=torch.float32) * 0.02).to(BF)
+        ws = ops.AttnWorkspace(DEV)
+        y1 = ops.linear(x, w, workspace=ws)
+        y2 = ops.linear(x, w, workspace=ws)
+        assert torch.equal(y1, y2)
+        ref = x.double() @ w.double().t()
+        mag = x.double().abs() @ w.double().abs().t()
+        err = (y1.double() - ref).abs()
+        tol = 2.0 ** -8 * ref.abs() + 2 * K * 2.0 ** -24 * mag
+        lib = (F.linear(x, w).double() - ref).abs()
+        parity_report(f"[gemm] full size M={M} N={N} K={K}: max err/tol {float((err / tol).max()):.3f}; != correctly "
+                      f"rounded: hip {100 * float((y1 != ref.to(BF)).double().mean()):.4f}%  hipBLASLt "
+                      f"{100 * float((F.linear(x, w) != ref.to(BF)).double().mean()):.4f}%  (max err hipBLASLt/tol "
+                      f"{float((lib / tol).max()):.3f})")
+        assert bool((err <= tol).all())
+
+
+def test_linear_rejects_bad_arguments(ops):
+    x = torch.zeros(4, 100, dtype=BF, device=DEV)
+    w = torch.zeros(64, 100, dtype=BF, device=DEV)
+    assert not ops.linear_supported(4, 64, 100) and not ops.linear_supported(300, 64, 128)
+    with pytest.raises(ops.MagicDecHipError):
+        ops.linear(x, w)
+    with pytest.raises(ValueError):
+        ops.linear(torch.zeros(4, 128, dtype=BF, device=DEV), torch.zeros(64, 128, dtype=torch.int8, device=DEV))
