@@ -212,6 +212,12 @@ int md_silu_mul(const void* a, const void* b, int64_t a_row_stride, int64_t b_ro
  *   epilogue MD_EPI_NONE: out[M][N] = bf16(acc + bias)   (bias bf16 [N] or NULL)
  *            MD_EPI_SWIGLU: w = [w1; w3] (N = 2*I rows): out[M][I] = bf16(bf16(silu(bf16(h1))) * bf16(h3))
  *   x row stride ldx, out row stride ldo (elements).  workspace: md_linear_workspace_bytes() bytes (16-B aligned).
+ *   w_packed 0: w is the nn.Linear row-major [N][K] tensor.
+ *            1: w is the STREAMING layout [ceil(N/32)][K/16][64][8]: element (t, s, lane, e) =
+ *               W[32*t + lane%32][16*s + 8*(lane/32) + e] (rows >= N zero) -- every wavefront load instruction is one
+ *               contiguous KiB and every wavefront reads one sequential stream; for MD_EPI_SWIGLU tile t holds rows
+ *               16t..16t+15 of w1 followed by rows 16t..16t+15 of w3 ([ceil(I/16)] tiles).  The row-major form makes
+ *               32-byte pieces of 32 different rows per instruction and streams at about half the rate.
  * md_linear_supported() == 0 -> use a library GEMM (M > 256, K % 128 != 0, ...).
  * ---------------------------------------------------------------------- */
 #define MD_W_BF16 0
@@ -221,8 +227,8 @@ int md_silu_mul(const void* a, const void* b, int64_t a_row_stride, int64_t b_ro
 int md_linear_supported(int M, int N, int K, int epilogue);
 size_t md_linear_workspace_bytes(int M, int N, int K, int epilogue);
 void md_debug_set_gemm_target_blocks(int n); /* development: split-K policy (workgroups to aim for) */
-int md_linear(const void* x, int64_t ldx, const void* w, int w_dtype, const void* scales, const void* bias,
-              void* out, int64_t ldo, int M, int N, int K, int epilogue, void* workspace,
+int md_linear(const void* x, int64_t ldx, const void* w, int w_dtype, int w_packed, const void* scales,
+              const void* bias, void* out, int64_t ldo, int M, int N, int K, int epilogue, void* workspace,
               size_t workspace_bytes, md_stream_t stream);
 
 /* ------------------------------------------------------------------------

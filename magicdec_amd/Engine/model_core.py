@@ -284,14 +284,20 @@ class Transformer(nn.Module):
         self._ready = True
 
     def _fuse_weights(self):
-        """w1|w3 -> one [2I, dim] GEMM operand; the original parameters become views of it (no extra HBM)."""
-        self._w13 = []
+        """w1|w3 -> one [2I, dim] GEMM operand; the original parameters become views of it (no extra HBM).
+        Weight-only int8 models (Engine/quantize.py) fuse the int8 rows and their per-row scales the same way."""
+        self._w13, self._s13 = [], []
         for b in self.layers:
             ff = b.feed_forward
             w13 = torch.cat([ff.w1.weight.data, ff.w3.weight.data], dim=0).contiguous()
             inter = ff.w1.weight.shape[0]
-            ff.w1.weight = nn.Parameter(w13[:inter], requires_grad=False)
-            ff.w3.weight = nn.Parameter(w13[inter:], requires_grad=False)
+            if w13.dtype == torch.int8:
+                ff.w1.weight, ff.w3.weight = w13[:inter], w13[inter:]
+                self._s13.append(torch.cat([ff.w1.scales, ff.w3.scales]).contiguous())
+            else:
+                ff.w1.weight = nn.Parameter(w13[:inter], requires_grad=False)
+                ff.w3.weight = nn.Parameter(w13[inter:], requires_grad=False)
+                self._s13.append(None)
             self._w13.append(w13)
 
     # ------------------------------------------------------------------ building blocks
@@ -307,10 +313,33 @@ class Transformer(nn.Module):
                 dist.all_reduce(y, group=group)
         return y
 
+    def _linear(self, x2d, lin, swiglu_w13=None):
+        """One linear of a step: the hand-written weight-streaming skinny GEMM (md_linear, csrc/gemm.hip) for the
+        decode / verify shapes it wins on (Engine/gemm_policy.py, measured A/B against hipBLASLt), the library GEMM
+        otherwise (prefill-sized M).  `swiglu_w13 = (w13, s13)`: the fused w1|w3 product with the SiLU*mul epilogue."""
+        from .gemm_policy import use_skinny
+        if swiglu_w13 is not None:
+            w, scales, bias = swiglu_w13[0], swiglu_w13[1], None
+        else:
+            w, scales, bias = lin.weight, getattr(lin, "scales", None), lin.bias
+        M, K = x2d.shape
+        N = w.shape[0]
+        swiglu = swiglu_w13 is not None
+        if x2d.is_cuda and use_skinny(M, N, K, swiglu, w.dtype == torch.int8) and ops.linear_supported(M, N, K, swiglu):
+            return ops.linear(x2d, w, bias, scales, swiglu, self.workspace)
+        if w.dtype == torch.int8:      # WeightOnlyInt8Linear.forward (Engine/quantize.py:84-86), dequantised on the fly
+            h = F.linear(x2d, w.to(dtype=x2d.dtype)) * scales
+        else:
+            h = F.linear(x2d, w, bias)
+        if swiglu:
+            inter = N // 2
+            return ops.silu_mul(h[:, :inter], h[:, inter:])
+        return h
+
     def _qkv(self, layer, y2d):
         c = self.config
         att = layer.attention
-        qkv = F.linear(y2d, att.wqkv.weight, att.wqkv.bias)          # [rows, (H+2KH)*D]
+        qkv = self._linear(y2d, att.wqkv)                              # [rows, (H+2KH)*D]
         H, KH, D = c.n_head, c.n_local_heads, c.head_dim
         rows = qkv.shape[0]
         q = qkv[:, :H * D].unflatten(1, (H, D))
@@ -319,10 +348,8 @@ class Transformer(nn.Module):
         return q, k, v, rows
 
     def _mlp(self, i, layer, y2d):
-        inter = layer.feed_forward.w2.weight.shape[1]
-        h13 = F.linear(y2d, self._w13[i])
-        act = ops.silu_mul(h13[:, :inter], h13[:, inter:])
-        return self._reduce(F.linear(act, layer.feed_forward.w2.weight), layer.feed_forward.process_group)
+        act = self._linear(y2d, None, swiglu_w13=(self._w13[i], self._s13[i]))
+        return self._reduce(self._linear(act, layer.feed_forward.w2), layer.feed_forward.process_group)
 
     def _run(self, idx, attn_fn):
         """embed -> L x (norm, attention, +res, norm, mlp, +res) -> norm -> head -> argmax.
@@ -337,14 +364,14 @@ class Transformer(nn.Module):
         for i, layer in enumerate(layers):
             q, k, v, rows = self._qkv(layer, y)
             o = attn_fn(i, layer, q, k, v, n)
-            a = self._reduce(F.linear(o.view(rows, -1), layer.attention.wo.weight), layer.attention.process_group)
+            a = self._reduce(self._linear(o.view(rows, -1), layer.attention.wo), layer.attention.process_group)
             x, y = ops.add_rmsnorm(x, a, layer.ffn_norm.weight, layer.ffn_norm.eps)
             f = self._mlp(i, layer, y)
             nxt = layers[i + 1].attention_norm if i + 1 < len(layers) else self.norm
             x, y = ops.add_rmsnorm(x, f, nxt.weight, nxt.eps)
         if self.skip_head:
             return None
-        logits = F.linear(y, self.output.weight)                      # [rows, vocab / tp]
+        logits = self._linear(y, self.output)                         # [rows, vocab / tp]
         self._last_logits = logits
         return self._argmax(logits).view(B, n)
 

@@ -57,9 +57,16 @@ def init_dist(draft_ranks=None):
     return global_rank, global_group
 
 
-def _slice_param(linear: nn.Linear, weight, size_attr):
+def _slice_param(linear: nn.Linear, weight, size_attr, scales=None):
+    """`scales`: the matching slice of a WeightOnlyInt8Linear's per-row scales for column-parallel (output-sliced)
+    layers (Engine/tp.py:105-110,141-142 of the reference); row-parallel layers keep all their scales."""
     weight = weight.clone()      # own storage: the full tensor is released, GEMM operands stay contiguous
-    linear.weight = nn.Parameter(weight, requires_grad=False)
+    if weight.dtype == torch.int8:
+        linear.weight = weight
+        if scales is not None:
+            linear.scales = scales.clone()
+    else:
+        linear.weight = nn.Parameter(weight, requires_grad=False)
     setattr(linear, size_attr, weight.shape[0 if size_attr == "out_features" else 1])
 
 
@@ -77,17 +84,23 @@ def apply_tp(model, rank_group, group) -> None:
     for block in model.layers:
         att, ff = block.attention, block.feed_forward
         q, k, v = att.wqkv.weight.split([q_size, kv_size, kv_size], dim=0)
-        _slice_param(att.wqkv, torch.cat((q[qs:qe], k[ks:ke], v[ks:ke]), dim=0), "out_features")
+        sc = getattr(att.wqkv, "scales", None)
+        if sc is not None:
+            sq, sk, sv = sc.split([q_size, kv_size, kv_size], dim=0)
+            sc = torch.cat((sq[qs:qe], sk[ks:ke], sv[ks:ke]))
+        _slice_param(att.wqkv, torch.cat((q[qs:qe], k[ks:ke], v[ks:ke]), dim=0), "out_features", sc)
         if att.wqkv.bias is not None:
             bq, bk, bv = att.wqkv.bias.split([q_size, kv_size, kv_size], dim=0)
             att.wqkv.bias = nn.Parameter(torch.cat((bq[qs:qe], bk[ks:ke], bv[ks:ke])), requires_grad=False)
         _slice_param(att.wo, att.wo.weight[:, qs:qe], "in_features")
-        _slice_param(ff.w1, torch.chunk(ff.w1.weight, world, dim=0)[rank], "out_features")
-        _slice_param(ff.w3, torch.chunk(ff.w3.weight, world, dim=0)[rank], "out_features")
+        chunk_sc = lambda lin: torch.chunk(lin.scales, world, dim=0)[rank] if hasattr(lin, "scales") else None
+        _slice_param(ff.w1, torch.chunk(ff.w1.weight, world, dim=0)[rank], "out_features", chunk_sc(ff.w1))
+        _slice_param(ff.w3, torch.chunk(ff.w3.weight, world, dim=0)[rank], "out_features", chunk_sc(ff.w3))
         _slice_param(ff.w2, torch.chunk(ff.w2.weight, world, dim=1)[rank], "in_features")
         att.process_group = group
         ff.process_group = group
-    _slice_param(model.output, torch.chunk(model.output.weight, world, dim=0)[rank], "out_features")
+    _slice_param(model.output, torch.chunk(model.output.weight, world, dim=0)[rank], "out_features",
+                 torch.chunk(model.output.scales, world, dim=0)[rank] if hasattr(model.output, "scales") else None)
     lkh = e - s
     cfg.dim = cfg.dim * lkh // cfg.n_local_heads
     cfg.n_head = lkh * g

@@ -61,8 +61,11 @@ def _load(transformer_cls, checkpoint_path, device, precision, use_tp, rank_grou
     checkpoint_path = Path(checkpoint_path)
     with torch.device("meta"):
         model = transformer_cls.from_name(checkpoint_path.parent.name)
-    if "int8" in str(checkpoint_path):
-        raise NotImplementedError("weight-only int8 checkpoints are outside the hot path (SURVEY.md section 2, #9)")
+    int8 = "int8" in str(checkpoint_path)          # Engine/utils.py:201-205 of the reference
+    if int8 and checkpoint_path.exists():
+        print("Using int8 weight-only quantization!")
+        from .quantize import WeightOnlyInt8QuantHandler
+        model = WeightOnlyInt8QuantHandler(model).convert_for_runtime()
     if checkpoint_path.exists():
         checkpoint = torch.load(str(checkpoint_path), mmap=True, weights_only=True)
         if "model" in checkpoint and "stories" in str(checkpoint_path):
@@ -71,6 +74,13 @@ def _load(transformer_cls, checkpoint_path, device, precision, use_tp, rank_grou
     else:
         print(f"[magicdec_amd] {checkpoint_path} not found: seeded random weights for '{checkpoint_path.parent.name}'")
         _random_init_(model, seed, device, precision)
+        if int8:                                   # quantise the seeded weights the way the reference's quantize.py does
+            print("Using int8 weight-only quantization!")
+            from .quantize import WeightOnlyInt8QuantHandler
+            handler = WeightOnlyInt8QuantHandler(model)
+            sd = handler.create_quantized_state_dict()
+            model = handler.convert_for_runtime()
+            model.load_state_dict(sd, assign=True)
     if use_tp:
         from .tp import apply_tp
         print("Applying tensor parallel to model ...")

@@ -43,6 +43,7 @@ struct GemmParams {
     float* partial;       // [S][M][N] fp32 when S > 1
     int64_t ldx, ldo;
     int M, N, K, kblk, S, Nout;
+    int packed;           // W is in the fragment-major streaming layout (md_pack_weight layout, see md_linear)
 };
 
 __device__ __forceinline__ bf16x8 ld_frag(const bf16_t* p) { return *reinterpret_cast<const bf16x8*>(p); }
@@ -101,7 +102,13 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(const GemmParams p) {
         col = n < p.N ? n : p.N - 1;
         if (n < p.N) out_col = n;
     }
-    const int64_t w_off = (int64_t)col * p.K + k_beg + kh * 8;   // element offset of this lane's first fragment
+    // element offset of this lane's first fragment and the distance between consecutive k-steps.
+    // row-major: 32 rows x 32 B per wave instruction.  packed: tile-major [n_tile][k_step][lane][8]: one fully
+    // contiguous KiB per wave instruction and one sequential stream per wavefront (the layout HBM likes best).
+    const int tile = blockIdx.x * 4 + wave;
+    const int64_t w_off = p.packed ? ((int64_t)tile * (p.K >> 4) + (k_beg >> 4)) * 512 + lane * 8
+                                   : (int64_t)col * p.K + k_beg + kh * 8;
+    const int64_t w_step = p.packed ? 512 : 16;
 
     // ---- activation slab staging: MP rows x 16 chunks of 16 B; thread t takes chunks t, t+256, ...
     constexpr int XCH = MP * 16 / 256;   // chunks per thread (MT * 2)
@@ -111,10 +118,10 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(const GemmParams p) {
         for (int q = 0; q < XCH; ++q) {
             const int c = tid + 256 * q;
             const int row = c >> 4, c16 = c & 15;
-            if (row < p.M)
-                xs[q] = *reinterpret_cast<const u32x4*>(p.x + (int64_t)row * p.ldx + k_beg + slab * kSlabK + c16 * 8);
-            else
-                xs[q] = u32x4{0u, 0u, 0u, 0u};
+            // rows >= M re-read row M-1 (branch-free: a branch per load would serialise the staging, and the results
+            // of those rows are never stored)
+            const int rr = row < p.M ? row : p.M - 1;
+            xs[q] = *reinterpret_cast<const u32x4*>(p.x + (int64_t)rr * p.ldx + k_beg + slab * kSlabK + c16 * 8);
         }
     };
     auto x_store = [&](int buf) {
@@ -136,7 +143,7 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(const GemmParams p) {
     bf16x8 wr[RD];
     const int nsteps = nslab * kStepsPerSlab;
 #pragma unroll
-    for (int s = 0; s < RD; ++s) wr[s] = ld_w<W8>(p.w, w_off + (int64_t)(s < nsteps ? s : nsteps - 1) * 16);
+    for (int s = 0; s < RD; ++s) wr[s] = ld_w<W8>(p.w, w_off + (int64_t)(s < nsteps ? s : nsteps - 1) * w_step);
     x_load(0);
     x_store(0);
     __syncthreads();
@@ -153,17 +160,30 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(const GemmParams p) {
                 const bool more = slab + 1 < nslab;
                 if (more) x_load(slab + 1);
                 const unsigned char* a_slab = a_base + buf * (MP * kPitch);
+                // A fragments are double-buffered in registers: the MT ds_reads of step st+1 are issued before the MT
+                // MFMAs of step st (an LDS round trip is longer than one MFMA; with one wave per SIMD at MT = 8
+                // nothing else would cover it)
+                bf16x8 af[2][MT];
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+                    af[0][mt] = *reinterpret_cast<const bf16x8*>(a_slab + mt * 32 * kPitch);
 #pragma unroll
                 for (int st = 0; st < kStepsPerSlab; ++st) {
                     const int s = ss * kStepsPerSlab + st;        // ring slot (compile time)
                     const bf16x8 b = wr[s];
                     const int nxt = slab * kStepsPerSlab + st + RD;   // k-step the slot is refilled with
-                    wr[s] = ld_w<W8>(p.w, w_off + (int64_t)(nxt < nsteps ? nxt : nsteps - 1) * 16);   // tail: re-touch a hot line
+                    wr[s] = ld_w<W8>(p.w, w_off + (int64_t)(nxt < nsteps ? nxt : nsteps - 1) * w_step);   // tail: re-touch a hot line
+                    if (st + 1 < kStepsPerSlab) {
 #pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) {
-                        const bf16x8 a = *reinterpret_cast<const bf16x8*>(a_slab + mt * 32 * kPitch + st * 32);
-                        acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[mt], 0, 0, 0);
+                        for (int mt = 0; mt < MT; ++mt)
+                            af[(st + 1) & 1][mt] =
+                                *reinterpret_cast<const bf16x8*>(a_slab + mt * 32 * kPitch + (st + 1) * 32);
                     }
+                    __builtin_amdgcn_sched_barrier(0);     // keep the reads of step st+1 AHEAD of the MFMAs of step st
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt)
+                        acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[st & 1][mt], b, acc[mt], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
                 if (more) x_store(buf ^ 1);
                 __syncthreads();
@@ -310,8 +330,8 @@ extern "C" int md_linear_supported(int M, int N, int K, int epilogue) {
     return (N % 4 == 0) ? 1 : 0;
 }
 
-extern "C" int md_linear(const void* x, int64_t ldx, const void* w, int w_dtype, const void* scales, const void* bias,
-                         void* out, int64_t ldo, int M, int N, int K, int epilogue, void* workspace,
+extern "C" int md_linear(const void* x, int64_t ldx, const void* w, int w_dtype, int w_packed, const void* scales,
+                         const void* bias, void* out, int64_t ldo, int M, int N, int K, int epilogue, void* workspace,
                          size_t workspace_bytes, md_stream_t stream) {
     MD_CHECK_ARG(x && w && out, "md_linear: null pointer argument");
     MD_CHECK_ARG(md_linear_supported(M, N, K, epilogue), "md_linear: unsupported shape M=%d N=%d K=%d epilogue=%d "
@@ -334,6 +354,7 @@ extern "C" int md_linear(const void* x, int64_t ldx, const void* w, int w_dtype,
     p.N = N;
     p.K = K;
     p.Nout = epilogue == EPI_SWIGLU ? N / 2 : N;
+    p.packed = w_packed ? 1 : 0;
     const int cols_per_block = epilogue == EPI_SWIGLU ? 64 : 128;      // output columns per workgroup
     const int n_blocks = (p.Nout + cols_per_block - 1) / cols_per_block;
     p.S = pick_splits(n_blocks, K);

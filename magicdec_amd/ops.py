@@ -257,26 +257,63 @@ def linear_supported(M, N, K, swiglu=False):
     return bool(_lib.load().md_linear_supported(int(M), int(N), int(K), EPI_SWIGLU if swiglu else EPI_NONE))
 
 
+class PackedWeight:
+    """A linear's weight in the streaming layout of md_linear (include/magicdec_hip.h: w_packed = 1):
+    [ceil(N/32)][K/16][64 lanes][8] -- element (t, s, lane, e) = W[32t + lane%32][16s + 8*(lane/32) + e], rows past N
+    zero; for swiglu=True tile t = rows 16t..16t+15 of w1 then rows 16t..16t+15 of w3 (weight = [w1; w3], N = 2I).
+    Built once at load time (a torch permute: plumbing); bf16 or int8."""
+
+    def __init__(self, weight, swiglu=False):
+        N, K = weight.shape
+        if K % 16:
+            raise ValueError("PackedWeight needs K % 16 == 0")
+        self.N, self.K, self.swiglu, self.dtype = N, K, swiglu, weight.dtype
+        if swiglu:
+            inter = N // 2
+            t = (inter + 15) // 16
+            w1 = torch.zeros((t * 16, K), dtype=weight.dtype, device=weight.device)
+            w3 = torch.zeros((t * 16, K), dtype=weight.dtype, device=weight.device)
+            w1[:inter], w3[:inter] = weight[:inter], weight[inter:]
+            rows = torch.cat([w1.view(t, 16, K), w3.view(t, 16, K)], dim=1)          # [t, 32, K]
+        else:
+            t = (N + 31) // 32
+            rows = torch.zeros((t * 32, K), dtype=weight.dtype, device=weight.device)
+            rows[:N] = weight
+            rows = rows.view(t, 32, K)
+        # [t, j, s, kh, e] -> [t, s, kh, j, e]
+        self.data = rows.view(t, 32, K // 16, 2, 8).permute(0, 2, 3, 1, 4).contiguous()
+
+
 def linear(x, weight, bias=None, scales=None, swiglu=False, workspace: "AttnWorkspace" = None, out=None):
     """F.linear(x, weight, bias) for M = x.shape[0] <= 256 rows on the hand-written gfx950 skinny GEMM (md_linear).
-    x [M, K] bf16 with unit inner stride (row stride free); weight [N, K] contiguous, bf16 -- or int8 with bf16
-    per-row `scales` (WeightOnlyInt8Linear semantics: bf16(x.w^T) * scales).  swiglu=True: weight = [w1; w3]
-    (N = 2*I rows) and the result is silu(x.w1^T) * (x.w3^T) [M, I] with the reference's bf16 rounding points."""
-    _gpu(x, weight, bias, scales)
-    if x.dim() != 2 or x.stride(1) != 1 or weight.dim() != 2 or not weight.is_contiguous():
-        raise ValueError("linear expects x [M, K] with unit inner stride and a contiguous weight [N, K]")
+    x [M, K] bf16 with unit inner stride (row stride free); weight: a contiguous [N, K] tensor or a PackedWeight
+    (streaming layout), bf16 -- or int8 with bf16 per-row `scales` (WeightOnlyInt8Linear semantics:
+    bf16(x.w^T) * scales).  swiglu=True: weight = [w1; w3] (N = 2*I rows) and the result is
+    silu(x.w1^T) * (x.w3^T) [M, I] with the reference's bf16 rounding points."""
+    packed = isinstance(weight, PackedWeight)
+    wt = weight.data if packed else weight
+    _gpu(x, wt, bias, scales)
+    if x.dim() != 2 or x.stride(1) != 1:
+        raise ValueError("linear expects x [M, K] with unit inner stride")
     M, K = x.shape
-    N = weight.shape[0]
-    if weight.shape[1] != K:
-        raise ValueError(f"linear: x has K={K}, weight has K={weight.shape[1]}")
-    if weight.dtype == torch.int8:
+    if packed:
+        if weight.swiglu != swiglu:
+            raise ValueError("PackedWeight was packed for a different epilogue")
+        N, wk = weight.N, weight.K
+    else:
+        if weight.dim() != 2 or not weight.is_contiguous():
+            raise ValueError("linear expects a contiguous weight [N, K]")
+        N, wk = weight.shape
+    if wk != K:
+        raise ValueError(f"linear: x has K={K}, weight has K={wk}")
+    if wt.dtype == torch.int8:
         if scales is None:
             raise ValueError("int8 weights need per-row scales")
         wd = MD_W_INT8
-    elif weight.dtype == torch.bfloat16:
+    elif wt.dtype == torch.bfloat16:
         wd = MD_W_BF16
     else:
-        raise TypeError(f"linear: weight dtype {weight.dtype} unsupported (bf16 or int8)")
+        raise TypeError(f"linear: weight dtype {wt.dtype} unsupported (bf16 or int8)")
     epi = EPI_SWIGLU if swiglu else EPI_NONE
     n_out = N // 2 if swiglu else N
     if out is None:
@@ -289,7 +326,8 @@ def linear(x, weight, bias=None, scales=None, swiglu=False, workspace: "AttnWork
             raise ValueError("linear: this shape splits K and needs a workspace")
         ws = workspace.get(nbytes + 256)
         off = (-ws.data_ptr()) % 256
-    check(lib.md_linear(_p(x), x.stride(0), _p(weight), wd, _p(scales), _p(bias), _p(out), out.stride(0), M, N, K, epi,
+    check(lib.md_linear(_p(x), x.stride(0), _p(wt), wd, 1 if packed else 0, _p(scales), _p(bias), _p(out),
+                        out.stride(0), M, N, K, epi,
                         ctypes.c_void_p(ws.data_ptr() + off) if ws is not None else None, nbytes, _stream()),
           "md_linear")
     return out

@@ -25,6 +25,26 @@ def ops():
     return _ops
 
 
+def _neighbours(t):
+    """bf16 tensor -> (t - 1 ulp, t, t + 1 ulp)."""
+    i = t.contiguous().view(torch.int16).int()
+    mag = i & 0x7fff
+    up = torch.where(i >= 0, i + 1, torch.where(mag == 0, torch.ones_like(i), i - 1))      # towards +inf
+    dn = torch.where(i > 0, i - 1, torch.where(mag == 0, torch.full_like(i, -32767), i + 1))
+    f = lambda v: v.to(torch.int16).view(torch.bfloat16)
+    return f(dn), t, f(up)
+
+
+def _matches_some_neighbour(y, fn, h1, h3=None):
+    """y equals fn evaluated on the correctly rounded GEMM output(s) or on a 1-ulp neighbour of them: what a different
+    fp32 summation order can legitimately produce at a rounding boundary (elementwise)."""
+    ok = torch.zeros(y.shape, dtype=torch.bool)
+    for a in _neighbours(h1):
+        for b in (_neighbours(h3) if h3 is not None else (None,)):
+            ok |= (fn(a, b) == y)
+    return ok
+
+
 def _exact(x, w, b=None):
     y = x.double() @ w.double().t()
     return y + b.double() if b is not None else y
@@ -36,7 +56,8 @@ SHAPES = [(1, 128, 128), (7, 96, 256), (32, 2048, 1024), (33, 132, 384), (64, 30
 
 @pytest.mark.parametrize("M,N,K", SHAPES, ids=[f"M{m}-N{n}-K{k}" for m, n, k in SHAPES])
 @pytest.mark.parametrize("bias", [False, True], ids=["nobias", "bias"])
-def test_linear_vs_exact(ops, M, N, K, bias):
+@pytest.mark.parametrize("packed", [False, True], ids=["rowmajor", "packed"])
+def test_linear_vs_exact(ops, M, N, K, bias, packed):
     g = torch.Generator().manual_seed(M * 131 + N * 7 + K)
     xfull = torch.randn(M, K + 64, generator=g).to(BF)
     x = xfull[:, :K]                                     # row stride != K: a slice of a wider activation tensor
@@ -46,59 +67,68 @@ def test_linear_vs_exact(ops, M, N, K, bias):
     mag = x.double().abs() @ w.double().abs().t() + (b.double().abs() if bias else 0)
     ws = ops.AttnWorkspace(DEV)
     assert ops.linear_supported(M, N, K)
-    y = ops.linear(xfull.to(DEV)[:, :K], w.to(DEV), b.to(DEV) if bias else None, workspace=ws)
+    wd = ops.PackedWeight(w.to(DEV)) if packed else w.to(DEV)
+    y = ops.linear(xfull.to(DEV)[:, :K], wd, b.to(DEV) if bias else None, workspace=ws)
     assert y.shape == (M, N) and y.dtype == BF
     err = (y.cpu().double() - ref).abs()
     tol = 2.0 ** -8 * ref.abs() + 2 * K * 2.0 ** -24 * mag
     ora = (F.linear(x, w, b).double() - ref).abs()
     ulp = bf16_ulp(ref)
-    parity_report(f"[gemm] M={M:3d} N={N:5d} K={K:5d} bias={int(bias)}  max err/tol {float((err / tol).max()):.3f}  "
+    parity_report(f"[gemm] M={M:3d} N={N:5d} K={K:5d} bias={int(bias)} packed={int(packed)}  max err/tol {float((err / tol).max()):.3f}  "
                   f"max err {float((err / ulp).max()):.2f} ulp  oracle(torch CPU) {float((ora / ulp).max()):.2f} ulp  "
                   f"!= correctly rounded: hip {100 * float((y.cpu() != ref.to(BF)).double().mean()):.3f}% "
                   f"oracle {100 * float((F.linear(x, w, b) != ref.to(BF)).double().mean()):.3f}%")
     assert bool((err <= tol).all())
 
 
+@pytest.mark.parametrize("packed", [False, True], ids=["rowmajor", "packed"])
 @pytest.mark.parametrize("M,I,K", [(4, 64, 256), (64, 1024, 512), (100, 176, 384), (256, 2048, 1024)])
-def test_linear_swiglu_epilogue(ops, M, I, K):
+def test_linear_swiglu_epilogue(ops, M, I, K, packed):
     """silu(x.w1^T) * (x.w3^T) with the reference's rounding points (h1, h3 -> bf16; silu -> bf16; product -> bf16,
-    Engine/SnapKV/model.py:451-455): equal to that sequence evaluated on the correctly rounded h1 / h3 up to 3 bf16
-    ulps (a 1-ulp flip of h1 or h3 where the fp32 sum sits on a rounding boundary), >= 99 % bit-equal."""
+    Engine/SnapKV/model.py:451-455): >= 99.9 % bit-equal to that sequence evaluated on the correctly rounded h1 / h3,
+    and every other element equals it evaluated on a 1-ulp neighbour of h1 / h3 (an fp32 sum on a rounding boundary)."""
     g = torch.Generator().manual_seed(M + I + K)
     x = torch.randn(M, K, generator=g).to(BF)
     w13 = (torch.randn(2 * I, K, generator=g) * 0.08).to(BF)
     h = _exact(x, w13).to(BF)
     ref = F.silu(h[:, :I]) * h[:, I:]
     ws = ops.AttnWorkspace(DEV)
-    y = ops.linear(x.to(DEV), w13.to(DEV), swiglu=True, workspace=ws).cpu()
+    wd = ops.PackedWeight(w13.to(DEV), swiglu=True) if packed else w13.to(DEV)
+    y = ops.linear(x.to(DEV), wd, swiglu=True, workspace=ws).cpu()
     assert y.shape == (M, I)
-    ulp = bf16_ulp(ref.double())
-    d = ((y.double() - ref.double()).abs() / ulp)
     eq = float((y == ref).double().mean())
-    parity_report(f"[gemm] swiglu M={M} I={I} K={K}: bit-equal {100 * eq:.3f}%  max diff {float(d.max()):.2f} ulp")
-    assert eq >= 0.99 and float(d.max()) <= 3.0
+    ok = _matches_some_neighbour(y, lambda a, b: F.silu(a) * b, h[:, :I], h[:, I:])
+    parity_report(f"[gemm] swiglu M={M} I={I} K={K} packed={int(packed)}: bit-equal to the correctly rounded sequence "
+                  f"{100 * eq:.3f}%; the rest explained by a 1-ulp neighbour of h1/h3: {bool(ok.all())}")
+    assert eq >= 0.999 and bool(ok.all())
 
 
 @pytest.mark.parametrize("M,N,K,swiglu", [(8, 256, 256, False), (64, 1024, 1024, False), (200, 128, 384, False),
                                           (64, 512, 512, True)])
 def test_linear_int8_weight_only(ops, M, N, K, swiglu):
     """WeightOnlyInt8Linear.forward (Engine/quantize.py:84-86): F.linear(x, w_int8.to(bf16)) * scales -- the GEMM output
-    is rounded to bf16, then multiplied by the bf16 per-channel scale in bf16.  Weights convert exactly; gate: equal
-    to that sequence on the correctly rounded GEMM output up to 2 ulps, >= 99 % bit-equal."""
+    is rounded to bf16, then multiplied by the bf16 per-channel scale in bf16.  Weights convert exactly; gate: >= 99.9 %
+    bit-equal to that sequence on the correctly rounded GEMM output, the rest explained by its 1-ulp neighbours."""
     g = torch.Generator().manual_seed(M + N + K)
     x = torch.randn(M, K, generator=g).to(BF)
     wq = torch.randint(-128, 128, (N, K), generator=g, dtype=torch.int8)
     sc = (torch.rand(N, generator=g) * 0.01 + 0.001).to(BF)
-    h = _exact(x, wq.to(BF)).to(BF) * sc
-    ref = F.silu(h[:, :N // 2]) * h[:, N // 2:] if swiglu else h
+    g0 = _exact(x, wq.to(BF)).to(BF)
+    h = g0 * sc
+    I = N // 2
+    ref = F.silu(h[:, :I]) * h[:, I:] if swiglu else h
     ws = ops.AttnWorkspace(DEV)
-    y = ops.linear(x.to(DEV), wq.to(DEV), scales=sc.to(DEV), swiglu=swiglu, workspace=ws).cpu()
-    ulp = bf16_ulp(ref.double())
-    d = ((y.double() - ref.double()).abs() / ulp)
-    eq = float((y == ref).double().mean())
-    parity_report(f"[gemm] int8 M={M} N={N} K={K} swiglu={int(swiglu)}: bit-equal {100 * eq:.3f}%  max diff "
-                  f"{float(d.max()):.2f} ulp")
-    assert eq >= 0.99 and float(d.max()) <= (3.0 if swiglu else 2.0)
+    wd = ops.PackedWeight(wq.to(DEV), swiglu=swiglu)
+    for tag, wdev in (("rowmajor", wq.to(DEV)), ("packed", wd)):
+        y = ops.linear(x.to(DEV), wdev, scales=sc.to(DEV), swiglu=swiglu, workspace=ws).cpu()
+        eq = float((y == ref).double().mean())
+        if swiglu:
+            ok = _matches_some_neighbour(y, lambda a, b: F.silu(a * sc[:I]) * (b * sc[I:]), g0[:, :I], g0[:, I:])
+        else:
+            ok = _matches_some_neighbour(y, lambda a, b: a * sc, g0)
+        parity_report(f"[gemm] int8 M={M} N={N} K={K} swiglu={int(swiglu)} {tag}: bit-equal {100 * eq:.3f}%; rest "
+                      f"explained by 1-ulp neighbours of the GEMM output: {bool(ok.all())}")
+        assert eq >= 0.999 and bool(ok.all())
 
 
 def test_linear_full_size_and_determinism(ops):
@@ -111,7 +141,8 @@ def test_linear_full_size_and_determinism(ops):
         ws = ops.AttnWorkspace(DEV)
         y1 = ops.linear(x, w, workspace=ws)
         y2 = ops.linear(x, w, workspace=ws)
-        assert torch.equal(y1, y2)
+        y3 = ops.linear(x, ops.PackedWeight(w), workspace=ws)
+        assert torch.equal(y1, y2) and torch.equal(y1, y3), "row-major and streaming layouts must give the same bits"
         ref = x.double() @ w.double().t()
         mag = x.double().abs() @ w.double().abs().t()
         err = (y1.double() - ref).abs()

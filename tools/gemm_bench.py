@@ -18,7 +18,7 @@ ap.add_argument("--blocks", type=int, nargs="+", default=[512])
 ap.add_argument("--only", default="")
 ap.add_argument("--iters", type=int, default=30)
 a = ap.parse_args()
-enable_tuned_gemms()
+print('tuned GEMM table loaded:', enable_tuned_gemms())
 dev = "cuda"
 SHAPES = [("1B wqkv", 64, 3072, 2048, 0), ("1B wo", 64, 2048, 2048, 0), ("1B w13", 64, 16384, 2048, 1),
           ("1B w2", 64, 2048, 8192, 0), ("1B head", 64, 128256, 2048, 0),
@@ -33,21 +33,34 @@ SHAPES = [("1B wqkv", 64, 3072, 2048, 0), ("1B wo", 64, 2048, 2048, 0), ("1B w13
 
 
 def timeit(fn, n):
+    """Device time per call with the calls captured into ONE hipGraph (what the engine does with a decode step): eager
+    launching would measure the host (~10-15 us per call through ctypes + two launches) for the small shapes."""
     for i in range(3):
         fn(i)
     torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        with torch.cuda.graph(g, stream=s):
+            for i in range(n):
+                fn(i)
+    torch.cuda.synchronize()
+    g.replay()
+    torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    reps = 3
     e0.record()
-    for i in range(n):
-        fn(i)
+    for _ in range(reps):
+        g.replay()
     e1.record()
     torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / n * 1e3
+    return e0.elapsed_time(e1) / (n * reps) * 1e3
 
 
 lib = _lib.load()
 ws = ops.AttnWorkspace(dev)
-print(f"{'shape':14s} {'M':>4s} {'N':>6s} {'K':>6s} | hipBLASLt us  TB/s |" + "".join(f" md_linear@{b} us  TB/s |" for b in a.blocks))
+print(f"{'shape':14s} {'M':>4s} {'N':>6s} {'K':>6s} | hipBLASLt us  TB/s |" + "".join(f" md_linear@{b}: row-major us TB/s / packed us TB/s |" for b in a.blocks))
 for name, M, N, K, swiglu in SHAPES:
     if a.only and a.only not in name:
         continue
@@ -62,9 +75,12 @@ for name, M, N, K, swiglu in SHAPES:
         return ops.silu_mul(h[:, :I], h[:, I:]) if swiglu else h
     t_ref = timeit(ref, a.iters)
     line = f"{name:14s} {M:4d} {N:6d} {K:6d} | {t_ref:9.1f} {nbytes / t_ref / 1e6:6.2f} |"
+    plist = [ops.PackedWeight(w, swiglu=bool(swiglu)) for w in wlist]
     for b in a.blocks:
         lib.md_debug_set_gemm_target_blocks(ctypes.c_int(b))
         t = timeit(lambda i: ops.linear(x, wlist[i % ncopy], swiglu=bool(swiglu), workspace=ws), a.iters)
-        line += f" {t:14.1f} {nbytes / t / 1e6:6.2f} |"
+        tp = timeit(lambda i: ops.linear(x, plist[i % ncopy], swiglu=bool(swiglu), workspace=ws), a.iters)
+        line += f" {t:7.1f} {nbytes / t / 1e6:5.2f} / packed {tp:7.1f} {nbytes / tp / 1e6:5.2f} |"
+    del plist
     print(line, flush=True)
     del wlist
