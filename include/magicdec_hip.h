@@ -206,7 +206,7 @@ int md_silu_mul(const void* a, const void* b, int64_t a_row_stride, int64_t b_ro
  *     reference: nn.Linear calls of a decode step -- Attention.wqkv / wo, FeedForward.w1 / w3 / w2, Transformer.output
  *     (Engine/SnapKV/model.py:288-289,446-455,175-177) and WeightOnlyInt8Linear.forward (Engine/quantize.py:84-86)
  * Weight-streaming skinny GEMM (csrc/gemm.hip): W rows go global -> registers in MFMA operand layout, activations
- * through LDS, fp32 accumulation, split-K combined in-kernel by the last-arriving slice in a fixed order (deterministic).
+ * through LDS, fp32 accumulation, split-K with a fixed-order combine (deterministic).
  *   w_dtype  MD_W_BF16: w is bf16 [N][K];  MD_W_INT8: w is int8 [N][K] with bf16 per-row `scales` [N]
  *            (out = bf16(bf16(x.w^T) * scale), the reference's rounding points)
  *   epilogue MD_EPI_NONE: out[M][N] = bf16(acc + bias)   (bias bf16 [N] or NULL)
@@ -227,13 +227,9 @@ int md_silu_mul(const void* a, const void* b, int64_t a_row_stride, int64_t b_ro
 int md_linear_supported(int M, int N, int K, int epilogue);
 size_t md_linear_workspace_bytes(int M, int N, int K, int epilogue);
 void md_debug_set_gemm_target_blocks(int n); /* development: split-K policy (workgroups to aim for) */
-#define MD_LINEAR_MAX_COLUMN_BLOCKS 4096
-/* counters: MD_LINEAR_MAX_COLUMN_BLOCKS int32, zero-initialised ONCE by the caller and left zero by every call (the
- * arrival tickets of the split-K slices; the last slice of a column block to arrive combines all slices in slice
- * order, so the result does not depend on the arrival order).  May be NULL when the workspace query returned 0. */
 int md_linear(const void* x, int64_t ldx, const void* w, int w_dtype, int w_packed, const void* scales,
               const void* bias, void* out, int64_t ldo, int M, int N, int K, int epilogue, void* workspace,
-              size_t workspace_bytes, int32_t* counters, md_stream_t stream);
+              size_t workspace_bytes, md_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * K10  argmax over a vocab shard / TP merge

@@ -45,7 +45,7 @@ _SIGNATURES = {
     "md_linear_supported": (c_int, [I, I, I, I]),
     "md_linear_workspace_bytes": (c_size_t, [I, I, I, I]),
     "md_debug_set_gemm_target_blocks": (None, [I]),
-    "md_linear": (c_int, [P, L, P, I, I, P, P, P, L, I, I, I, I, P, c_size_t, P, P]),
+    "md_linear": (c_int, [P, L, P, I, I, P, P, P, L, I, I, I, I, P, c_size_t, P]),
     "md_rmsnorm": (c_int, [P, P, P, I, I, c_float, P]),
     "md_add_rmsnorm": (c_int, [P, P, P, P, P, I, I, c_float, P]),
     "md_silu_mul": (c_int, [P, P, L, L, P, I, I, P]),

@@ -40,8 +40,7 @@ struct GemmParams {
     const bf16_t* bias;   // [N] or null
     const bf16_t* scales; // [N] bf16 per-output-channel scales (int8 weights) or null
     bf16_t* out;          // [M][Nout], row stride ldo
-    float* partial;       // [S][column blocks][M][128] fp32 slabs when S > 1
-    int* counters;        // [column blocks] arrival tickets of the split-K slices (zero between calls)
+    float* partial;       // [S][M][N] fp32 when S > 1
     int64_t ldx, ldo;
     int M, N, K, kblk, S, Nout;
     int packed;           // W is in the fragment-major streaming layout (md_pack_weight layout, see md_linear)
@@ -194,79 +193,17 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(const GemmParams p) {
 
     // ---- epilogue.  acc[mt][r] = D[row = mt*32 + (r&3) + 8*(r>>2) + 4*kh][column j of the wave]
     if (p.S > 1) {
-        // Split-K: every slice writes its fp32 tile [M][128 block columns] to its own slab; the LAST slice of a column
-        // block to arrive (ticket counter) adds the S slabs IN SLICE ORDER -- the same bits whoever is last -- and
-        // applies the epilogue.  Publish / consume exactly as MI355X_MICROARCH.md prescribes for cross-XCD hand-offs:
-        // plain stores -> vmcnt(0) -> barrier -> lane 0: agent release fence, vmcnt(0), relaxed ticket; the last
-        // arriver: agent acquire fence -> barrier -> plain loads.
-        float* slab = p.partial + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * ((int64_t)p.M * 128);
+        float* pp = p.partial + (int64_t)blockIdx.y * p.M * p.N;
+        const int n = (EPI == EPI_SWIGLU) ? col : out_col;
+        const bool ok = (EPI == EPI_SWIGLU) ? ((blockIdx.x * 4 + wave) * 16 + (j & 15) < (p.N >> 1)) : (out_col >= 0);
+        if (ok) {
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
+            for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-                if (row < p.M) slab[row * 128 + wave * 32 + j] = acc[mt][r];
-            }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        int* flag = reinterpret_cast<int*>(lds);          // the slabs are dead: reuse LDS (one __shared__ object only)
-        if (tid == 0) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            *flag = __hip_atomic_fetch_add(&p.counters[blockIdx.x], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        __syncthreads();
-        if (*reinterpret_cast<volatile int*>(flag) != p.S - 1) return;
-        if (tid == 0) {
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            __hip_atomic_store(&p.counters[blockIdx.x], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // next call
-        }
-        __syncthreads();
-        const int64_t sstride = (int64_t)gridDim.x * p.M * 128;
-        const float* base = p.partial + (int64_t)blockIdx.x * ((int64_t)p.M * 128);
-        if constexpr (EPI == EPI_SWIGLU) {
-            // 64 output columns per block: thread -> (row, group q of 4 columns): h1 at wave*32 + c, h3 at +16
-            const int q = tid & 15, w = q >> 2, c = (q & 3) * 4;
-            const int i0 = (blockIdx.x * 4 + w) * 16 + c;
-            for (int row = tid >> 4; row < p.M; row += 16) {
-                f32x4 a = {0.f, 0.f, 0.f, 0.f}, b3 = {0.f, 0.f, 0.f, 0.f};
-                for (int sl = 0; sl < p.S; ++sl) {
-                    const float* pp = base + sl * sstride + row * 128 + w * 32 + c;
-                    a += *reinterpret_cast<const f32x4*>(pp);
-                    b3 += *reinterpret_cast<const f32x4*>(pp + 16);
+                for (int r = 0; r < 16; ++r) {
+                    const int row = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                    if (row < p.M) pp[(int64_t)row * p.N + n] = acc[mt][r];
                 }
-                if (i0 < p.Nout) {
-                    bf16x4 o;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        float h1 = bf16_to_f32(f32_to_bf16(a[e])), h3 = bf16_to_f32(f32_to_bf16(b3[e]));
-                        if (W8) {
-                            h1 = bf16_to_f32(f32_to_bf16(h1 * bf16_to_f32(p.scales[i0 + e])));
-                            h3 = bf16_to_f32(f32_to_bf16(h3 * bf16_to_f32(p.scales[p.Nout + i0 + e])));
-                        }
-                        o[e] = f32_to_bf16(silu_bf16(h1) * h3);
-                    }
-                    *reinterpret_cast<bf16x4*>(p.out + (int64_t)row * p.ldo + i0) = o;
-                }
-            }
-        } else {
-            const int c = (tid & 31) * 4;
-            const int n0 = blockIdx.x * 128 + c;
-            for (int row = tid >> 5; row < p.M; row += 8) {
-                f32x4 a = {0.f, 0.f, 0.f, 0.f};
-                for (int sl = 0; sl < p.S; ++sl) a += *reinterpret_cast<const f32x4*>(base + sl * sstride + row * 128 + c);
-                if (n0 < p.N) {          // N % 4 == 0: a group of 4 columns is inside or outside as a whole
-                    bf16x4 o;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        float v = a[e];
-                        if (p.bias) v += bf16_to_f32(p.bias[n0 + e]);
-                        if (W8) v = bf16_to_f32(f32_to_bf16(v)) * bf16_to_f32(p.scales[n0 + e]);
-                        o[e] = f32_to_bf16(v);
-                    }
-                    *reinterpret_cast<bf16x4*>(p.out + (int64_t)row * p.ldo + n0) = o;
-                }
-            }
         }
         return;
     }
@@ -292,6 +229,42 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(const GemmParams p) {
             }
             if (out_col >= 0 && row < p.M) p.out[(int64_t)row * p.ldo + out_col] = f32_to_bf16(v);
         }
+}
+
+// Fixed-order combine of the S fp32 partials + epilogue.  One thread per 4 consecutive output columns of one row.
+template <int EPI, bool W8>
+__global__ __launch_bounds__(256) void skinny_reduce_kernel(const GemmParams p) {
+    const int Nout = p.Nout;
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int per_row = Nout / 4;
+    if (t >= (int64_t)p.M * per_row) return;
+    const int row = (int)(t / per_row), c0 = (int)(t % per_row) * 4;
+    const int64_t plane = (int64_t)p.M * p.N;
+    f32x4 a = {0.f, 0.f, 0.f, 0.f}, b3 = {0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < p.S; ++s) {
+        const float* pp = p.partial + s * plane + (int64_t)row * p.N + c0;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(pp);
+        a += v;
+        if constexpr (EPI == EPI_SWIGLU) b3 += *reinterpret_cast<const f32x4*>(pp + (p.N >> 1));
+    }
+    bf16x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        float v = a[e];
+        if constexpr (EPI == EPI_SWIGLU) {
+            float h1 = bf16_to_f32(f32_to_bf16(v)), h3 = bf16_to_f32(f32_to_bf16(b3[e]));
+            if (W8) {
+                h1 = bf16_to_f32(f32_to_bf16(h1 * bf16_to_f32(p.scales[c0 + e])));
+                h3 = bf16_to_f32(f32_to_bf16(h3 * bf16_to_f32(p.scales[(p.N >> 1) + c0 + e])));
+            }
+            v = silu_bf16(h1) * h3;
+        } else {
+            if (p.bias) v += bf16_to_f32(p.bias[c0 + e]);
+            if (W8) v = bf16_to_f32(f32_to_bf16(v)) * bf16_to_f32(p.scales[c0 + e]);
+        }
+        o[e] = f32_to_bf16(v);
+    }
+    *reinterpret_cast<bf16x4*>(p.out + (int64_t)row * p.ldo + c0) = o;
 }
 
 int g_target_blocks = 256;   // split-K is chosen so that about this many workgroups exist (1 per CU: measured best)
@@ -324,6 +297,10 @@ int launch(const GemmParams& p, int n_blocks, hipStream_t st) {
         }
     }
     hipLaunchKernelGGL(k, dim3(n_blocks, p.S), dim3(256), lds, st, p);
+    if (p.S > 1) {
+        const int64_t threads = (int64_t)p.M * (p.Nout / 4);
+        hipLaunchKernelGGL((skinny_reduce_kernel<EPI, W8>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, p);
+    }
     return MD_OK;
 }
 
@@ -343,9 +320,8 @@ extern "C" size_t md_linear_workspace_bytes(int M, int N, int K, int epilogue) {
     if (M <= 0 || N <= 0 || K <= 0 || K % kSlabK) return 0;
     const int nout = epilogue == EPI_SWIGLU ? N / 2 : N;
     const int cols_per_block = epilogue == EPI_SWIGLU ? 64 : 128;
-    const int nb = (nout + cols_per_block - 1) / cols_per_block;
-    const int S = pick_splits(nb, K);
-    return S > 1 ? (size_t)S * nb * M * 128 * 4 : 0;     // fp32 slabs [S][column blocks][M][128]
+    const int S = pick_splits((nout + cols_per_block - 1) / cols_per_block, K);
+    return S > 1 ? (size_t)S * M * N * 4 : 0;     // fp32 partial sums of the K slices
 }
 
 extern "C" int md_linear_supported(int M, int N, int K, int epilogue) {
@@ -356,7 +332,7 @@ extern "C" int md_linear_supported(int M, int N, int K, int epilogue) {
 
 extern "C" int md_linear(const void* x, int64_t ldx, const void* w, int w_dtype, int w_packed, const void* scales,
                          const void* bias, void* out, int64_t ldo, int M, int N, int K, int epilogue, void* workspace,
-                         size_t workspace_bytes, int32_t* counters, md_stream_t stream) {
+                         size_t workspace_bytes, md_stream_t stream) {
     MD_CHECK_ARG(x && w && out, "md_linear: null pointer argument");
     MD_CHECK_ARG(md_linear_supported(M, N, K, epilogue), "md_linear: unsupported shape M=%d N=%d K=%d epilogue=%d "
                  "(need 1 <= M <= 256, K %% 128 == 0, N %% 4 == 0)", M, N, K, epilogue);
@@ -384,13 +360,9 @@ extern "C" int md_linear(const void* x, int64_t ldx, const void* w, int w_dtype,
     p.S = pick_splits(n_blocks, K);
     p.kblk = K / p.S;
     p.partial = (float*)workspace;
-    p.counters = counters;
     if (p.S > 1) {
-        const size_t need = (size_t)p.S * n_blocks * M * 128 * 4;
-        MD_CHECK_ARG(workspace && workspace_bytes >= need && (((uintptr_t)workspace) & 15) == 0,
-                     "md_linear: workspace too small (need %zu bytes) or not 16-byte aligned", need);
-        MD_CHECK_ARG(counters && n_blocks <= MD_LINEAR_MAX_COLUMN_BLOCKS,
-                     "md_linear: split-K needs the zero-initialised ticket array (%d int32)", MD_LINEAR_MAX_COLUMN_BLOCKS);
+        MD_CHECK_ARG(workspace && workspace_bytes >= (size_t)p.S * M * N * 4 && (((uintptr_t)workspace) & 15) == 0,
+                     "md_linear: workspace too small (need %zu bytes) or not 16-byte aligned", (size_t)p.S * M * N * 4);
     }
     hipStream_t st = (hipStream_t)stream;
     int rc;

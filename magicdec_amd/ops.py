@@ -160,8 +160,6 @@ class AttnWorkspace:
         self.device = device
         self.buf = torch.empty(1 << 20, dtype=torch.uint8, device=device)
         self._retired = []     # outgrown buffers stay allocated: captured hipGraphs have their addresses baked in
-        # split-K arrival tickets of md_linear: zero here, left zero by every call (include/magicdec_hip.h)
-        self.counters = torch.zeros(4096, dtype=torch.int32, device=device)
 
     def get(self, nbytes):
         if self.buf.numel() < nbytes:
@@ -330,8 +328,7 @@ def linear(x, weight, bias=None, scales=None, swiglu=False, workspace: "AttnWork
         off = (-ws.data_ptr()) % 256
     check(lib.md_linear(_p(x), x.stride(0), _p(wt), wd, 1 if packed else 0, _p(scales), _p(bias), _p(out),
                         out.stride(0), M, N, K, epi,
-                        ctypes.c_void_p(ws.data_ptr() + off) if ws is not None else None, nbytes,
-                        _p(workspace.counters) if workspace is not None else None, _stream()),
+                        ctypes.c_void_p(ws.data_ptr() + off) if ws is not None else None, nbytes, _stream()),
           "md_linear")
     return out
 
