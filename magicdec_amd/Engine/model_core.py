@@ -299,6 +299,25 @@ class Transformer(nn.Module):
                 ff.w3.weight = nn.Parameter(w13[inter:], requires_grad=False)
                 self._s13.append(None)
             self._w13.append(w13)
+        self._pack_weights()
+
+    def _pack_weights(self):
+        """Streaming-layout copies (ops.PackedWeight) of the weights md_linear serves in decode / verify steps
+        (Engine/gemm_policy.py); keyed by the id of the row-major tensor the step would otherwise use."""
+        from .gemm_policy import want_packed
+        self._packed = {}
+        if not self.output.weight.is_cuda:
+            return
+
+        def pack(w, swiglu=False):
+            if want_packed(w.shape[0], w.shape[1]):
+                self._packed[id(w)] = ops.PackedWeight(w.data if isinstance(w, nn.Parameter) else w, swiglu=swiglu)
+        for i, b in enumerate(self.layers):
+            pack(self._w13[i], swiglu=True)
+            pack(b.attention.wqkv.weight)
+            pack(b.attention.wo.weight)
+            pack(b.feed_forward.w2.weight)
+        pack(self.output.weight)
 
     # ------------------------------------------------------------------ building blocks
     def _reduce(self, y, group):
@@ -325,8 +344,10 @@ class Transformer(nn.Module):
         M, K = x2d.shape
         N = w.shape[0]
         swiglu = swiglu_w13 is not None
-        if x2d.is_cuda and use_skinny(M, N, K, swiglu, w.dtype == torch.int8) and ops.linear_supported(M, N, K, swiglu):
-            return ops.linear(x2d, w, bias, scales, swiglu, self.workspace)
+        pk = self._packed.get(id(w))
+        if (x2d.is_cuda and use_skinny(M, N, K, swiglu, w.dtype == torch.int8, pk is not None)
+                and ops.linear_supported(M, N, K, swiglu)):
+            return ops.linear(x2d, pk if pk is not None else w, bias, scales, swiglu, self.workspace)
         if w.dtype == torch.int8:      # WeightOnlyInt8Linear.forward (Engine/quantize.py:84-86), dequantised on the fly
             h = F.linear(x2d, w.to(dtype=x2d.dtype)) * scales
         else:

@@ -602,7 +602,30 @@ def scen_pg19():
     print({k: v["shape"] for k, v in out.items()})
 
 
-SCENARIOS = {"pg19": scen_pg19, "convert_hf": scen_convert_hf, "mylib_schemas": scen_mylib_schemas, "snapkv_select": scen_snapkv_select, "stream_prefill": scen_stream_prefill,
+def scen_int8_quant():
+    """The REAL Engine/quantize.py: dynamically_quantize_per_channel (:7-41) on a seeded weight matrix (rows with
+    all-zero, all-negative and huge entries included) and WeightOnlyInt8Linear.forward (:84-86) on seeded activations."""
+    import hashlib
+    Q = ref_import.module("Engine.quantize")
+    g = torch.Generator().manual_seed(31)
+    w = torch.randn(96, 256, generator=g) * 0.05
+    w[3] = 0.0
+    w[5] = -w[5].abs()
+    w[7, 11] = 40.0
+    q, sc, zp = Q.dynamically_quantize_per_channel(w.float(), -128, 127, torch.int8)
+    lin = Q.WeightOnlyInt8Linear(256, 96)
+    lin.weight, lin.scales = q, sc.to(BF16)
+    x = torch.randn(5, 256, generator=g).to(BF16)
+    y = lin(x)
+    h = lambda t: hashlib.sha256(t.contiguous().view(torch.uint8).numpy().tobytes()).hexdigest()
+    out = dict(q_sha=h(q), scales_sha=h(sc), scales_bf16_sha=h(sc.to(BF16)), y_sha=h(y), q_row7=q[7].tolist(),
+               scales_head=sc[:8].tolist(), zp_all_zero=bool((zp == 0).all()), y_dtype=str(y.dtype))
+    with open(GOLD / "int8_quant.json", "w") as f:
+        json.dump(out, f)
+    print({k: (v if not isinstance(v, list) else len(v)) for k, v in out.items()})
+
+
+SCENARIOS = {"int8_quant": scen_int8_quant, "pg19": scen_pg19, "convert_hf": scen_convert_hf, "mylib_schemas": scen_mylib_schemas, "snapkv_select": scen_snapkv_select, "stream_prefill": scen_stream_prefill,
              "accept_loop": scen_accept_loop, "tp_shapes": scen_tp_shapes}
 RUNS = ["run_longspec_snapkv", "run_longspec_snapkv_rej", "run_longspec_stream", "run_selfspec_snapkv",
         "run_selfspec_stream", "run_baseline", "run_longspec_stream_tp2", "run_longspec_snapkv_tp2",

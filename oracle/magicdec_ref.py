@@ -131,8 +131,11 @@ LINEAR_MODE = "fp32"     # "fp32": torch CPU bf16 linear (fp32 accumulation in t
 #                          yardstick the HIP engine's logits are gated with (tests/test_gpu_engine.py).
 
 
-def linear(x, w, b=None):
-    """F.linear at the reference's rounding points (bf16 in, bf16 out), see LINEAR_MODE."""
+def linear(x, w, b=None, scales=None):
+    """F.linear at the reference's rounding points (bf16 in, bf16 out), see LINEAR_MODE.  int8 `w` with per-row
+    `scales`: WeightOnlyInt8Linear.forward (Engine/quantize.py:84-86) = F.linear(x, w.to(x.dtype)) * scales."""
+    if w.dtype == torch.int8:
+        return linear(x, w.to(x.dtype), b) * scales
     if LINEAR_MODE == "fp64":
         y = x.double() @ w.double().t()
         if b is not None:
@@ -148,9 +151,9 @@ def rmsnorm(x, weight, eps):
     return y * weight
 
 
-def feed_forward(x, w1, w3, w2):
+def feed_forward(x, w1, w3, w2, s1=None, s3=None, s2=None):
     """Engine/SnapKV/model.py:451-455."""
-    return linear(F.silu(linear(x, w1)) * linear(x, w3), w2)
+    return linear(F.silu(linear(x, w1, None, s1)) * linear(x, w3, None, s3), w2, None, s2)
 
 
 FP8_MAX, FP8_MARGIN = 448.0, 1.5
@@ -347,7 +350,7 @@ class RefModel:
         p = f"layers.{i}.attention."
         B, n, _ = x.shape
         kv = c.n_local_heads * c.head_dim
-        y = linear(x, self.sd[p + "wqkv.weight"], self.sd.get(p + "wqkv.bias"))
+        y = linear(x, self.sd[p + "wqkv.weight"], self.sd.get(p + "wqkv.bias"), self.sd.get(p + "wqkv.scales"))
         q, k, v = y.split([c.n_head * c.head_dim, kv, kv], dim=-1)
         return (q.reshape(B * n, c.n_head, c.head_dim), k.reshape(B * n, c.n_local_heads, c.head_dim),
                 v.reshape(B * n, c.n_local_heads, c.head_dim))
@@ -365,17 +368,19 @@ class RefModel:
         p = f"layers.{i}."
         B, n, _ = x.shape
         y = attn_fn(rmsnorm(x, self.sd[p + "attention_norm.weight"], self.cfg.norm_eps), i)
-        y = self._all_reduce(linear(y.reshape(B, n, -1), self.sd[p + "attention.wo.weight"]))
+        y = self._all_reduce(linear(y.reshape(B, n, -1), self.sd[p + "attention.wo.weight"], None,
+                                    self.sd.get(p + "attention.wo.scales")))
         h = x + y
         f = feed_forward(rmsnorm(h, self.sd[p + "ffn_norm.weight"], self.cfg.norm_eps),
                          self.sd[p + "feed_forward.w1.weight"], self.sd[p + "feed_forward.w3.weight"],
-                         self.sd[p + "feed_forward.w2.weight"])
+                         self.sd[p + "feed_forward.w2.weight"], self.sd.get(p + "feed_forward.w1.scales"),
+                         self.sd.get(p + "feed_forward.w3.scales"), self.sd.get(p + "feed_forward.w2.scales"))
         return h + self._all_reduce(f)
 
     def head(self, x, return_logits=False):
         """:175-188 final norm -> lm head -> argmax (TP: merge of per-rank maxima)."""
         x = rmsnorm(x, self.sd["norm.weight"], self.cfg.norm_eps)
-        logits = linear(x, self.sd["output.weight"])
+        logits = linear(x, self.sd["output.weight"], None, self.sd.get("output.scales"))
         self.last_logits = logits          # kept for tie-aware token comparisons in tests
         if return_logits:
             return logits

@@ -414,6 +414,60 @@ def test_cfg5_layout_lockstep_qwen_selfspec_snapkv_fp8_cache():
     assert frac <= 0.02
 
 
+def test_lockstep_with_every_linear_on_the_skinny_gemm(ckpt_dir):
+    """MAGICDEC_GEMM=hip: every linear of the decode / verify steps (wqkv, wo, w1|w3 + fused SiLU*mul, w2, lm head)
+    runs on md_linear over the streaming weight layout instead of hipBLASLt; same lock-step gates as the default
+    policy (the tiny models are below the policy's size threshold, so this is the engine-level test of the kernel)."""
+    from magicdec_amd.Engine import gemm_policy
+    cfg, sd = gc.tiny("tinytgt")
+    log = []
+    tgt = Recorder(mr.RefEngine("target", cfg, sd, gc.B, gc.MAX_LEN), "T", log)
+    drf = Recorder(mr.RefEngine("snapkv_draft", cfg, sd, gc.B, gc.MAX_LEN, gc.BUDGET), "D", log)
+    hr.longspec_batch(tgt, drf, gc.synthetic_batches()[0], gc.GAMMA, gc.MAX_LEN, gc.EOT_1, gc.EOT_2)
+    old = gemm_policy.mode()
+    gemm_policy.set_mode("hip")
+    try:
+        e_t, e_d = _hip("target", ckpt_dir), _hip("snapkv_draft", ckpt_dir)
+        assert len(e_t.model._packed) == 4 * cfg.n_layer + 1, "every weight should have a streaming-layout copy"
+        st = replay(log, {"T": e_t, "D": e_d}, {"T": _alt("target", cfg, sd, gc.B, gc.MAX_LEN),
+                                                 "D": _alt("snapkv_draft", cfg, sd, gc.B, gc.MAX_LEN, gc.BUDGET)})
+    finally:
+        gemm_policy.set_mode(old)
+    parity_report(st.line("longspec/snapkv, all linears md_linear"))
+
+
+def test_int8_weight_only_engine_lockstep():
+    """Weight-only int8 (Engine/quantize.py, "int8" in the checkpoint path -> Engine/utils.py:201-205): the tiny
+    target quantised per channel, loaded through the int8 loader, every linear streamed as int8 by md_linear with the
+    fused bf16 scale epilogue; lock-step against the oracle running F.linear(x, w.to(bf16)) * scales."""
+    from pathlib import Path
+    from magicdec_amd.Engine import model_core
+    from magicdec_amd.Engine.quantize import WeightOnlyInt8Linear, dynamically_quantize_per_channel
+    from magicdec_amd.Engine.SnapKV.backend import LMBackend
+    cfg, sd = gc.tiny("tinytgt")
+    qsd = {}
+    for k, v in sd.items():
+        if k.endswith(".weight") and v.dim() == 2 and "tok_embeddings" not in k:
+            q, sc, _ = dynamically_quantize_per_channel(v.float(), -128, 127, torch.int8)
+            qsd[k], qsd[k[:-len("weight")] + "scales"] = q, sc.to(torch.bfloat16)
+        else:
+            qsd[k] = v
+    d = tempfile.mkdtemp(prefix="md_ckpt_")
+    os.makedirs(os.path.join(d, "tinytgt-int8"))
+    torch.save(qsd, os.path.join(d, "tinytgt-int8", "model.pth"))
+    model_core.transformer_configs["tinytgt"] = gc.config_kwargs(cfg)
+    log = []
+    eng = Recorder(mr.RefEngine("target", cfg, qsd, gc.B, gc.MAX_LEN), "T", log)
+    hr.baseline_batch(eng, gc.synthetic_batches()[0], gc.S + 24, -1, -1)
+    e = LMBackend(dtype=torch.bfloat16, device=DEV)
+    e.load_model(Path(d) / "tinytgt-int8" / "model.pth", use_tp=False)
+    e.setup_caches(max_batch_size=gc.B, max_seq_length=gc.MAX_LEN)
+    assert isinstance(e.model.layers[0].attention.wqkv, WeightOnlyInt8Linear)
+    assert e.model.layers[0].feed_forward.w2.weight.dtype == torch.int8
+    st = replay(log, {"T": e}, {"T": _alt("target", cfg, qsd, gc.B, gc.MAX_LEN)})
+    parity_report(st.line("baseline, weight-only int8 linears"))
+
+
 def test_baseline_llama68m_shape_lockstep():
     """BASELINE.json configs[0]: llama-68m autoregressive baseline, B=1, prefix 129 (MHA, D=64, vocab 32000)."""
     from magicdec_amd.Engine.SnapKV.backend import LMBackend

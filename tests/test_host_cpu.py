@@ -535,6 +535,38 @@ def test_pg19_adapter_equals_the_reference(tag, bos):
         tokenize_pg19(pf.WordTokenizer(bos), seq_len=pf.SEQ_LEN, end=1, data_dir=d + "/", n_books=60)
 
 
+def test_int8_quantiser_and_linear_equal_the_reference():
+    """magicdec_amd.Engine.quantize against the REFERENCE's Engine/quantize.py on the same seeded inputs (fixture
+    tests/golden/int8_quant.json, oracle/gen_golden.py:scen_int8_quant): int8 weights, scales and the
+    WeightOnlyInt8Linear output (CPU path: F.linear(x, w.to(bf16)) * scales) byte-identical; the oracle's int8 linear
+    (the checker of the GPU path) gives the same bytes."""
+    import hashlib
+    from magicdec_amd.Engine import quantize as Q
+    from oracle import magicdec_ref as mr
+    want = gc.load_json("int8_quant.json")
+    g = torch.Generator().manual_seed(31)
+    w = torch.randn(96, 256, generator=g) * 0.05
+    w[3] = 0.0
+    w[5] = -w[5].abs()
+    w[7, 11] = 40.0
+    q, sc, zp = Q.dynamically_quantize_per_channel(w.float(), -128, 127, torch.int8)
+    h = lambda t: hashlib.sha256(t.contiguous().view(torch.uint8).numpy().tobytes()).hexdigest()
+    assert h(q) == want["q_sha"] and h(sc) == want["scales_sha"] and bool((zp == 0).all())
+    assert q[7].tolist() == want["q_row7"]
+    lin = Q.WeightOnlyInt8Linear(256, 96)
+    lin.weight, lin.scales = q, sc.to(torch.bfloat16)
+    x = torch.randn(5, 256, generator=g).to(torch.bfloat16)
+    assert h(lin(x)) == want["y_sha"]
+    assert h(mr.linear(x, q, None, sc.to(torch.bfloat16))) == want["y_sha"]
+    # handler: state dict keys / dtypes as the reference's create_quantized_state_dict
+    m = torch.nn.Sequential(torch.nn.Linear(256, 96, bias=False)).to(torch.bfloat16)
+    sd = Q.WeightOnlyInt8QuantHandler(m).create_quantized_state_dict()
+    assert sd["0.weight"].dtype == torch.int8 and sd["0.scales"].dtype == torch.bfloat16
+    m2 = Q.WeightOnlyInt8QuantHandler(m).convert_for_runtime()
+    m2.load_state_dict(sd)
+    assert isinstance(m2[0], Q.WeightOnlyInt8Linear)
+
+
 def test_fp8_kv_cache_host_logic(cpu_ops_patched, ckpt_dir):
     """kv_dtype="fp8" (BASELINE configs[4], not in the reference): the full cache is e4m3fn, scales are calibrated on
     the first prefill chunk, the compressed draft cache stays bf16, and teacher-forced logits stay close to the
