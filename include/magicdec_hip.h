@@ -270,28 +270,40 @@ int md_accept_rollback(int64_t* tokens_buffer, const int64_t* target_tokens, int
                        int64_t* cachelens_update, int32_t* flags, md_stream_t stream);
 
 /* ------------------------------------------------------------------------
- * C1  one-shot sum-all-reduce of bf16 partials over peer-mapped buffers (xGMI)
- *     reference: the two dist.all_reduce per layer, Engine/SnapKV/model.py:336,455
- *     (Attention.forward / FeedForward.forward) and the StreamingLLM twins; NCCL there.
- * One communicator per process group.  Set-up (host, once):
- *   md_ar_create      allocates this rank's registered data buffer (2 x max_bytes) and signal area;
+ * C1  the per-layer sum-all-reduce of the tensor-parallel decode path over xGMI peer-mapped buffers
+ *     reference: dist.all_reduce at Engine/SnapKV/model.py:334-335,453-454 (and the StreamingLLM twins), NCCL with
+ *     PyTorch's intra-node one-/two-shot kernels (README.md:59 ENABLE_INTRA_NODE_COMM=1); the fused form also
+ *     replaces the residual add + RMSNorm that consumes the result (model.py:260-278,464-469).
+ *   md_ar_create      allocates this rank's registered buffer (4 x max_bytes: two halves of published partials, two
+ *                     halves of two-shot results) and its signal area;
  *   md_ar_get_handles writes 2 IPC handles (data, signal; MD_AR_HANDLE_BYTES each) to handles_host;
- *                     the caller all-gathers them (any transport: torch.distributed / MPI / files);
+ *                     the caller exchanges them over its bootstrap transport (RCCL / gloo all-gather);
  *   md_ar_open_peers  takes the world x 2 handles in rank order and maps the peers' buffers.
- * md_allreduce_oneshot: out = sum over ranks of in (count bf16, multiple of 8, count*2 <= max_bytes;
- * in == out allowed), fp32 accumulation in rank order 0..world-1 -> bit-identical on every rank.
- * Asynchronous on `stream`, capturable into a hipGraph (the call counter lives in device memory).
- * All ranks of the communicator must issue the same sequence of calls.  A peer that never arrives makes
- * the kernel give up after ~2 s and set the status word (md_ar_status: 0 = ok, 1 = timed out) instead
- * of hanging the GPU.  Requires HSA_ENABLE_IPC_MODE_LEGACY=0 (dmabuf IPC) in the environment.
+ * md_allreduce: out = sum over ranks of in (count bf16, multiple of 8, count*2 <= max_bytes; in == out allowed).
+ *   algo MD_AR_ALGO_ONESHOT: every rank reads all N partials ((N-1) x message inbound, one hop);
+ *        MD_AR_ALGO_TWOSHOT: reduce-scatter + all-gather through the registered buffers (2(N-1)/N x message, two hops);
+ *        MD_AR_ALGO_AUTO:    two-shot for world >= 4 and messages > 512 KiB, else one-shot.
+ * md_allreduce_add_rmsnorm: h = bf16(resid + allreduce(partial)), y = rmsnorm(h) * weight ([rows, dim] bf16, dim <= 8192)
+ *   in the same launch (a wavefront owns a row).
+ * Every rank adds in rank order with fp32 accumulation and one rounding: all ranks get the same bits.  Calls are
+ * asynchronous on `stream`, graph-capturable (call counters live in device memory), and must be issued in the same
+ * order with the same sizes on every rank.  Spins are bounded (~2 s): on a time-out the kernel sets the status word
+ * (md_ar_status: 0 = ok, 1 = timed out) and writes NaN into the rows it could not complete -- a missing peer is
+ * never papered over; the host checks md_ar_status per batch and raises.
  * ---------------------------------------------------------------------- */
 #define MD_AR_HANDLE_BYTES 64
 #define MD_AR_MAX_RANKS 8
+#define MD_AR_ALGO_AUTO 0
+#define MD_AR_ALGO_ONESHOT 1
+#define MD_AR_ALGO_TWOSHOT 2
 typedef struct md_ar_comm md_ar_comm;
 int md_ar_create(int rank, int world, size_t max_bytes, md_ar_comm** comm_out);
 int md_ar_get_handles(md_ar_comm* comm, void* handles_host /* 2 * MD_AR_HANDLE_BYTES */);
 int md_ar_open_peers(md_ar_comm* comm, const void* all_handles_host /* world * 2 * MD_AR_HANDLE_BYTES */);
+int md_allreduce(md_ar_comm* comm, const void* in, void* out, size_t count, int algo, md_stream_t stream);
 int md_allreduce_oneshot(md_ar_comm* comm, const void* in, void* out, size_t count, md_stream_t stream);
+int md_allreduce_add_rmsnorm(md_ar_comm* comm, const void* partial, const void* resid, const void* weight,
+                             void* out_h, void* out_y, int rows, int dim, float eps, int algo, md_stream_t stream);
 int md_ar_status(md_ar_comm* comm, int* status_host);
 int md_ar_destroy(md_ar_comm* comm);
 

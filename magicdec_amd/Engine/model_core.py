@@ -357,6 +357,18 @@ class Transformer(nn.Module):
             return ops.silu_mul(h[:, :inter], h[:, inter:])
         return h
 
+    def _reduce_add_norm(self, partial, x, norm, group):
+        """all-reduce of a sub-layer's partial output (C1), residual add, RMSNorm for the next sub-layer:
+        (h, y) = (x + sum_ranks(partial), rmsnorm(h) * w).  With the xGMI all-reduce attached (tp.apply_tp,
+        MAGICDEC_ONESHOT_AR=1) and a decode-sized message this is ONE launch (md_allreduce_add_rmsnorm); otherwise
+        the collective (RCCL) followed by the fused add + norm kernel."""
+        if group is not None:
+            ar = getattr(self, "_oneshot", None)
+            if ar is not None and ar.fits_fused(partial, norm.weight) and x.is_contiguous():
+                return ar.all_reduce_add_rmsnorm(partial, x, norm.weight, norm.eps)
+            partial = self._reduce(partial, group)
+        return ops.add_rmsnorm(x, partial, norm.weight, norm.eps)
+
     def _qkv(self, layer, y2d):
         c = self.config
         att = layer.attention
@@ -370,7 +382,7 @@ class Transformer(nn.Module):
 
     def _mlp(self, i, layer, y2d):
         act = self._linear(y2d, None, swiglu_w13=(self._w13[i], self._s13[i]))
-        return self._reduce(self._linear(act, layer.feed_forward.w2), layer.feed_forward.process_group)
+        return self._linear(act, layer.feed_forward.w2)
 
     def _run(self, idx, attn_fn):
         """embed -> L x (norm, attention, +res, norm, mlp, +res) -> norm -> head -> argmax.
@@ -385,11 +397,11 @@ class Transformer(nn.Module):
         for i, layer in enumerate(layers):
             q, k, v, rows = self._qkv(layer, y)
             o = attn_fn(i, layer, q, k, v, n)
-            a = self._reduce(self._linear(o.view(rows, -1), layer.attention.wo), layer.attention.process_group)
-            x, y = ops.add_rmsnorm(x, a, layer.ffn_norm.weight, layer.ffn_norm.eps)
+            a = self._linear(o.view(rows, -1), layer.attention.wo)
+            x, y = self._reduce_add_norm(a, x, layer.ffn_norm, layer.attention.process_group)
             f = self._mlp(i, layer, y)
             nxt = layers[i + 1].attention_norm if i + 1 < len(layers) else self.norm
-            x, y = ops.add_rmsnorm(x, f, nxt.weight, nxt.eps)
+            x, y = self._reduce_add_norm(f, x, nxt, layer.feed_forward.process_group)
         if self.skip_head:
             return None
         logits = self._linear(y, self.output)                         # [rows, vocab / tp]

@@ -1,16 +1,20 @@
-"""C1 of SURVEY.md section 8e: one-shot sum-all-reduce of the per-layer bf16 partials over xGMI peer-mapped buffers
-(`md_allreduce_oneshot`, csrc/allreduce.hip), one communicator per process group.
+"""C1 of SURVEY.md section 8e: the per-layer sum-all-reduce of the bf16 partials over xGMI peer-mapped buffers
+(`md_allreduce` / `md_allreduce_add_rmsnorm`, csrc/allreduce.hip), one communicator per process group.
 
-Replaces `dist.all_reduce` at Engine/SnapKV/model.py:336,455 (and the StreamingLLM twins) for the latency-bound
-decode messages; anything larger than the registered buffer (prefill chunks) stays on RCCL.  RCCL / gloo is still
-the bootstrap transport: the IPC handles are exchanged with `dist.all_gather_object`.
+Replaces `dist.all_reduce` at Engine/SnapKV/model.py:334-335,453-454 (and the StreamingLLM twins) for the
+latency-bound decode messages -- one-shot for the small ones (a 1B draft step: 256 KiB), two-shot (reduce-scatter +
+all-gather through the registered buffers) for the 2 MiB verify message on >= 4 ranks -- and, fused into the same
+launch, the residual add + RMSNorm that consumes the result.  Anything larger than the registered buffer (prefill
+chunks) stays on RCCL.  RCCL / gloo is still the bootstrap transport: the IPC handles are exchanged with
+`dist.all_gather_object`.
 
-Selection: `MAGICDEC_ONESHOT_AR=1` asks for it (bench.py does for N > 1; the Engine default is RCCL).  The kernel and
-the IPC set-up are validated with 2 and 3 processes sharing one GPU (tests/test_gpu_allreduce.py) -- the only
-multi-process configuration available to the development box -- so on a real xGMI node `try_create` treats the
-first use as a probe: every stage (allocation, handle export, peer mapping) is agreed on collectively, then a
-self-test compares a few all-reduces with the bootstrap backend's (RCCL) results; any rank failing any stage makes
-ALL ranks fall back to RCCL, loudly."""
+Selection: `MAGICDEC_ONESHOT_AR=1` asks for it; the Engine default is RCCL.  The kernels and the IPC set-up are
+validated with 2 and 3 processes sharing one GPU (tests/test_gpu_allreduce.py) -- the only multi-process configuration
+available to the development box -- so on a real xGMI node `try_create` treats the first use as a probe: every stage
+(allocation, handle export, peer mapping) is agreed on collectively, then a self-test compares all-reduces of every
+algorithm with the bootstrap backend's (RCCL) results; any rank failing any stage makes ALL ranks fall back to RCCL,
+loudly.  A peer that goes missing later is never papered over: the kernel poisons its output with NaN and sets the
+status word, `check()` (called by the decode loops once per batch) raises."""
 from __future__ import annotations
 
 import ctypes
@@ -24,6 +28,11 @@ from .._lib import check
 
 HANDLE_BYTES = 64           # MD_AR_HANDLE_BYTES
 DEFAULT_MAX_BYTES = 4 << 20
+ALGO_AUTO, ALGO_ONESHOT, ALGO_TWOSHOT = 0, 1, 2      # MD_AR_ALGO_*
+
+
+class AllReduceTimeout(RuntimeError):
+    pass
 
 
 def enabled() -> bool:
@@ -105,16 +114,40 @@ class OneShotAllReduce:
         return (t.is_cuda and t.dtype == torch.bfloat16 and t.is_contiguous() and t.numel() % 8 == 0
                 and t.numel() * 2 <= self.max_bytes and t.data_ptr() % 16 == 0)
 
-    def all_reduce_(self, t: torch.Tensor) -> torch.Tensor:
+    def all_reduce_(self, t: torch.Tensor, algo: int = ALGO_AUTO) -> torch.Tensor:
         """In-place sum over the group (same result bits on every rank)."""
         if not self.fits(t):
             raise ValueError("OneShotAllReduce: tensor must be contiguous bf16 on the GPU, numel % 8 == 0, and fit "
                              f"the registered buffer ({self.max_bytes} bytes)")
         p = ctypes.c_void_p(t.data_ptr())
-        check(self.lib.md_allreduce_oneshot(self.comm, p, p, t.numel(),
-                                            ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)),
-              "md_allreduce_oneshot")
+        check(self.lib.md_allreduce(self.comm, p, p, t.numel(), int(algo),
+                                    ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "md_allreduce")
         return t
+
+    def fits_fused(self, partial: torch.Tensor, weight: torch.Tensor) -> bool:
+        return (partial.dim() == 2 and self.fits(partial) and partial.shape[1] % 8 == 0 and partial.shape[1] <= 8192
+                and weight.is_contiguous() and weight.dtype == torch.bfloat16)
+
+    def all_reduce_add_rmsnorm(self, partial, resid, weight, eps, algo: int = ALGO_AUTO):
+        """(h, y) with h = resid + all_reduce(partial) (bf16 add) and y = rmsnorm(h) * weight, one launch."""
+        rows, dim = partial.shape
+        if not self.fits_fused(partial, weight) or not resid.is_contiguous() or resid.shape != partial.shape:
+            raise ValueError("all_reduce_add_rmsnorm: [rows, dim] contiguous bf16 tensors, dim % 8 == 0, dim <= 8192")
+        h = torch.empty_like(partial)
+        y = torch.empty_like(partial)
+        pv = lambda t: ctypes.c_void_p(t.data_ptr())
+        check(self.lib.md_allreduce_add_rmsnorm(self.comm, pv(partial), pv(resid), pv(weight), pv(h), pv(y), rows, dim,
+                                                float(eps), int(algo),
+                                                ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)),
+              "md_allreduce_add_rmsnorm")
+        return h, y
+
+    def check(self):
+        """Raise if any call since the last check gave up waiting for a peer (its output rows are NaN).
+        Synchronises the device: call it per batch, not per step."""
+        if self.status() != 0:
+            raise AllReduceTimeout(f"rank {self.rank}: an xGMI all-reduce timed out waiting for a peer; the affected "
+                                   "hidden states were poisoned with NaN -- this rank's results are invalid")
 
     def self_test(self) -> bool:
         """Local verdict: a few all-reduces agree with the bootstrap backend's (different summation order, so a bf16
@@ -122,13 +155,13 @@ class OneShotAllReduce:
         dev = torch.device("cuda", torch.cuda.current_device())
         ok = True
         for k, n in enumerate((2048, 64 * 2048, min(256 * 4096, self.max_bytes // 2))):
-            for rep in range(2):                       # both halves of the double buffer
+            for rep, algo in enumerate((ALGO_ONESHOT, ALGO_TWOSHOT, ALGO_ONESHOT, ALGO_TWOSHOT)):   # both buffer halves
                 g = torch.Generator(device=dev).manual_seed(1000 * k + 10 * rep + self.rank)
                 x = torch.randn(n, device=dev, generator=g, dtype=torch.float32).to(torch.bfloat16)
                 ref = x.clone()
                 dist.all_reduce(ref, group=self.group)
                 y = x.clone()
-                self.all_reduce_(y)
+                self.all_reduce_(y, algo)
                 torch.cuda.synchronize()
                 tol = 2.0 ** -6 * float(ref.float().abs().max()) + 1e-3
                 ok = ok and bool((y.float() - ref.float()).abs().max() <= tol) and bool(torch.isfinite(y.float()).all())

@@ -38,6 +38,8 @@ _SIGNATURES = {
     "md_ar_get_handles": (c_int, [P, P]),
     "md_ar_open_peers": (c_int, [P, P]),
     "md_allreduce_oneshot": (c_int, [P, P, P, c_size_t, P]),
+    "md_allreduce": (c_int, [P, P, P, c_size_t, I, P]),
+    "md_allreduce_add_rmsnorm": (c_int, [P, P, P, P, P, P, I, I, c_float, I, P]),
     "md_ar_status": (c_int, [P, P]),
     "md_ar_destroy": (c_int, [P]),
     "md_streaming_shift_append": (c_int, [P, P, L, L, P, I, I, I, I, I, I, I, I, P]),

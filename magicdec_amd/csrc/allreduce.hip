@@ -1,106 +1,295 @@
-// C1: one-shot sum-all-reduce of the per-layer bf16 partials over peer-mapped buffers (xGMI), for the
-// tensor-parallel decode path.
+// C1: sum-all-reduce of the per-layer bf16 partials over peer-mapped buffers (xGMI), for the tensor-parallel decode
+// path -- one-shot and two-shot, optionally fused with the residual add + RMSNorm that follows it.
 //
-// Replaces the two `dist.all_reduce` per layer of the reference (Engine/SnapKV/model.py:336,455 and twins; NCCL
-// there).  The messages are tiny and latency-bound -- [B*(gamma+1), dim] bf16 = 2 MiB for the 8B verify step,
-// 256 KiB for a 1B draft step -- so a ring (2(N-1) hops over point-to-point xGMI links) pays ~N link latencies.
-// One-shot: every rank publishes its partial in an IPC-mapped buffer, raises one flag per peer, and then reads all
-// N partials directly and sums them itself: one hop.
+// Replaces the two `dist.all_reduce` per layer of the reference (Engine/SnapKV/model.py:334-335,453-454 and twins;
+// NCCL there, with ENABLE_INTRA_NODE_COMM one-/two-shot kernels per README.md:59) plus, in the fused form, the
+// `h = x + y ; norm(h)` that consumes the result (model.py:260-278).  The messages are small and latency-bound --
+// [B*(gamma+1), dim] bf16 = 2 MiB for the 8B verify step, 256 KiB for a 1B draft step -- and xGMI is point-to-point:
+// a ring pays 2(N-1) link latencies.
 //
-// Determinism: every rank adds the N partials in rank order 0..N-1 with fp32 accumulation
-// and one final rounding, so all ranks obtain bit-identical results (the replicated argmax / page tables need that).
+//   one-shot  every rank publishes its partial in an IPC-mapped buffer, raises a flag at every peer, then reads all
+//             N partials and sums them itself: one hop, (N-1) x message inbound per rank.  Right for <= 256 KiB.
+//   two-shot  rank r owns the rows r, r+N, ...: it sums only those over the N published partials (reduce-scatter),
+//             publishes the reduced rows in a second registered buffer, raises a second flag, and copies the other
+//             ranks' reduced rows (all-gather): two hops, 2(N-1)/N x message inbound.  Right for the 2 MiB verify
+//             message at N = 8 (3.5 MiB instead of 14 MiB per rank).
 //
-// Protocol per call k (flag = k, kept in device memory so that a captured hipGraph replays correctly):
-//   block b copies slice b of `in` into my data buffer [k & 1]; release-stores flag k into start[b][my_rank] of
-//   every peer's signal area (system scope); acquire-spins until start[b][r] >= k for every r in my own signal
-//   area; then sums slice b over the N data buffers [k & 1] and writes `out`.
-// Two data buffers make a closing barrier unnecessary: a rank can only reach call k+2 (which overwrites buffer
-// [k & 1]) after every peer entered call k+1, i.e. after every peer finished reading in call k (stream order).
-// Every call launches the same kMaxBlocks blocks so that all per-block counters stay equal (see the launcher).
+// Determinism: a row is summed by exactly one piece of code in rank order 0..N-1 with fp32
+// accumulation and one rounding -- in the one-shot form by every rank identically, in the two-shot form by its
+// owner only -- so all ranks obtain bit-identical results (the replicated argmax / page tables need that).
+//
+// Fused epilogue (md_allreduce_add_rmsnorm): the unit of work is a ROW of the [rows, dim] message and a wavefront
+// handles a whole row, so the consumer of the reduced row can finish the layer's next two ops in registers:
+// h = bf16(x + sum) and y = bf16(bf16(h * rsqrt(mean(h^2) + eps)) * w) -- the reference's rounding points
+// (Engine/SnapKV/model.py:464-469) -- saving one kernel launch and one round trip of h per all-reduce.
+//
+// Protocol, per call k = 1, 2, ... (k lives in device memory so that a captured hipGraph replays correctly; every
+// block of a call reads the same k because only the LAST block to finish advances it) and per block b of a grid
+// that is sized to the message:
+//   1. copy the rows of block b from `in` into my data buffer half (k & 1);
+//   2. release; store k into start[b][me] of every peer; spin until start[b][p] >= k for every p; acquire;
+//   3. one-shot: sum the rows of block b over all ranks -> out.           two-shot: sum MY rows of block b -> my
+//      result buffer half (k & 1) (and out); release; store k into start2[b][me] of every peer; spin until
+//      start2[b][p] >= k; acquire; copy the other owners' rows of block b from their result buffers -> out.
+//   Rows are dealt to blocks by (row / N) % grid, so the producer of anything block b reads is the peer's block b.
+//   Two halves per buffer make a closing barrier unnecessary and the message-size-dependent grid safe: I overwrite
+//   half (k & 1) in call k+2, after ALL my blocks finished call k+1; one of them (block 0 exists in every call) waited
+//   for every peer's call-(k+1) flag, so every peer had entered call k+1, i.e. finished reading in call k (kernels
+//   of one stream run in order).  tests/test_allreduce_protocol_model.py runs the protocol under random schedules.
 // Signals live in uncached (fine-grained) memory; data buffers are ordinary device memory -- the system-scope
 // release / acquire pair performs the L2 write-back / invalidate the AMDGPU memory model prescribes.
-// Spins are bounded (kSpinTimeoutTicks): on timeout the kernel records an error and returns instead of hanging the GPU.
+// Spins are bounded: on a time-out the kernel does NOT continue silently -- it records the error in the status word
+// and POISONS its output rows with NaN, and the host raises at the next status check (Engine/oneshot.py).
 #include "md_common.h"
 
 namespace {
 
 constexpr int kMaxRanks = 8;
 constexpr int kMaxBlocks = 64;
-constexpr int kThreads = 512;
+constexpr int kThreads = 512;                 // 8 wavefronts: 8 rows in flight per block
+constexpr int kRowVecs = 512;                 // plain (unfused) calls: a "row" is 512 vectors of 8 bf16 = 8 KiB
+constexpr int kMaxVecPerLane = 16;            // fused rows: dim <= 64 * 16 * 8 = 8192
 constexpr unsigned long long kSpinTimeoutTicks = 200ull * 1000 * 1000;   // wall_clock64() ticks at 100 MHz: 2 s
 
 struct Signal {
-    uint32_t start[kMaxBlocks][kMaxRanks];   // written by peers (system-scope release), read by the owner
-    uint32_t flag[kMaxBlocks];               // owner only: call counter per block
-    uint32_t status;                         // owner only: 0 ok, 1 = a spin timed out
+    uint32_t start[kMaxBlocks][kMaxRanks];    // written by peers (system-scope release), read by the owner
+    uint32_t start2[kMaxBlocks][kMaxRanks];   // second hop of the two-shot form
+    uint32_t call;                            // owner only: number of completed calls
+    uint32_t done;                            // owner only: blocks of the running call that have finished
+    uint32_t status;                          // owner only: 0 ok, 1 = a spin timed out (output poisoned)
 };
 
 struct ArDev {
-    bf16_t* data[kMaxRanks];   // peer data buffers (2 * max_bytes each), index = rank
+    bf16_t* data[kMaxRanks];   // peer buffers: [data half 0][data half 1][result half 0][result half 1]
     Signal* sig[kMaxRanks];
     int rank, world;
     size_t buf_elems;          // elements per half buffer
 };
 
-template <int NR>
-__global__ __launch_bounds__(kThreads) void oneshot_ar_kernel(const ArDev c, const bf16_t* __restrict__ in,
-                                                              bf16_t* __restrict__ out, size_t n_vec) {
-    const int b = blockIdx.x, tid = threadIdx.x;
-    __shared__ uint32_t s_flag;
-    Signal* self = c.sig[c.rank];
-    if (tid == 0) {
-        const uint32_t f = self->flag[b] + 1;
-        self->flag[b] = f;
-        s_flag = f;
-    }
-    __syncthreads();
-    const uint32_t flag = s_flag;
-    const size_t half = (flag & 1u) ? c.buf_elems : 0;
-    const size_t per = (n_vec + gridDim.x - 1) / gridDim.x;
-    const size_t v0 = (size_t)b * per, v1 = v0 + per < n_vec ? v0 + per : n_vec;
+struct ArArgs {
+    const bf16_t* in;          // [rows][row_elems] contiguous
+    bf16_t* out;               // sum (plain) or h = x + sum (fused)
+    const bf16_t* resid;       // fused: x
+    const bf16_t* weight;      // fused: RMSNorm weight [row_elems]
+    bf16_t* out_y;             // fused: normalised rows
+    float eps;
+    int rows, row_vecs;        // row_vecs = vectors of 8 bf16 per row (the last row of a plain call may be shorter)
+    size_t n_vec;              // total vectors
+};
 
-    // phase 0: publish my slice
-    u32x4* mine = reinterpret_cast<u32x4*>(c.data[c.rank] + half);
-    const u32x4* src = reinterpret_cast<const u32x4*>(in);
-    for (size_t i = v0 + tid; i < v1; i += kThreads) mine[i] = src[i];
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");   // every wave: its copies are written back before the flag is raised
-    __syncthreads();
-    if (tid < NR) {
-        __hip_atomic_store(&c.sig[tid]->start[b][c.rank], flag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-        const unsigned long long t0 = wall_clock64();
-        while ((int32_t)(__hip_atomic_load(&self->start[b][tid], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - flag) < 0) {
-            __builtin_amdgcn_s_sleep(2);
-            if (wall_clock64() - t0 > kSpinTimeoutTicks) {
-                self->status = 1;
-                break;
+__device__ __forceinline__ bool spin_ge(const uint32_t* p, uint32_t want) {
+    const unsigned long long t0 = wall_clock64();
+    while ((int32_t)(__hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - want) < 0) {
+        __builtin_amdgcn_s_sleep(2);
+        if (wall_clock64() - t0 > kSpinTimeoutTicks) return false;
+    }
+    return true;
+}
+
+__device__ __forceinline__ void unpack8(const u32x4 v, float (&f)[8]) {
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        f[2 * w] = __uint_as_float(v[w] << 16);
+        f[2 * w + 1] = __uint_as_float(v[w] & 0xffff0000u);
+    }
+}
+__device__ __forceinline__ u32x4 pack8(const float (&f)[8]) {
+    bf16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = f32_to_bf16(f[e]);
+    return *reinterpret_cast<u32x4*>(&o);
+}
+
+// A wavefront finishes one row whose reduced value it holds as vectors s[0..nv) (lane-strided: vector lane + 64*i).
+// Plain: store.  Fused: h = bf16(x + s) -> out, y = rmsnorm(h) * w -> out_y.  poisoned: NaN everywhere.
+template <bool FUSED>
+__device__ __forceinline__ void finish_row(const ArArgs& a, int row, int lane, int nvec_row, u32x4 (&s)[kMaxVecPerLane],
+                                           bool poisoned) {
+    const size_t base = (size_t)row * a.row_vecs;
+    u32x4* o = reinterpret_cast<u32x4*>(a.out) + base;
+    if (poisoned) {
+        const u32x4 nan = {0x7fc07fc0u, 0x7fc07fc0u, 0x7fc07fc0u, 0x7fc07fc0u};
+        for (int i = 0; lane + 64 * i < nvec_row; ++i) {
+            o[lane + 64 * i] = nan;
+            if constexpr (FUSED) (reinterpret_cast<u32x4*>(a.out_y) + base)[lane + 64 * i] = nan;
+        }
+        return;
+    }
+    if constexpr (!FUSED) {
+#pragma unroll
+        for (int i = 0; i < kMaxVecPerLane; ++i)
+            if (lane + 64 * i < nvec_row) o[lane + 64 * i] = s[i];
+    } else {
+        const u32x4* x = reinterpret_cast<const u32x4*>(a.resid) + base;
+        float ss = 0.f;
+#pragma unroll
+        for (int i = 0; i < kMaxVecPerLane; ++i) {
+            if (lane + 64 * i < nvec_row) {
+                float fs[8], fx[8], fh[8];
+                unpack8(s[i], fs);
+                unpack8(x[lane + 64 * i], fx);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) fh[e] = bf16_to_f32(f32_to_bf16(fx[e] + fs[e]));   // h = x + y in bf16
+                s[i] = pack8(fh);
+                o[lane + 64 * i] = s[i];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) ss += fh[e] * fh[e];
             }
         }
+        ss = wave_reduce_sum(ss);
+        const float rstd = rsqrtf(ss / (float)(a.row_vecs * 8) + a.eps);
+        const u32x4* w = reinterpret_cast<const u32x4*>(a.weight);
+        u32x4* y = reinterpret_cast<u32x4*>(a.out_y) + base;
+#pragma unroll
+        for (int i = 0; i < kMaxVecPerLane; ++i) {
+            if (lane + 64 * i < nvec_row) {
+                float fh[8], fw[8], fy[8];
+                unpack8(s[i], fh);
+                unpack8(w[lane + 64 * i], fw);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) fy[e] = bf16_to_f32(f32_to_bf16(fh[e] * rstd)) * fw[e];   // (x*rstd).type_as(x) * w
+                y[lane + 64 * i] = pack8(fy);
+            }
+        }
+    }
+}
+
+template <int NR, bool TWOSHOT, bool FUSED>
+__global__ __launch_bounds__(kThreads) void allreduce_kernel(const ArDev c, const ArArgs a) {
+    const int b = blockIdx.x, G = gridDim.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    __shared__ uint32_t s_k;
+    __shared__ int s_bad;
+    Signal* self = c.sig[c.rank];
+    if (tid == 0) {
+        s_k = self->call + 1;
+        s_bad = 0;
+    }
+    __syncthreads();
+    const uint32_t k = s_k;
+    const size_t half = (k & 1u) ? c.buf_elems : 0;
+
+    // rows of this block: row -> owner = row % NR, idx = row / NR, block = idx % G
+    auto row_vecs_of = [&](int row) -> int {
+        const size_t v0 = (size_t)row * a.row_vecs;
+        const size_t left = a.n_vec - v0;
+        return left < (size_t)a.row_vecs ? (int)left : a.row_vecs;
+    };
+
+    // 1. publish: copy every row of block b into my data buffer
+    {
+        u32x4* mine = reinterpret_cast<u32x4*>(c.data[c.rank] + half);
+        const u32x4* src = reinterpret_cast<const u32x4*>(a.in);
+        for (int idx = b; idx * NR < a.rows; idx += G) {
+            const int r0 = idx * NR;
+            const int r1 = r0 + NR < a.rows ? r0 + NR : a.rows;            // NR consecutive rows (one per owner)
+            const size_t v0 = (size_t)r0 * a.row_vecs;
+            size_t v1 = (size_t)r1 * a.row_vecs;
+            if (v1 > a.n_vec) v1 = a.n_vec;
+            for (size_t i = v0 + tid; i < v1; i += kThreads) mine[i] = src[i];
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");   // every wave: its copies are written back before the flag is raised
+    __syncthreads();
+    // 2. first hop
+    if (tid < NR) {
+        __hip_atomic_store(&c.sig[tid]->start[b][c.rank], k, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (!spin_ge(&self->start[b][tid], k)) s_bad = 1;
     }
     __syncthreads();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");   // every wave: no stale peer data from two calls ago
+    bool bad = s_bad != 0;
 
-    // phase 1: sum slice b over the ranks, in rank order, fp32 accumulate, one rounding
     const u32x4* peer[NR];
 #pragma unroll
     for (int r = 0; r < NR; ++r) peer[r] = reinterpret_cast<const u32x4*>(c.data[r] + half);
-    u32x4* dst = reinterpret_cast<u32x4*>(out);
-    for (size_t i = v0 + tid; i < v1; i += kThreads) {
-        float acc[8];
+
+    // sum of one row over the ranks, in rank order, fp32 accumulate, one rounding
+    auto reduce_row = [&](int row, int nv, u32x4 (&s)[kMaxVecPerLane]) {
+        const size_t base = (size_t)row * a.row_vecs;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+        for (int i = 0; i < kMaxVecPerLane; ++i) {
+            if (lane + 64 * i < nv) {
+                float acc[8];
 #pragma unroll
-        for (int r = 0; r < NR; ++r) {
-            const u32x4 v = __builtin_nontemporal_load(peer[r] + i);
+                for (int e = 0; e < 8; ++e) acc[e] = 0.f;
 #pragma unroll
-            for (int w = 0; w < 4; ++w) {
-                acc[2 * w] += __uint_as_float(v[w] << 16);
-                acc[2 * w + 1] += __uint_as_float(v[w] & 0xffff0000u);
+                for (int r = 0; r < NR; ++r) {
+                    float f[8];
+                    unpack8(__builtin_nontemporal_load(peer[r] + base + lane + 64 * i), f);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) acc[e] += f[e];
+                }
+                s[i] = pack8(acc);
             }
         }
-        bf16x8 o;
+    };
+
+    if constexpr (!TWOSHOT) {
+        // 3. every rank sums every row of block b itself (rows of the block dealt to the 8 waves)
+        for (int t = wave;; t += kThreads / 64) {
+            const int idx = b + (t / NR) * G, row = idx * NR + t % NR;
+            if (idx * NR >= a.rows) break;
+            if (row >= a.rows) continue;
+            const int nv = row_vecs_of(row);
+            u32x4 s[kMaxVecPerLane];
+            if (!bad) reduce_row(row, nv, s);
+            finish_row<FUSED>(a, row, lane, nv, s, bad);
+        }
+    } else {
+        // 3a. reduce-scatter: my rows of block b -> my result buffer (+ finished locally)
+        u32x4* myres = reinterpret_cast<u32x4*>(c.data[c.rank] + 2 * c.buf_elems + half);
+        for (int idx = b + wave * G; idx * NR + c.rank < a.rows; idx += G * (kThreads / 64)) {
+            const int row = idx * NR + c.rank;
+            const int nv = row_vecs_of(row);
+            u32x4 s[kMaxVecPerLane];
+            if (!bad) {
+                reduce_row(row, nv, s);
+                const size_t base = (size_t)row * a.row_vecs;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = f32_to_bf16(acc[e]);
-        dst[i] = *reinterpret_cast<u32x4*>(&o);
+                for (int i = 0; i < kMaxVecPerLane; ++i)
+                    if (lane + 64 * i < nv) myres[base + lane + 64 * i] = s[i];
+            }
+            finish_row<FUSED>(a, row, lane, nv, s, bad);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+        __syncthreads();
+        // 3b. second hop
+        if (tid < NR) {
+            __hip_atomic_store(&c.sig[tid]->start2[b][c.rank], k, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (!spin_ge(&self->start2[b][tid], k)) s_bad = 1;
+        }
+        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+        bad = s_bad != 0;
+        // 3c. all-gather: the other owners' rows of block b from their result buffers
+        for (int t = wave;; t += kThreads / 64) {
+            const int idx = b + (t / NR) * G, o = t % NR, row = idx * NR + o;
+            if (idx * NR >= a.rows) break;
+            if (row >= a.rows || o == c.rank) continue;
+            const int nv = row_vecs_of(row);
+            const u32x4* src = reinterpret_cast<const u32x4*>(c.data[o] + 2 * c.buf_elems + half) +
+                               (size_t)row * a.row_vecs;
+            u32x4 s[kMaxVecPerLane];
+            if (!bad) {
+#pragma unroll
+                for (int i = 0; i < kMaxVecPerLane; ++i)
+                    if (lane + 64 * i < nv) s[i] = __builtin_nontemporal_load(src + lane + 64 * i);
+            }
+            finish_row<FUSED>(a, row, lane, nv, s, bad);
+        }
+    }
+
+    // the last block to finish advances the call counter (every block of the NEXT call then reads the same k)
+    __syncthreads();
+    if (tid == 0) {
+        if (bad || s_bad) self->status = 1;
+        __threadfence();
+        const uint32_t d = atomicAdd(&self->done, 1u);
+        if (d == (uint32_t)G - 1) {
+            self->done = 0;
+            self->call = k;
+            __threadfence();
+        }
     }
 }
 
@@ -122,13 +311,14 @@ extern "C" int md_ar_create(int rank, int world, size_t max_bytes, md_ar_comm** 
     md_ar_comm* c = new md_ar_comm();
     c->n_opened = 0;
     c->max_bytes = max_bytes;
-    if (hipMalloc(&c->my_data, 2 * max_bytes) != hipSuccess ||
+    // one registered allocation: data halves 0/1 (published partials), result halves 0/1 (two-shot reduced rows)
+    if (hipMalloc(&c->my_data, 4 * max_bytes) != hipSuccess ||
         hipExtMallocWithFlags(&c->my_sig, sizeof(Signal), hipDeviceMallocUncached) != hipSuccess) {
         md_set_error("md_ar_create: device allocation failed: %s", hipGetErrorString(hipGetLastError()));
         delete c;
         return MD_ERR_WORKSPACE;
     }
-    if (hipMemset(c->my_sig, 0, sizeof(Signal)) != hipSuccess || hipMemset(c->my_data, 0, 2 * max_bytes) != hipSuccess ||
+    if (hipMemset(c->my_sig, 0, sizeof(Signal)) != hipSuccess || hipMemset(c->my_data, 0, 4 * max_bytes) != hipSuccess ||
         hipDeviceSynchronize() != hipSuccess) {
         md_set_error("md_ar_create: clearing the buffers failed: %s", hipGetErrorString(hipGetLastError()));
         (void)hipFree(c->my_data);
@@ -181,26 +371,13 @@ extern "C" int md_ar_open_peers(md_ar_comm* c, const void* all_handles_host) {
     return MD_OK;
 }
 
-extern "C" int md_allreduce_oneshot(md_ar_comm* c, const void* in, void* out, size_t count, md_stream_t stream) {
-    MD_CHECK_ARG(c && in && out, "md_allreduce_oneshot: null argument");
-    MD_CHECK_ARG(count % 8 == 0 && count * 2 <= c->max_bytes,
-                 "md_allreduce_oneshot: count must be a multiple of 8 bf16 and fit the registered buffer (%zu bytes)",
-                 c->max_bytes);
-    MD_CHECK_ARG(((uintptr_t)in | (uintptr_t)out) % 16 == 0, "md_allreduce_oneshot: in/out must be 16-byte aligned");
-    for (int r = 0; r < c->dev.world; ++r)
-        MD_CHECK_ARG(c->dev.data[r] && c->dev.sig[r], "md_allreduce_oneshot: peer %d not opened (md_ar_open_peers)", r);
-    if (count == 0) return MD_OK;
-    const size_t n_vec = count / 8;
-    // Always the full grid, whatever the message size: every block then advances its call counter on every call,
-    // so all blocks of call k agree on the data-buffer half (k & 1).  (With a size-dependent grid the per-block
-    // counters drift apart when message sizes alternate, and a small call could overwrite a region of the half a
-    // slower peer is still reading for the previous, larger call.)  Idle blocks only run the flag handshake.
-    const int blocks = kMaxBlocks;
-    hipStream_t st = (hipStream_t)stream;
-#define MD_AR_LAUNCH(N)                                                                                       \
-    case N:                                                                                                   \
-        hipLaunchKernelGGL((oneshot_ar_kernel<N>), dim3(blocks), dim3(kThreads), 0, st, c->dev, (const bf16_t*)in, \
-                           (bf16_t*)out, n_vec);                                                              \
+namespace {
+
+template <bool TWOSHOT, bool FUSED>
+void launch_world(const md_ar_comm* c, const ArArgs& a, int grid, hipStream_t st) {
+#define MD_AR_LAUNCH(N)                                                                                         \
+    case N:                                                                                                     \
+        hipLaunchKernelGGL((allreduce_kernel<N, TWOSHOT, FUSED>), dim3(grid), dim3(kThreads), 0, st, c->dev, a); \
         break;
     switch (c->dev.world) {
         MD_AR_LAUNCH(1)
@@ -213,7 +390,78 @@ extern "C" int md_allreduce_oneshot(md_ar_comm* c, const void* in, void* out, si
         MD_AR_LAUNCH(8)
     }
 #undef MD_AR_LAUNCH
-    MD_CHECK_LAUNCH("md_allreduce_oneshot");
+}
+
+int run(md_ar_comm* c, ArArgs a, int algo, bool fused, hipStream_t st, const char* who) {
+    for (int r = 0; r < c->dev.world; ++r)
+        MD_CHECK_ARG(c->dev.data[r] && c->dev.sig[r], "%s: peer %d not opened (md_ar_open_peers)", who, r);
+    MD_CHECK_ARG(algo == MD_AR_ALGO_AUTO || algo == MD_AR_ALGO_ONESHOT || algo == MD_AR_ALGO_TWOSHOT,
+                 "%s: unknown algorithm %d", who, algo);
+    const size_t bytes = a.n_vec * 16;
+    bool two = algo == MD_AR_ALGO_TWOSHOT;
+    if (algo == MD_AR_ALGO_AUTO)   // one-shot pulls (N-1) x the message into every rank, two-shot 2(N-1)/N x in two hops
+        two = c->dev.world >= 4 && bytes > (size_t)512 * 1024;
+    if (c->dev.world == 1) two = false;
+    // grid sized to the message: one block per group of N rows (a block's 8 waves take a row each), at least one
+    // (block 0 carries the call-level hand-shake), at most kMaxBlocks
+    const int groups = (a.rows + c->dev.world - 1) / c->dev.world;
+    const int grid = groups < 1 ? 1 : (groups > kMaxBlocks ? kMaxBlocks : groups);
+    if (two) {
+        if (fused) launch_world<true, true>(c, a, grid, st); else launch_world<true, false>(c, a, grid, st);
+    } else {
+        if (fused) launch_world<false, true>(c, a, grid, st); else launch_world<false, false>(c, a, grid, st);
+    }
+    return MD_OK;
+}
+
+}  // namespace
+
+extern "C" int md_allreduce(md_ar_comm* c, const void* in, void* out, size_t count, int algo, md_stream_t stream) {
+    MD_CHECK_ARG(c && in && out, "md_allreduce: null argument");
+    MD_CHECK_ARG(count % 8 == 0 && count * 2 <= c->max_bytes,
+                 "md_allreduce: count must be a multiple of 8 bf16 and fit the registered buffer (%zu bytes)",
+                 c->max_bytes);
+    MD_CHECK_ARG(((uintptr_t)in | (uintptr_t)out) % 16 == 0, "md_allreduce: in/out must be 16-byte aligned");
+    if (count == 0) return MD_OK;
+    ArArgs a = {};
+    a.in = (const bf16_t*)in;
+    a.out = (bf16_t*)out;
+    a.n_vec = count / 8;
+    a.row_vecs = kRowVecs;
+    a.rows = (int)((a.n_vec + kRowVecs - 1) / kRowVecs);
+    const int rc = run(c, a, algo, false, (hipStream_t)stream, "md_allreduce");
+    if (rc != MD_OK) return rc;
+    MD_CHECK_LAUNCH("md_allreduce");
+    return MD_OK;
+}
+
+extern "C" int md_allreduce_oneshot(md_ar_comm* c, const void* in, void* out, size_t count, md_stream_t stream) {
+    return md_allreduce(c, in, out, count, MD_AR_ALGO_ONESHOT, stream);
+}
+
+extern "C" int md_allreduce_add_rmsnorm(md_ar_comm* c, const void* partial, const void* resid, const void* weight,
+                                        void* out_h, void* out_y, int rows, int dim, float eps, int algo,
+                                        md_stream_t stream) {
+    MD_CHECK_ARG(c && partial && resid && weight && out_h && out_y, "md_allreduce_add_rmsnorm: null argument");
+    MD_CHECK_ARG(rows > 0 && dim > 0 && dim % 8 == 0 && dim <= 64 * kMaxVecPerLane * 8,
+                 "md_allreduce_add_rmsnorm: need rows > 0 and dim %% 8 == 0, dim <= %d", 64 * kMaxVecPerLane * 8);
+    MD_CHECK_ARG((size_t)rows * dim * 2 <= c->max_bytes,
+                 "md_allreduce_add_rmsnorm: message does not fit the registered buffer (%zu bytes)", c->max_bytes);
+    MD_CHECK_ARG(((uintptr_t)partial | (uintptr_t)resid | (uintptr_t)weight | (uintptr_t)out_h | (uintptr_t)out_y) % 16 == 0,
+                 "md_allreduce_add_rmsnorm: pointers must be 16-byte aligned");
+    ArArgs a = {};
+    a.in = (const bf16_t*)partial;
+    a.out = (bf16_t*)out_h;
+    a.resid = (const bf16_t*)resid;
+    a.weight = (const bf16_t*)weight;
+    a.out_y = (bf16_t*)out_y;
+    a.eps = eps;
+    a.rows = rows;
+    a.row_vecs = dim / 8;
+    a.n_vec = (size_t)rows * (dim / 8);
+    const int rc = run(c, a, algo, true, (hipStream_t)stream, "md_allreduce_add_rmsnorm");
+    if (rc != MD_OK) return rc;
+    MD_CHECK_LAUNCH("md_allreduce_add_rmsnorm");
     return MD_OK;
 }
 

@@ -28,9 +28,8 @@
 //   * verify/draft ("decode" variant): the 4 waves of a workgroup split the KV
 //     range of one (request, kv head, kv-split) and merge (m,l,O) through
 //     LDS; optional split-KV across workgroups + a small merge kernel.
-//   * chunked prefill ("splitq" variant): the 4 waves own different 16/32-row
-//     query tiles and each streams the causal KV range; workgroups sharing a
-//     (request, kv head) are placed on one XCD (block id mod 8) to share L2.
+//   * chunked prefill: prefill_attn_kernel below (a workgroup of 4 or 8 waves x 16/32 query rows shares every
+//     K/V tile through LDS); workgroups sharing a (request, kv head) are placed on one XCD (block id mod 8).
 #include <type_traits>
 
 #include "md_common.h"
@@ -107,7 +106,7 @@ __device__ __forceinline__ void cvt16_fp8_bf16(const u32x4 x, u32x4& lo, u32x4& 
     }
 }
 
-template <int D, int QT, bool SPLITQ, bool FP8>
+template <int D, int QT, bool FP8>
 __global__ __launch_bounds__(256, 2) void paged_attn_kernel(const AttnParams p) {
     constexpr int EB = FP8 ? 1 : 2;          // bytes per cache element
     constexpr int CH = D * EB / 16;          // 16-B chunks per K/V row in HBM
@@ -124,7 +123,7 @@ __global__ __launch_bounds__(256, 2) void paged_attn_kernel(const AttnParams p) 
     // and inside V sub-tiles 4..7 (undone when O is stored).
     constexpr bool FP8_SWAP = FP8 && D == 128;
     constexpr int WAVE_LDS = attn_wave_lds<D, QT>();
-    constexpr int TSTEP = SPLITQ ? 1 : 4;
+    constexpr int TSTEP = 4;      // the 4 waves of a workgroup take the KV tiles round-robin
     // two tiles of loads in flight per wave where the register budget allows it (256 VGPRs at 2 waves/SIMD)
     // register staging depth: tiles of this wave whose loads are in flight while one tile is consumed.  Two where
     // the register budget allows it (256 VGPRs at 2 waves/SIMD; QT=2 at D=128 needs them for O and Q).  Deeper
@@ -132,7 +131,7 @@ __global__ __launch_bounds__(256, 2) void paged_attn_kernel(const AttnParams p) 
     // two M tiles at D=128 (g*(gamma+1) in 17..32: Qwen2.5-32B g=5, Llama-70B g=8) are register-bound; measured best:
     // fp8: both tiles in flight + batched fragment reads, plain loop (60-63 % of peak vs 57-59 % for the other
     // combinations); bf16: one tile in flight, steady loop (70-78 %; batching / plain loop measured equal, two tiles spill)
-    constexpr bool Q2F8 = FP8 && QT == 2 && D == 128 && !SPLITQ;
+    constexpr bool Q2F8 = FP8 && QT == 2 && D == 128;
     constexpr int NS = Q2F8 ? 2 : (QT == 2 && D == 128) ? 1 : 2;
     // fp8 with two M tiles (e.g. Qwen2.5-32B: g=5, gamma+1=4 -> 20 rows) has no registers left for the duplicated
     // steady-state body; it keeps both tiles in flight with the plain (conditional-prefetch) loop
@@ -166,7 +165,7 @@ __global__ __launch_bounds__(256, 2) void paged_attn_kernel(const AttnParams p) 
     // clamped to the mapped pages: an over-long last_page_len must not walk past the request's page list
     const int kv_len = npages > 0 ? min((npages - 1) * p.page_size + p.last_page_len[b], npages * p.page_size) : 0;
     const int nrows = n_b * g;
-    const int tile_base = SPLITQ ? (qg * 4 + wave) * QT : qg * QT;
+    const int tile_base = qg * QT;
 
     // per-lane query row (column lq of S^T) and its causal limit
     int lim[QT];
@@ -275,10 +274,10 @@ __global__ __launch_bounds__(256, 2) void paged_attn_kernel(const AttnParams p) 
         const int64_t jstep = (int64_t)RPI * p.slot_stride * EB;
 #pragma unroll
         for (int j = 0; j < NL; ++j)
-            kreg[j] = ldg_stream<!SPLITQ>(reinterpret_cast<const u32x4*>(kb_ + j * jstep + goff));
+            kreg[j] = ldg_stream<true>(reinterpret_cast<const u32x4*>(kb_ + j * jstep + goff));
 #pragma unroll
         for (int j = 0; j < NL; ++j)
-            vreg[j] = ldg_stream<!SPLITQ>(reinterpret_cast<const u32x4*>(vb_ + j * jstep + goff));
+            vreg[j] = ldg_stream<true>(reinterpret_cast<const u32x4*>(vb_ + j * jstep + goff));
     };
 
     // `always_prefetch` (a std::bool_constant): the steady-state loop issues the next tile's loads unconditionally, so
@@ -437,7 +436,7 @@ __global__ __launch_bounds__(256, 2) void paged_attn_kernel(const AttnParams p) 
         __builtin_amdgcn_wave_barrier();
     };
 
-    int t = t_begin + (SPLITQ ? 0 : wave);
+    int t = t_begin + wave;
     if (STEADY && t + (2 * NS - 1) * TSTEP < t_end) {
         // steady state: NS tiles in flight, every processed tile re-arms its register set with tile t + PF
 #pragma unroll
@@ -466,24 +465,7 @@ __global__ __launch_bounds__(256, 2) void paged_attn_kernel(const AttnParams p) 
         l[qt] += __shfl_xor(l[qt], 32);
     }
 
-    if constexpr (SPLITQ) {
-        // each wave owns its query tiles: normalise and store (lane: row lq, d = nb*16+lc*4+{0..3})
-#pragma unroll
-        for (int qt = 0; qt < QT; ++qt) {
-            const int R = (tile_base + qt) * 16 + lq;
-            if (R < nrows) {
-                const int i = R / g, r = R - i * g;
-                const float inv = l[qt] > 0.f ? vsc / l[qt] : 0.f;
-                bf16_t* op = p.out + ((int64_t)(q0 + i) * p.H + kvh * g + r) * D;
-#pragma unroll
-                for (int nb = 0; nb < NB; ++nb) {
-                    const f32x4 ov = o[qt][nb] * inv;
-                    const int dd = nb * 16 + ((FP8_SWAP && nb >= 4) ? (lc ^ 2) : lc) * 4;
-                    *reinterpret_cast<bf16x4*>(op + dd) = __builtin_convertvector(ov, bf16x4);
-                }
-            }
-        }
-    } else {
+    {
         // merge the 4 waves' (m, l, O) through LDS
         __syncthreads();
         float* mo = reinterpret_cast<float*>(smem + wave * WAVE_LDS);
@@ -857,11 +839,6 @@ struct AttnPlan {
 // per-workgroup prologue/epilogue and the partial-result round trip dominate once a wave owns < ~30 tiles
 int g_target_wgs = 256;  // dev knob: md_debug_set_attn_target_wgs
 
-bool old_prefill() {   // development A/B switch: the wave-private "split-q" variant of the decode kernel
-    static const bool v = getenv("MD_ATTN_OLD_PREFILL") != nullptr;
-    return v;
-}
-
 AttnPlan make_plan(int B, int n_max, int H, int KH, int max_pages, int page_size, bool fp8) {
     AttnPlan pl;
     pl.nw = 4;
@@ -887,7 +864,7 @@ AttnPlan make_plan(int B, int n_max, int H, int KH, int max_pages, int page_size
         // through L2: +21 % at the 8B TP1 shape and still +10 % at the TP8 shard shape where the grid no longer
         // fills the chip (128 workgroups); fp8 staging (4 load instructions per tile, plus the conversion) is
         // better spread over 4-wave workgroups (measured: 2.9 vs 3.3 ms)
-        pl.nw = (!old_prefill() && !fp8 && rows >= 16 * pl.qt * 8) ? 8 : 4;
+        pl.nw = (!fp8 && rows >= 16 * pl.qt * 8) ? 8 : 4;
         const int wg_rows = 16 * pl.qt * pl.nw;
         pl.n_qgroups = (rows + wg_rows - 1) / wg_rows;
         pl.nsplit = 1;
@@ -896,21 +873,20 @@ AttnPlan make_plan(int B, int n_max, int H, int KH, int max_pages, int page_size
     return pl;
 }
 
-template <int D, int QT, bool SPLITQ, bool FP8>
+template <int D, int QT, bool FP8>
 int launch_attn(const AttnParams& p, int grid, hipStream_t st) {
     constexpr int lds = 4 * attn_wave_lds<D, QT>();
-    static bool attr_set = false;
-    if (!attr_set) {
+    static MdPerDeviceOnce attr_once;
+    if (attr_once.first()) {
         hipError_t e = hipFuncSetAttribute(
-            reinterpret_cast<const void*>(&paged_attn_kernel<D, QT, SPLITQ, FP8>),
+            reinterpret_cast<const void*>(&paged_attn_kernel<D, QT, FP8>),
             hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) {
             md_set_error("md_paged_attn: hipFuncSetAttribute(%d B LDS) failed: %s", lds, hipGetErrorString(e));
             return MD_ERR_LAUNCH;
         }
-        attr_set = true;
     }
-    hipLaunchKernelGGL((paged_attn_kernel<D, QT, SPLITQ, FP8>), dim3(grid), dim3(256), lds, st, p);
+    hipLaunchKernelGGL((paged_attn_kernel<D, QT, FP8>), dim3(grid), dim3(256), lds, st, p);
     MD_CHECK_LAUNCH("md_paged_attn");
     return MD_OK;
 }
@@ -1004,11 +980,9 @@ extern "C" int md_paged_attn(const void* q, int64_t q_row_stride, const void* ca
     const int grid = npairs8 * pl.n_qgroups * pl.nsplit;
     int rc;
 #define MD_ATTN_DISPATCH(DD, FP)                                                                                  \
-    (pl.splitq ? (old_prefill() ? (pl.qt == 2 ? launch_attn<DD, 2, true, FP>(p, grid, st)                            \
-                                            : launch_attn<DD, 1, true, FP>(p, grid, st))                           \
-                              : (pl.qt == 2 ? launch_prefill<DD, 2, FP>(p, grid, pl.nw, st)                        \
-                                            : launch_prefill<DD, 1, FP>(p, grid, pl.nw, st)))                      \
-               : (pl.qt == 2 ? launch_attn<DD, 2, false, FP>(p, grid, st) : launch_attn<DD, 1, false, FP>(p, grid, st)))
+    (pl.splitq ? (pl.qt == 2 ? launch_prefill<DD, 2, FP>(p, grid, pl.nw, st)                                         \
+                             : launch_prefill<DD, 1, FP>(p, grid, pl.nw, st))                                       \
+               : (pl.qt == 2 ? launch_attn<DD, 2, FP>(p, grid, st) : launch_attn<DD, 1, FP>(p, grid, st)))
     if (D == 128)
         rc = fp8 ? MD_ATTN_DISPATCH(128, true) : MD_ATTN_DISPATCH(128, false);
     else

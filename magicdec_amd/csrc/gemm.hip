@@ -105,7 +105,9 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(const GemmParams p) {
     // element offset of this lane's first fragment and the distance between consecutive k-steps.
     // row-major: 32 rows x 32 B per wave instruction.  packed: tile-major [n_tile][k_step][lane][8]: one fully
     // contiguous KiB per wave instruction and one sequential stream per wavefront (the layout HBM likes best).
-    const int tile = blockIdx.x * 4 + wave;
+    // (a workgroup covers 4 tiles; the last workgroup may reach past the last tile: re-read that one, like `col`)
+    const int ntiles = (EPI == EPI_SWIGLU) ? ((p.N >> 1) + 15) / 16 : (p.N + 31) / 32;
+    const int tile = min(blockIdx.x * 4 + wave, ntiles - 1);
     const int64_t w_off = p.packed ? ((int64_t)tile * (p.K >> 4) + (k_beg >> 4)) * 512 + lane * 8
                                    : (int64_t)col * p.K + k_beg + kh * 8;
     const int64_t w_step = p.packed ? 512 : 16;
@@ -286,14 +288,13 @@ int launch(const GemmParams& p, int n_blocks, hipStream_t st) {
     const size_t lds = (size_t)2 * MT * 32 * kPitch;
     auto k = skinny_gemm_kernel<MT, EPI, W8, RD>;
     if (lds > 64 * 1024) {
-        static bool done = false;     // per (MT, EPI, W8) instantiation; the attribute is per function, not per device
-        if (!done) {
+        static MdPerDeviceOnce once;   // per (MT, EPI, W8) instantiation and per device
+        if (once.first()) {
             if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)lds) != hipSuccess) {
                 md_set_error("md_linear: hipFuncSetAttribute(%zu B LDS) failed", lds);
                 return MD_ERR_LAUNCH;
             }
-            done = true;
         }
     }
     hipLaunchKernelGGL(k, dim3(n_blocks, p.S), dim3(256), lds, st, p);

@@ -39,6 +39,25 @@ void md_set_error(const char* fmt, ...);
         }                                                                         \
     } while (0)
 
+// hipFuncSetAttribute is per (function, device): "done" flags are kept per device ordinal so that a process driving
+// several GPUs sets the attribute on each of them (one process per GPU is the deployment, but the C ABI allows more)
+#define MD_MAX_DEVICES 64
+struct MdPerDeviceOnce {
+    bool done[MD_MAX_DEVICES] = {};
+    // true exactly once per device for the calling host thread's current device
+    bool first() {
+        int d = 0;
+        if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= MD_MAX_DEVICES) return true;
+        if (done[d]) return false;
+        done[d] = true;
+        return true;
+    }
+    void undo() {
+        int d = 0;
+        if (hipGetDevice(&d) == hipSuccess && d >= 0 && d < MD_MAX_DEVICES) done[d] = false;
+    }
+};
+
 __device__ __forceinline__ float bf16_bits_to_f32(unsigned short b) {
     return __uint_as_float(((unsigned int)b) << 16);
 }

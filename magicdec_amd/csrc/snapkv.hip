@@ -506,15 +506,14 @@ extern "C" int md_snapkv_select(const void* q_win, const void* cache, const int3
     MD_CHECK_LAUNCH("md_snapkv_select(scores)");
 
     const size_t lds3 = (size_t)((N + 7) / 8 * 8) * 2 + (256 + 1024 + 32) * 4;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static MdPerDeviceOnce attr_once;
+    if (attr_once.first()) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&snapkv_select_kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) {
             md_set_error("md_snapkv_select: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
             return MD_ERR_LAUNCH;
         }
-        attr_set = true;
     }
     hipLaunchKernelGGL(snapkv_select_kernel, dim3(KH, B), dim3(1024), lds3, st, p.aws, H, KH, g, N, pool_kernel, topk,
                        idx_out, scores);

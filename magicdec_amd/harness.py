@@ -109,6 +109,15 @@ def warn_on_page_overflow(where):
     return n
 
 
+def check_collectives(*engines):
+    """Raise if an xGMI all-reduce of any engine timed out since the last check (its hidden states were poisoned with
+    NaN, Engine/oneshot.py): a rank must never carry on with a partial sum.  Once per batch (synchronises)."""
+    for e in engines:
+        ar = getattr(getattr(e, "model", None), "_oneshot", None) if e is not None else None
+        if ar is not None:
+            ar.check()
+
+
 def _draft_round(step_fn, st: LoopState, gamma, next_double):
     """gamma draft steps; after an all-accept iteration the first step consumes two tokens
     (tests/SnapKV/longspec_benchmark.py:165-188)."""
@@ -222,6 +231,7 @@ def run_longspec_batch(engine, draft, input_ids, gamma, max_len, eot_1, eot_2, f
     dt = time.perf_counter() - t0
     if input_ids.is_cuda:
         warn_on_page_overflow("longspec batch")
+        check_collectives(engine, draft)
     return st, dt
 
 
@@ -244,6 +254,7 @@ def run_selfspec_batch(engine, input_ids, gamma, max_len, eot_1, eot_2, streamin
     dt = time.perf_counter() - t0
     if input_ids.is_cuda:
         warn_on_page_overflow("selfspec batch")
+        check_collectives(engine)
     return st, dt
 
 
@@ -267,4 +278,5 @@ def run_baseline_batch(engine, input_ids, max_len, eot_1, eot_2, check_eot_every
     dt = time.perf_counter() - t0
     if input_ids.is_cuda:
         warn_on_page_overflow("baseline batch")
+        check_collectives(engine)
     return output, steps, dt

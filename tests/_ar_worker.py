@@ -23,14 +23,29 @@ def expected(world, n, seed):
     return ins, acc.to(torch.bfloat16)
 
 
+def expected_fused(world, rows, dim, seed, eps):
+    """h = bf16(x + bf16(sum in rank order, fp32)), y = bf16(bf16(h * rsqrt(mean(h^2) + eps)) * w): the kernel's
+    definition of md_allreduce_add_rmsnorm = the reference's rounding points (Engine/SnapKV/model.py:464-469)."""
+    ins, s = expected(world, rows * dim, seed)
+    g = torch.Generator().manual_seed(seed * 100 + 77)
+    x = torch.randn(rows, dim, generator=g).to(torch.bfloat16)
+    w = (1 + 0.1 * torch.randn(dim, generator=g)).to(torch.bfloat16)
+    h = x + s.view(rows, dim)
+    hf = h.float()
+    y = (hf * torch.rsqrt(hf.pow(2).mean(-1, keepdim=True) + eps)).to(torch.bfloat16) * w
+    return [t.view(rows, dim) for t in ins], x, w, h, y
+
+
 def main():
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.cuda.set_device(0)
+    from magicdec_amd.Engine import oneshot
     from magicdec_amd.Engine.oneshot import OneShotAllReduce
     ar = OneShotAllReduce(dist.group.WORLD, max_bytes=4 << 20)
     dev = "cuda:0"
     call = 0
+    algos = (oneshot.ALGO_ONESHOT, oneshot.ALGO_TWOSHOT, oneshot.ALGO_AUTO)
     # eager calls of many sizes (1 vector ... the full 4 MiB buffer), in place; odd/even call counts hit both halves
     # sizes alternate (large, small, large, ...) without any host synchronisation between calls: a small call must
     # never disturb the half-buffer a slower peer is still reading for the previous large call
@@ -42,8 +57,8 @@ def main():
             pending.append((n, ins[rank].to(dev), want))
     torch.cuda.synchronize()
     dist.barrier()
-    for n, t, want in pending:            # 36 kernels queued back to back
-        ar.all_reduce_(t)
+    for i, (n, t, want) in enumerate(pending):            # 36 kernels queued back to back, algorithms interleaved
+        ar.all_reduce_(t, algos[i % 3])
     torch.cuda.synchronize()
     for n, t, want in pending:
         assert torch.equal(t.cpu().view(torch.int16), want.view(torch.int16)), (n, "back-to-back mismatch")
@@ -52,23 +67,36 @@ def main():
             call += 1
             ins, want = expected(world, n, call)
             t = ins[rank].to(dev)
-            ar.all_reduce_(t)
+            ar.all_reduce_(t, algos[rep])
             got = t.cpu()
             assert torch.equal(got.view(torch.int16), want.view(torch.int16)), (n, rep, "eager mismatch")
+    # fused all-reduce + residual add + RMSNorm: rows of the 8B verify step, a 1B draft step, ragged row counts; the
+    # sum and h are integer-exact, y is compared with the sequence above (the in-row fp32 sum of squares runs in
+    # another order on the GPU: <= 1 bf16 ulp, as for md_add_rmsnorm)
+    for rows, dim in ((256, 4096), (64, 2048), (5, 512), (1, 8192), (67, 1024)):
+        for algo in algos:
+            call += 1
+            ins, x, w, h_want, y_want = expected_fused(world, rows, dim, call, 1e-5)
+            h, y = ar.all_reduce_add_rmsnorm(ins[rank].contiguous().to(dev), x.to(dev), w.to(dev), 1e-5, algo)
+            h, y = h.cpu(), y.cpu()
+            assert torch.equal(h.view(torch.int16), h_want.view(torch.int16)), (rows, dim, algo, "fused h mismatch")
+            d = (y.view(torch.int16).int() - y_want.view(torch.int16).int()).abs()
+            same_sign = (y.view(torch.int16).int() ^ y_want.view(torch.int16).int()) >= 0
+            assert bool((d[same_sign] <= 1).all()) and float((d == 0).float().mean()) > 0.98, (rows, dim, algo, "fused y")
     # a captured graph with three dependent all-reduces, replayed with fresh inputs (flags live in device memory)
     n = 256 * 4096
     static = [torch.zeros(n, dtype=torch.bfloat16, device=dev) for _ in range(3)]
     s = torch.cuda.Stream()
     with torch.cuda.stream(s):
-        for t in static:
-            ar.all_reduce_(t)              # warm-up outside capture
+        for i, t in enumerate(static):
+            ar.all_reduce_(t, algos[i])    # warm-up outside capture
     torch.cuda.current_stream().wait_stream(s)
     torch.cuda.synchronize()
     dist.barrier()
     g = torch.cuda.CUDAGraph()
     with torch.cuda.graph(g, capture_error_mode="thread_local"):
-        for t in static:
-            ar.all_reduce_(t)
+        for i, t in enumerate(static):
+            ar.all_reduce_(t, algos[i])
     for it in range(5):
         wants = []
         for k, t in enumerate(static):
@@ -88,6 +116,7 @@ def main():
     except ValueError:
         pass
     assert ar.status() == 0, "a kernel timed out waiting for its peer"
+    ar.check()
     dist.barrier()
     ar.close()
     dist.destroy_process_group()

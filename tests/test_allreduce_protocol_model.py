@@ -1,129 +1,152 @@
 """Model check (randomised schedules) of the synchronisation protocol of csrc/allreduce.hip -- CPU only.
 
-The kernel's correctness argument (double-buffered data, one monotonic flag per (block, source rank), no closing
-barrier, stream order between calls) is easy to get subtly wrong and cannot be exercised across real GPUs on the
-development box, so the protocol is restated here as interleaved state machines and run under thousands of random
-schedules.  Every rank r executes a sequence of calls; per call every launched block b
+The kernel's correctness argument (double-buffered data and result buffers, one monotonic flag per (block, source
+rank) and hop, a per-call sequence number, a grid sized to the message, no closing barrier, stream order between
+calls) is easy to get subtly wrong and cannot be exercised across real GPUs on the development box, so the protocol
+is restated here as interleaved state machines and run under thousands of random schedules.  Every rank r executes the
+same sequence of calls; call k (k = 1, 2, ..., the same for every block of the call: only the last block to finish
+advances the counter) launches G(k) = min(MAXB, ceil(rows / N)) blocks, and block b
 
-    1. f = ++flag[r][b]; half = f & 1
-    2. writes its slice of the input into data[r][half]        (one micro-step per element)
-    3. stores f into start[p][b][r] of every peer p
-    4. waits until start[r][b][p] >= f for every p
-    5. reads its slice from data[p][half] of every rank p       (one micro-step per element per rank)
+    1. writes the rows of block b into data[r][k & 1]               (rows are dealt by (row / N) % G)
+    2. stores k into start[p][b][r] of every peer p;  waits until start[r][b][p] >= k for every p
+    3. one-shot: reads every row of block b from data[p][k & 1] of every rank p
+       two-shot: reads ITS rows (row % N == r) of block b from every rank, writes them to res[r][k & 1];
+                 stores k into start2[p][b][r] of every p;  waits until start2[r][b][p] >= k;
+                 reads the other owners' rows of block b from res[owner][k & 1]
 
 and a rank starts call k+1 only when all blocks of call k have finished (kernels of one stream run in order).
-Invariant: every element read in call k was written in call k.  The model also shows WHY the launcher always starts
-the full grid: with a message-size-dependent grid the per-block counters drift apart and a small call overwrites a
-region a slower peer is still reading (found by this model, see test_size_dependent_grid_is_unsafe)."""
+Invariant: every element read in call k was written in call k.  Why a message-size-dependent grid is safe here (it
+was not with the per-block call counters of the first version of the kernel, whose blocks could disagree on the
+buffer half): a rank overwrites half (k & 1) in call k+2, i.e. after ALL its blocks finished call k+1, and at least
+one of them (block 0 exists in every call) waited for every peer's call-(k+1) flag -- so every peer had entered call
+k+1 and therefore finished reading in call k."""
 import random
-
-import pytest
 
 MAXB = 4          # blocks of the model (kMaxBlocks = 64 in the kernel)
 
 
-def simulate(n_ranks, sizes, seed, full_grid):
-    """sizes: elements of each call (same on all ranks).  Returns None, or a description of the first violation."""
+def simulate(n_ranks, calls, seed):
+    """calls: list of (rows, two_shot).  Returns None, or a description of the first violation."""
     rng = random.Random(seed)
-    cap = max(sizes)
-    data = [[[None] * cap, [None] * cap] for _ in range(n_ranks)]            # data[r][half][i] = call id written
-    start = [[[0] * n_ranks for _ in range(MAXB)] for _ in range(n_ranks)]   # start[owner][b][src]
-    flag = [[0] * MAXB for _ in range(n_ranks)]
+    N = n_ranks
+    cap = max(c[0] for c in calls)
+    data = [[[None] * cap, [None] * cap] for _ in range(N)]          # data[r][half][row] = call id written
+    res = [[[None] * cap, [None] * cap] for _ in range(N)]
+    start = [[[0] * N for _ in range(MAXB)] for _ in range(N)]       # start[owner][b][src]
+    start2 = [[[0] * N for _ in range(MAXB)] for _ in range(N)]
+    done_calls = [0] * N
 
-    def blocks_of(n):
-        # size-dependent variant: ~2 elements per block up to the block cap, like the first version of the launcher
-        # (ceil(n / 1024 vectors) capped at 64): once the cap is hit the per-block regions grow and overlap the
-        # regions other blocks use in smaller calls
-        return MAXB if full_grid else max(1, min(MAXB, (n + 1) // 2))
+    def grid_of(rows):
+        return max(1, min(MAXB, (rows + N - 1) // N))
 
     class Block:
-        def __init__(self, r, k, b, nb):
-            self.r, self.k, self.b = r, k, b
-            n = sizes[k]
-            per = (n + nb - 1) // nb
-            self.lo, self.hi = b * per, min(n, (b + 1) * per)
-            self.pc, self.i, self.p = 0, self.lo, 0
-            self.f = self.half = None
+        def __init__(self, r, ci, b, G):
+            self.r, self.ci, self.b, self.G = r, ci, b, G
+            self.rows_n, self.two = calls[ci]
+            self.k = done_calls[r] + 1
+            self.half = self.k & 1
+            self.rows = [i for i in range(self.rows_n) if (i // N) % G == b]
+            self.mine = [i for i in self.rows if i % N == r]
+            self.others = [i for i in self.rows if i % N != r]
+            self.pc, self.i, self.p = 0, 0, 0
             self.done = False
 
         def runnable(self):
-            if self.pc == 3:      # spinning on the peers' flags
-                return all(start[self.r][self.b][p] >= self.f for p in range(n_ranks))
+            if self.pc == 3:
+                return all(start[self.r][self.b][p] >= self.k for p in range(N))
+            if self.pc == 6:
+                return all(start2[self.r][self.b][p] >= self.k for p in range(N))
             return True
 
         def step(self):
-            r, b = self.r, self.b
+            r, b, k, h = self.r, self.b, self.k, self.half
             if self.pc == 0:
-                flag[r][b] += 1
-                self.f, self.half = flag[r][b], flag[r][b] & 1
-                self.pc = 1 if self.lo < self.hi else 2
-            elif self.pc == 1:                                   # copy one element of my slice
-                data[r][self.half][self.i] = self.k
+                self.pc, self.i = (1 if self.rows else 2), 0
+            elif self.pc == 1:                                   # publish one row
+                data[r][h][self.rows[self.i]] = k
                 self.i += 1
-                if self.i == self.hi:
-                    self.pc = 2
+                if self.i == len(self.rows):
+                    self.pc, self.p = 2, 0
             elif self.pc == 2:                                   # raise my flag at one peer per micro-step
-                start[self.p][b][r] = self.f
+                start[self.p][b][r] = k
                 self.p += 1
-                if self.p == n_ranks:
-                    self.pc, self.p, self.i = 3, 0, self.lo
+                if self.p == N:
+                    self.pc = 3
             elif self.pc == 3:
-                self.pc = 4 if self.lo < self.hi else 5
-            elif self.pc == 4:                                   # read one element of one rank's buffer
-                got = data[self.p][self.half][self.i]
-                if got != self.k:
-                    return (f"rank {r} call {self.k} block {b}: read element {self.i} of rank {self.p} half "
-                            f"{self.half} written by call {got}")
+                self.pc, self.i, self.p = 4, 0, 0
+                if not (self.mine if self.two else self.rows):
+                    self.pc = 5 if self.two else 9
+            elif self.pc == 4:                                   # read one row of one rank's data buffer
+                rows = self.mine if self.two else self.rows
+                row = rows[self.i]
+                got = data[self.p][h][row]
+                if got != k:
+                    return f"rank {r} call {k} block {b}: read row {row} of rank {self.p} data half {h} written by call {got}"
+                self.p += 1
+                if self.p == N:
+                    self.p = 0
+                    if self.two:
+                        res[r][h][row] = k
+                    self.i += 1
+                    if self.i == len(rows):
+                        self.pc, self.p = (5 if self.two else 9), 0
+            elif self.pc == 5:                                   # second hop flags
+                start2[self.p][b][r] = k
+                self.p += 1
+                if self.p == N:
+                    self.pc = 6
+            elif self.pc == 6:
+                self.pc, self.i = (7 if self.others else 9), 0
+            elif self.pc == 7:                                   # gather one row from its owner's result buffer
+                row = self.others[self.i]
+                got = res[row % N][h][row]
+                if got != k:
+                    return f"rank {r} call {k} block {b}: gathered row {row} of owner {row % N} half {h} from call {got}"
                 self.i += 1
-                if self.i == self.hi:
-                    self.i, self.p = self.lo, self.p + 1
-                    if self.p == n_ranks:
-                        self.pc = 5
-            if self.pc == 5:
+                if self.i == len(self.others):
+                    self.pc = 9
+            if self.pc == 9:
                 self.done = True
             return None
 
-    call = [0] * n_ranks
-    live = [[] for _ in range(n_ranks)]
-    for r in range(n_ranks):
-        nb = blocks_of(sizes[0])
-        live[r] = [Block(r, 0, b, nb) for b in range(nb)]
-    steps = 0
-    while any(call[r] < len(sizes) for r in range(n_ranks)):
-        cands = [blk for r in range(n_ranks) for blk in live[r] if not blk.done and blk.runnable()]
+    ci = [0] * N
+    live = [[Block(r, 0, b, grid_of(calls[0][0])) for b in range(grid_of(calls[0][0]))] for r in range(N)]
+    while any(ci[r] < len(calls) for r in range(N)):
+        cands = [blk for r in range(N) for blk in live[r] if not blk.done and blk.runnable()]
         assert cands, "deadlock"
-        # bias the schedule: now and then let one rank sprint ahead, the interesting interleavings
         blk = rng.choice(cands)
-        for _ in range(rng.choice((1, 1, 1, 4, 16))):
+        for _ in range(rng.choice((1, 1, 1, 4, 16))):           # now and then let one block sprint ahead
             err = blk.step()
-            steps += 1
             if err:
                 return err
             if blk.done or not blk.runnable():
                 break
         r = blk.r
         if all(x.done for x in live[r]):
-            call[r] += 1
-            if call[r] < len(sizes):
-                nb = blocks_of(sizes[call[r]])
-                live[r] = [Block(r, call[r], b, nb) for b in range(nb)]
+            done_calls[r] += 1                                   # the last block advances the call counter
+            ci[r] += 1
+            if ci[r] < len(calls):
+                G = grid_of(calls[ci[r]][0])
+                live[r] = [Block(r, ci[r], b, G) for b in range(G)]
             else:
                 live[r] = []
     return None
 
 
-SIZES = [16, 4, 16, 2, 6, 16, 3, 8, 16, 7, 16, 16, 1, 12, 4, 16]      # alternating large / small messages
+ROWS = [16, 4, 16, 2, 6, 16, 3, 8, 16, 7, 16, 16, 1, 12, 4, 16]      # alternating large / small messages
 
 
-@pytest.mark.parametrize("n_ranks", [2, 3, 4])
-def test_protocol_invariant_under_random_schedules(n_ranks):
-    for seed in range(400):
-        err = simulate(n_ranks, SIZES, seed, full_grid=True)
-        assert err is None, (seed, err)
+def _calls(mode):
+    if mode == "oneshot":
+        return [(n, False) for n in ROWS]
+    if mode == "twoshot":
+        return [(n, True) for n in ROWS]
+    return [(n, i % 3 == 1) for i, n in enumerate(ROWS)]             # mixed, as the auto policy produces
 
 
-def test_size_dependent_grid_is_unsafe():
-    """The variant the kernel does NOT use: launching only as many blocks as the message needs.  The model finds a
-    schedule in which a rank reads data of the wrong call (the reason md_allreduce_oneshot always launches the full
-    grid)."""
-    assert any(simulate(2, SIZES, seed, full_grid=False) is not None for seed in range(400))
+def test_protocol_invariant_under_random_schedules():
+    for n_ranks in (2, 3, 4):
+        for mode in ("oneshot", "twoshot", "mixed"):
+            for seed in range(150):
+                err = simulate(n_ranks, _calls(mode), seed)
+                assert err is None, (n_ranks, mode, seed, err)
