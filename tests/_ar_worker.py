@@ -72,7 +72,8 @@ def main():
             assert torch.equal(got.view(torch.int16), want.view(torch.int16)), (n, rep, "eager mismatch")
     # fused all-reduce + residual add + RMSNorm: rows of the 8B verify step, a 1B draft step, ragged row counts; the
     # sum and h are integer-exact, y is compared with the sequence above (the in-row fp32 sum of squares runs in
-    # another order on the GPU: <= 1 bf16 ulp, as for md_add_rmsnorm)
+    # another order on the GPU: a 1-ulp flip of bf16(h * rstd) becomes at most 2 ulps after the bf16 multiply by w;
+    # > 99.9 % of the elements are bit-equal)
     for rows, dim in ((256, 4096), (64, 2048), (5, 512), (1, 8192), (67, 1024)):
         for algo in algos:
             call += 1
@@ -82,7 +83,11 @@ def main():
             assert torch.equal(h.view(torch.int16), h_want.view(torch.int16)), (rows, dim, algo, "fused h mismatch")
             d = (y.view(torch.int16).int() - y_want.view(torch.int16).int()).abs()
             same_sign = (y.view(torch.int16).int() ^ y_want.view(torch.int16).int()) >= 0
-            assert bool((d[same_sign] <= 1).all()) and float((d == 0).float().mean()) > 0.98, (rows, dim, algo, "fused y")
+            bad_rows = sorted(set(torch.nonzero((d > 2) & same_sign)[:, 0].tolist()))
+            assert bool((d[same_sign] <= 2).all()) and float((d == 0).float().mean()) > 0.999, (
+                rows, dim, algo, "fused y", "equal fraction", float((d == 0).float().mean()), "max d", int(d.max()),
+                "rows with d > 2", bad_rows[:20], len(bad_rows), "y", y[bad_rows[0], :4].tolist() if bad_rows else None,
+                "want", y_want[bad_rows[0], :4].tolist() if bad_rows else None)
     # a captured graph with three dependent all-reduces, replayed with fresh inputs (flags live in device memory)
     n = 256 * 4096
     static = [torch.zeros(n, dtype=torch.bfloat16, device=dev) for _ in range(3)]
