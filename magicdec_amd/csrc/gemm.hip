@@ -19,6 +19,10 @@
 //   * split-K across workgroups (grid.y) so that even N = 2048 yields >= 256 workgroups; partial sums are written as
 //     fp32 and combined IN A FIXED ORDER by a small second kernel (deterministic: graph replays, eager runs and TP
 //     ranks see the same bits), which also applies the epilogue; with one K slice the epilogue runs in the main kernel.
+//     (Two alternatives were built, measured and removed: the last-arriving slice combining in-kernel -- one workgroup
+//     reading S 32-KB slabs serially is 2x slower than the parallel combine kernel -- and a "short-stream" variant with
+//     K split over the waves of one workgroup and the activations loaded straight from global memory in MFMA layout --
+//     32-byte pieces of 32 rows per instruction: 1.4-3x slower.  profiles/r02_gemm_ab_*_rejected.txt)
 // Epilogues: bias add (Qwen wqkv), SwiGLU (w1|w3: a wavefront takes 16 rows of w1 and the matching 16 rows of w3 as
 // its 32 columns, so silu(h1)*h3 needs one cross-lane move; rounding points of the reference: h1, h3 -> bf16,
 // silu -> bf16, product -> bf16), weight-only int8 (Engine/quantize.py:72-86: bf16(acc) * bf16 scale -> bf16).
@@ -76,8 +80,8 @@ __device__ __forceinline__ bf16x8 ld_w(const void* base, int64_t elem_off) {
 }
 
 __device__ __forceinline__ float silu_bf16(float h1) {
-    // F.silu on a bf16 tensor: computed in fp32, rounded to bf16 (x * sigmoid(x))
-    return bf16_to_f32(f32_to_bf16(h1 / (1.0f + __expf(-h1))));
+    // F.silu on a bf16 tensor: computed in fp32, rounded to bf16 (x * sigmoid(x)); same expression as md_silu_mul
+    return bf16_to_f32(f32_to_bf16(h1 / (1.0f + expf(-h1))));
 }
 
 // One workgroup: 4 wavefronts x 32 GEMM columns, rows [0, M), k in [blockIdx.y*kblk, +kblk).

@@ -80,7 +80,13 @@ def main():
             ins, x, w, h_want, y_want = expected_fused(world, rows, dim, call, 1e-5)
             h, y = ar.all_reduce_add_rmsnorm(ins[rank].contiguous().to(dev), x.to(dev), w.to(dev), 1e-5, algo)
             h, y = h.cpu(), y.cpu()
-            assert torch.equal(h.view(torch.int16), h_want.view(torch.int16)), (rows, dim, algo, "fused h mismatch")
+            if not torch.equal(h.view(torch.int16), h_want.view(torch.int16)):
+                neq = h.view(torch.int16) != h_want.view(torch.int16)
+                rws = sorted(set(torch.nonzero(neq)[:, 0].tolist()))
+                raise AssertionError((rows, dim, algo, "fused h mismatch", "elements", int(neq.sum()), "rows", rws[:24],
+                                      len(rws), "nan", int(torch.isnan(h.float()).sum()), "status", ar.status(),
+                                      "got", h[rws[0], :4].tolist(), "want", h_want[rws[0], :4].tolist(),
+                                      "x", x[rws[0], :4].tolist()))
             d = (y.view(torch.int16).int() - y_want.view(torch.int16).int()).abs()
             same_sign = (y.view(torch.int16).int() ^ y_want.view(torch.int16).int()) >= 0
             bad_rows = sorted(set(torch.nonzero((d > 2) & same_sign)[:, 0].tolist()))

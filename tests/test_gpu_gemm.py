@@ -35,13 +35,21 @@ def _neighbours(t):
     return f(dn), t, f(up)
 
 
-def _matches_some_neighbour(y, fn, h1, h3=None):
+def _matches_some_neighbour(y, fn, h1, h3=None, silu_ulp=False):
     """y equals fn evaluated on the correctly rounded GEMM output(s) or on a 1-ulp neighbour of them: what a different
     fp32 summation order can legitimately produce at a rounding boundary (elementwise)."""
     ok = torch.zeros(y.shape, dtype=torch.bool)
     for a in _neighbours(h1):
         for b in (_neighbours(h3) if h3 is not None else (None,)):
-            ok |= (fn(a, b) == y)
+            cand = fn(a, b)
+            if silu_ulp:
+                # + SiLU's own <= 1 ulp (expf implementation), which the bf16 multiply by h3 can turn into 2 ulps of
+                # the product: accept a bit distance <= 2 from the candidate
+                ci, yi = cand.contiguous().view(torch.int16).int(), y.contiguous().view(torch.int16).int()
+                ok |= ((ci - yi).abs() <= 2) & ((ci ^ yi) >= 0)
+                ok |= (cand.float().abs() < 1e-30) & (y.float().abs() < 1e-30)
+            else:
+                ok |= (cand == y)
     return ok
 
 
@@ -86,7 +94,8 @@ def test_linear_vs_exact(ops, M, N, K, bias, packed):
 def test_linear_swiglu_epilogue(ops, M, I, K, packed):
     """silu(x.w1^T) * (x.w3^T) with the reference's rounding points (h1, h3 -> bf16; silu -> bf16; product -> bf16,
     Engine/SnapKV/model.py:451-455): >= 99.9 % bit-equal to that sequence evaluated on the correctly rounded h1 / h3,
-    and every other element equals it evaluated on a 1-ulp neighbour of h1 / h3 (an fp32 sum on a rounding boundary)."""
+    and every other element equals it evaluated on a 1-ulp neighbour of h1 / h3 (an fp32 sum on a rounding boundary),
+    up to the 1 ulp the SiLU itself is gated at (expf implementation; tests/test_gpu_ops.py::test_silu_mul)."""
     g = torch.Generator().manual_seed(M + I + K)
     x = torch.randn(M, K, generator=g).to(BF)
     w13 = (torch.randn(2 * I, K, generator=g) * 0.08).to(BF)
@@ -97,7 +106,7 @@ def test_linear_swiglu_epilogue(ops, M, I, K, packed):
     y = ops.linear(x.to(DEV), wd, swiglu=True, workspace=ws).cpu()
     assert y.shape == (M, I)
     eq = float((y == ref).double().mean())
-    ok = _matches_some_neighbour(y, lambda a, b: F.silu(a) * b, h[:, :I], h[:, I:])
+    ok = _matches_some_neighbour(y, lambda a, b: F.silu(a) * b, h[:, :I], h[:, I:], silu_ulp=True)
     parity_report(f"[gemm] swiglu M={M} I={I} K={K} packed={int(packed)}: bit-equal to the correctly rounded sequence "
                   f"{100 * eq:.3f}%; the rest explained by a 1-ulp neighbour of h1/h3: {bool(ok.all())}")
     assert eq >= 0.999 and bool(ok.all())
@@ -123,7 +132,8 @@ def test_linear_int8_weight_only(ops, M, N, K, swiglu):
         y = ops.linear(x.to(DEV), wdev, scales=sc.to(DEV), swiglu=swiglu, workspace=ws).cpu()
         eq = float((y == ref).double().mean())
         if swiglu:
-            ok = _matches_some_neighbour(y, lambda a, b: F.silu(a * sc[:I]) * (b * sc[I:]), g0[:, :I], g0[:, I:])
+            ok = _matches_some_neighbour(y, lambda a, b: F.silu(a * sc[:I]) * (b * sc[I:]), g0[:, :I], g0[:, I:],
+                                         silu_ulp=True)
         else:
             ok = _matches_some_neighbour(y, lambda a, b: a * sc, g0)
         parity_report(f"[gemm] int8 M={M} N={N} K={K} swiglu={int(swiglu)} {tag}: bit-equal {100 * eq:.3f}%; rest "

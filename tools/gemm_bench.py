@@ -26,8 +26,12 @@ SHAPES = [("1B wqkv", 64, 3072, 2048, 0), ("1B wo", 64, 2048, 2048, 0), ("1B w13
           ("8B w2 v", 256, 4096, 14336, 0), ("8B head v", 256, 128256, 4096, 0),
           ("8B wqkv ar", 64, 6144, 4096, 0), ("8B wo ar", 64, 4096, 4096, 0), ("8B w13 ar", 64, 28672, 4096, 1),
           ("8B w2 ar", 64, 4096, 14336, 0), ("8B head ar", 64, 128256, 4096, 0),
-          ("8B wqkv c2", 32, 6144, 4096, 0), ("8B w13 c2", 32, 28672, 4096, 1), ("8B w2 c2", 32, 4096, 14336, 0),
+          ("8B wqkv c2", 32, 6144, 4096, 0), ("8B wo c2", 32, 4096, 4096, 0), ("8B w13 c2", 32, 28672, 4096, 1),
+          ("8B w2 c2", 32, 4096, 14336, 0),
           ("8B wqkv c2v", 128, 6144, 4096, 0), ("8B w13 c2v", 128, 28672, 4096, 1), ("8B w2 c2v", 128, 4096, 14336, 0),
+          ("8B/8 wqkv ar", 64, 768, 4096, 0), ("8B/8 wo ar", 64, 4096, 512, 0), ("8B/8 w13 ar", 64, 3584, 4096, 1),
+          ("8B/8 w2 ar", 64, 4096, 1792, 0), ("1B/4 wqkv", 64, 768, 2048, 0), ("1B/4 wo", 64, 2048, 512, 0),
+          ("1B/4 w13", 64, 4096, 2048, 1), ("1B/4 w2", 64, 2048, 2048, 0),
           ("8B/8 wqkv v", 256, 768, 4096, 0), ("8B/8 wo v", 256, 4096, 512, 0), ("8B/8 w13 v", 256, 3584, 4096, 1),
           ("8B/8 w2 v", 256, 4096, 1792, 0)]
 
