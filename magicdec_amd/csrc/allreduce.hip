@@ -77,6 +77,15 @@ struct ArArgs {
     size_t n_vec;              // total vectors
 };
 
+// System-scope release of everything this wave has stored.  The explicit s_waitcnt after the fence restates the wait
+// behind buffer_wbl2 where the compiler cannot drop it (ROCm 7.2 drops it when its scoreboard believes nothing is
+// outstanding -- MI355X_MICROARCH.md "Compiler hazard": the flag can then overtake the write-back and a peer reads
+// stale rows, observed here as a rare mismatch in the 3-process stress test before this line existed).
+__device__ __forceinline__ void publish_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+}
+
 __device__ __forceinline__ bool spin_ge(const uint32_t* p, uint32_t want) {
     const unsigned long long t0 = wall_clock64();
     while ((int32_t)(__hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - want) < 0) {
@@ -188,10 +197,11 @@ __global__ __launch_bounds__(kThreads) void allreduce_kernel(const ArDev c, cons
             for (size_t i = v0 + tid; i < v1; i += kThreads) mine[i] = src[i];
         }
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");   // every wave: its copies are written back before the flag is raised
+    publish_fence();                                // every wave: its copies are written back before the flag is raised
     __syncthreads();
     // 2. first hop
     if (tid < NR) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __hip_atomic_store(&c.sig[tid]->start[b][c.rank], k, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         if (!spin_ge(&self->start[b][tid], k)) s_bad = 1;
     }
@@ -251,10 +261,11 @@ __global__ __launch_bounds__(kThreads) void allreduce_kernel(const ArDev c, cons
             }
             finish_row<FUSED>(a, row, lane, nv, s, bad);
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+        publish_fence();
         __syncthreads();
         // 3b. second hop
         if (tid < NR) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __hip_atomic_store(&c.sig[tid]->start2[b][c.rank], k, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
             if (!spin_ge(&self->start2[b][tid], k)) s_bad = 1;
         }
