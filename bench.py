@@ -157,6 +157,10 @@ def run(args, dev):
     os.environ.setdefault("LOCAL_WORLD_SIZE", str(world))
 
     from magicdec_amd import harness, _lib
+    from magicdec_amd.Engine import gemm_policy
+    gemm_mode = {"auto": "md_linear (streaming layout) for the long weight streams, hipBLASLt otherwise "
+                         "(Engine/gemm_policy.py)", "hip": "md_linear everywhere it supports the shape",
+                 "lib": "hipBLASLt only"}[gemm_policy.mode()]
     from magicdec_amd.Engine import model_core
     from magicdec_amd.Engine.SnapKV.backend import LMBackend
     from magicdec_amd.Engine.SnapKV.backend_draft import LMBackend_Draft
@@ -416,6 +420,9 @@ def run(args, dev):
                    "acceptance": f"fixed replay alpha={args.alpha} (E[tokens/iter]={tok_replay / args.steps / B:.3f})",
                    "weights": "seeded random init (no checkpoints on the box)",
                    "hip_graphs": bool(engine._use_graphs),
+                   "iteration_graph": bool(getattr(engine, "_iter_graphs", None) is not None
+                                           and any(b.graph is not None for b in engine._iter_graphs.bodies.values())),
+                   "gemm": gemm_mode,
                    **({"emulated_tp_rank0_of": emu} if emu > 1 else {}),
                    "allreduce": (None if not use_tp else
                                  "oneshot-ipc" if getattr(engine.model, "_oneshot", None) is not None else "rccl"),
@@ -514,7 +521,10 @@ def cpu_baseline(tgt_name, drf_name, S, budget, gamma, alpha, Bc=4):
     from magicdec_amd.Engine.model_core import ModelArgs
     from oracle import flashinfer_ref as fr
     from oracle import magicdec_ref as mr
-    ncores = os.cpu_count() or 1
+    # threads actually used: the M = 4..16-row products and the per-request attention loops of the restatement do not
+    # scale past a few cores -- on the 256-core host of the GPU box torch.set_num_threads(256) ran the same sample 80x
+    # SLOWER than 8 threads (thread wake-up / NUMA traffic dominates), so the pool is capped and the cap is reported
+    ncores = min(os.cpu_count() or 1, 16)
     torch.set_num_threads(ncores)
     t_all = time.perf_counter()
 
@@ -582,7 +592,8 @@ def cpu_baseline(tgt_name, drf_name, S, budget, gamma, alpha, Bc=4):
 
     iter_s = gamma * (n_d * tl_d + th_d + te_d) + (n_t * tl_t + th_t + te_t)
     e_tok = sum(alpha ** j for j in range(gamma + 1))
-    return {"value": round(Bc * e_tok / iter_s, 4), "unit": "tokens/s", "cores": ncores, "kind": "port",
+    return {"value": round(Bc * e_tok / iter_s, 4), "unit": "tokens/s", "cores": ncores,
+            "host_cores": os.cpu_count(), "kind": "port",
             "sample": f"oracle (torch-eager CPU restatement), batch {Bc}, prefix {S}, random KV: 1 of {n_t} target layers "
                       f"at {gamma + 1} rows/request ({tl_t * 1e3:.1f} ms) + target head ({th_t * 1e3:.1f} ms) + embedding "
                       f"({te_t * 1e3:.2f} ms); 1 of {n_d} draft layers at 1 row/request over the {budget}-row SnapKV cache "

@@ -129,6 +129,18 @@ def _draft_round(step_fn, st: LoopState, gamma, next_double):
             st.tokens_buffer[:, i + 1:i + 2] = step_fn(st.tokens_buffer[:, i].view(-1, 1), None)
 
 
+def _iterate(engine, draft, st: LoopState, key, body, forced, timers):
+    """Runs one iteration body: as ONE hipGraph when the back-ends were compile()d (Engine/itergraph.py), else (or
+    with per-phase timers, which need host synchronisation inside the iteration) launch by launch."""
+    from .Engine import itergraph
+    if timers is None and itergraph.enabled(engine, draft):
+        itergraph.get(engine, draft).run(key, st, body, forced)
+    else:
+        body(forced)
+    st.iters += 1
+    return _read_flags(st)
+
+
 def longspec_iteration(engine, draft, st: LoopState, gamma, eot_1, eot_2, max_nodes, next_double,
                        forced_accept=None, bcast=None, timers: PhaseTimers = None):
     """One iteration of the longspec loop: gamma draft steps, one verify, the fused accept/rollback.
@@ -137,27 +149,29 @@ def longspec_iteration(engine, draft, st: LoopState, gamma, eot_1, eot_2, max_no
     Tensor parallel (tests/SnapKV/longspec_benchmark.py:163-189): `draft` is None on ranks outside the draft
     sub-group; when the draft group is smaller than the target group the gamma draft tokens are broadcast from
     `bcast = (src_rank, group)` before the verify.  Every rank runs the (replicated, all-integer) accept kernel."""
-    if timers is not None:
-        timers.start()
-    if draft is not None:
-        _draft_round(lambda ids, cu: draft.inference(ids, cachelen_update=cu), st, gamma, next_double)
-    if bcast is not None:
-        import torch.distributed as dist
-        dist.broadcast(st.tokens_buffer, src=bcast[0], group=bcast[1])
-    if timers is not None:
-        timers.lap("draft")
-    target_tokens = engine.inference(st.tokens_buffer)
-    if timers is not None:
-        timers.lap("target")
-    if forced_accept is not None:
-        target_tokens = _force_accept(st.tokens_buffer, target_tokens, forced_accept, gamma)
-    ops.accept_rollback(st.tokens_buffer, target_tokens, st.output, st.num_nodes, engine.cachelens,
-                        engine.paged_kv_last_page_len, draft.cachelens if draft is not None else None,
-                        draft.paged_kv_last_page_len if draft is not None else None, gamma,
-                        gamma, gamma, eot_1, eot_2, max_nodes, st.accept_nums, st.bonus, st.double_buffer,
-                        st.cachelens_update, st.flags)
-    st.iters += 1
-    res = _read_flags(st)
+    def body(forced):
+        if timers is not None:
+            timers.start()
+        if draft is not None:
+            _draft_round(lambda ids, cu: draft.inference(ids, cachelen_update=cu), st, gamma, next_double)
+        if bcast is not None:
+            import torch.distributed as dist
+            dist.broadcast(st.tokens_buffer, src=bcast[0], group=bcast[1])
+        if timers is not None:
+            timers.lap("draft")
+        target_tokens = engine.inference(st.tokens_buffer)
+        if timers is not None:
+            timers.lap("target")
+        if forced is not None:
+            target_tokens = _force_accept(st.tokens_buffer, target_tokens, forced, gamma)
+        ops.accept_rollback(st.tokens_buffer, target_tokens, st.output, st.num_nodes, engine.cachelens,
+                            engine.paged_kv_last_page_len, draft.cachelens if draft is not None else None,
+                            draft.paged_kv_last_page_len if draft is not None else None, gamma,
+                            gamma, gamma, eot_1, eot_2, max_nodes, st.accept_nums, st.bonus, st.double_buffer,
+                            st.cachelens_update, st.flags)
+    key = ("longspec", bool(next_double), forced_accept is not None, gamma, int(eot_1), int(eot_2), int(max_nodes),
+           bcast is not None)
+    res = _iterate(engine, draft, st, key, body, forced_accept, timers)
     if timers is not None:
         timers.lap("verify_loop")
     return res
@@ -167,31 +181,33 @@ def selfspec_iteration(engine, st: LoopState, gamma, eot_1, eot_2, max_nodes, ne
                        forced_accept=None, timers: PhaseTimers = None):
     """One iteration of tests/SnapKV/selfspec_benchmark.py:121-211 (streaming=False: draft rolled back by
     gamma+1 and advanced by accept_nums, no two-token step) or tests/StreamingLLM/selfspec_benchmark.py:121-238."""
-    if timers is not None:
-        timers.start()
-    if streaming:
-        _draft_round(lambda ids, cu: engine.speculate(ids, cachelen_update=cu), st, gamma, next_double)
-    else:
-        _draft_round(lambda ids, cu: engine.speculate(ids), st, gamma, False)
-    if timers is not None:
-        timers.lap("draft")
-    target_tokens = engine.verify(st.tokens_buffer)
-    if timers is not None:
-        timers.lap("target")
-    if forced_accept is not None:
-        target_tokens = _force_accept(st.tokens_buffer, target_tokens, forced_accept, gamma)
-    if streaming:
-        ops.accept_rollback(st.tokens_buffer, target_tokens, st.output, st.num_nodes, engine.cachelens,
-                            engine.paged_kv_last_page_len, engine.draft_cachelens,
-                            engine.draft_paged_kv_last_page_len, gamma, gamma, gamma, eot_1, eot_2, max_nodes,
-                            st.accept_nums, st.bonus, st.double_buffer, st.cachelens_update, st.flags)
-    else:
-        ops.accept_rollback(st.tokens_buffer, target_tokens, st.output, st.num_nodes, engine.cachelens,
-                            engine.paged_kv_last_page_len, engine.draft_cachelens,
-                            engine.draft_paged_kv_last_page_len, gamma, gamma + 1, gamma + 1, eot_1, eot_2, max_nodes,
-                            st.accept_nums, st.bonus, None, None, st.flags)
-    st.iters += 1
-    res = _read_flags(st)
+    def body(forced):
+        if timers is not None:
+            timers.start()
+        if streaming:
+            _draft_round(lambda ids, cu: engine.speculate(ids, cachelen_update=cu), st, gamma, next_double)
+        else:
+            _draft_round(lambda ids, cu: engine.speculate(ids), st, gamma, False)
+        if timers is not None:
+            timers.lap("draft")
+        target_tokens = engine.verify(st.tokens_buffer)
+        if timers is not None:
+            timers.lap("target")
+        if forced is not None:
+            target_tokens = _force_accept(st.tokens_buffer, target_tokens, forced, gamma)
+        if streaming:
+            ops.accept_rollback(st.tokens_buffer, target_tokens, st.output, st.num_nodes, engine.cachelens,
+                                engine.paged_kv_last_page_len, engine.draft_cachelens,
+                                engine.draft_paged_kv_last_page_len, gamma, gamma, gamma, eot_1, eot_2, max_nodes,
+                                st.accept_nums, st.bonus, st.double_buffer, st.cachelens_update, st.flags)
+        else:
+            ops.accept_rollback(st.tokens_buffer, target_tokens, st.output, st.num_nodes, engine.cachelens,
+                                engine.paged_kv_last_page_len, engine.draft_cachelens,
+                                engine.draft_paged_kv_last_page_len, gamma, gamma + 1, gamma + 1, eot_1, eot_2,
+                                max_nodes, st.accept_nums, st.bonus, None, None, st.flags)
+    key = ("selfspec", bool(streaming), bool(next_double) and bool(streaming), forced_accept is not None, gamma,
+           int(eot_1), int(eot_2), int(max_nodes))
+    res = _iterate(engine, None, st, key, body, forced_accept, timers)
     if timers is not None:
         timers.lap("verify_loop")
     return res
