@@ -6,6 +6,12 @@ iteration on one GPU (profiles/r01_bench_cfg3_iter_breakdown.csv: "idle"), and t
 shrink under tensor parallelism.  Nothing in an iteration reads device memory on the host -- the one host read (the
 terminal / next_double flags) happens AFTER it -- so the whole body is capturable: one launch per iteration.
 
+MEASURED (profiles/r02_bench_cfg3_itergraph.log vs r02_bench_cfg3.json, same code otherwise): on one GPU the
+whole-iteration graph is NOT faster -- 31.74 ms against 31.36 ms per iteration with per-step graphs (the host already
+runs ahead of the GPU; the per-node cost inside one large graph is the same) and each body costs a ~25 ms capture.
+It is therefore OFF by default (MAGICDEC_ITER_GRAPH=1 turns it on; graphs == eager is tested with it on) and kept for
+the tensor-parallel case, where a rank's kernels are 3-8x shorter and the host-side launch rate is the limit.
+
 There are two bodies per loop (the first draft step consumes one token, or two after an all-accept iteration:
 tests/SnapKV/longspec_benchmark.py:165-188), selected by the flag the host read at the end of the previous iteration.
 
@@ -31,7 +37,7 @@ CAPTURE_AFTER = 2          # iterations of a kind run with step graphs before it
 
 
 def enabled(*backends) -> bool:
-    if os.environ.get("MAGICDEC_ITER_GRAPH", "1") == "0":
+    if os.environ.get("MAGICDEC_ITER_GRAPH", "0") != "1":
         return False
     bs = [b for b in backends if b is not None]
     return bool(bs) and all(getattr(b, "_use_graphs", False) and torch.device(b.device).type == "cuda" for b in bs)
