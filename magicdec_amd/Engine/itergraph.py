@@ -6,8 +6,8 @@ iteration on one GPU (profiles/r01_bench_cfg3_iter_breakdown.csv: "idle"), and t
 shrink under tensor parallelism.  Nothing in an iteration reads device memory on the host -- the one host read (the
 terminal / next_double flags) happens AFTER it -- so the whole body is capturable: one launch per iteration.
 
-MEASURED (profiles/r02_bench_cfg3_itergraph.log vs r02_bench_cfg3.json, same code otherwise): on one GPU the
-whole-iteration graph is NOT faster -- 31.74 ms against 31.36 ms per iteration with per-step graphs (the host already
+MEASURED (profiles/r02_ab_iteration_graph.txt, same box, back to back): on one GPU the
+whole-iteration graph is NOT faster -- 31.53-31.67 ms against 31.51-31.64 ms per iteration with per-step graphs (the host already
 runs ahead of the GPU; the per-node cost inside one large graph is the same) and each body costs a ~25 ms capture.
 It is therefore OFF by default (MAGICDEC_ITER_GRAPH=1 turns it on; graphs == eager is tested with it on) and kept for
 the tensor-parallel case, where a rank's kernels are 3-8x shorter and the host-side launch rate is the limit.
