@@ -447,10 +447,68 @@ def run(args, dev):
     }
     if rank == 0 and not args.no_cpu_baseline and world == 1 and not selfspec:
         line["cpu_baseline"] = cpu_baseline(tgt_name, drf_name, S, BUDGET, G, args.alpha)
+    if use_tp and world > 1 and on_gpu and os.environ.get("MAGICDEC_BENCH_COLLECTIVES", "1") != "0":
+        # after every number of the line has been taken: what one per-layer collective of this run costs, RCCL against
+        # the xGMI kernels (never run over real links before the first multi-GPU bench: this is where they get measured)
+        dim_t = engine.model.tok_embeddings.weight.shape[1]
+        try:
+            coll = collective_microbench(group, [("verify", B * (G + 1), dim_t), ("autoregressive", B, dim_t)], dev)
+        except Exception as e:  # noqa: BLE001 -- a report, never a reason to lose the line
+            coll = {"error": f"{type(e).__name__}: {e}"}
+        if rank == 0:
+            line["collectives_us"] = coll
     if use_tp:
         dist.barrier()
         dist.destroy_process_group()
     return line if rank == 0 else None
+
+
+def collective_microbench(group, shapes, dev, iters=30):
+    """Mean time (us, max over ranks) of ONE per-layer all-reduce of this run's hidden-state messages [rows, dim] bf16:
+    RCCL (`dist.all_reduce`, what the timed run used) followed by the add + RMSNorm kernel, against the xGMI kernels of
+    csrc/allreduce.hip (one-shot, two-shot, and fused with the add + RMSNorm), each queued `iters` times back to back
+    between two events.  The xGMI communicator is created here (collective, validated against RCCL by its self-test;
+    `None` -> reported as unavailable).  Every rank runs the same sequence; the kernels' spins are bounded."""
+    from magicdec_amd import ops
+    from magicdec_amd.Engine import oneshot
+    out = {}
+    ar = oneshot.try_create(group)
+
+    def timed(fn):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        dist.barrier(group=group)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        t = torch.tensor([e0.elapsed_time(e1) / iters * 1e3], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+        return round(float(t.item()), 2)
+
+    for name, rows, dim in shapes:
+        x = torch.randn(rows, dim, device=dev, dtype=torch.float32).to(torch.bfloat16)
+        res = torch.randn(rows, dim, device=dev, dtype=torch.float32).to(torch.bfloat16)
+        w = torch.ones(dim, device=dev, dtype=torch.bfloat16)
+        buf = x.clone()
+        r = {"bytes": rows * dim * 2}
+        r["rccl_allreduce"] = timed(lambda: dist.all_reduce(buf, group=group))
+        r["rccl_allreduce_then_add_rmsnorm"] = timed(lambda: (dist.all_reduce(buf, group=group),
+                                                              ops.add_rmsnorm(res, buf, w, 1e-5)))
+        if ar is not None and ar.fits(buf):
+            r["xgmi_oneshot"] = timed(lambda: ar.all_reduce_(buf, oneshot.ALGO_ONESHOT))
+            r["xgmi_twoshot"] = timed(lambda: ar.all_reduce_(buf, oneshot.ALGO_TWOSHOT))
+            r["xgmi_fused_add_rmsnorm_auto"] = timed(lambda: ar.all_reduce_add_rmsnorm(x, res, w, 1e-5))
+            r["xgmi_timeouts"] = ar.status()
+        else:
+            r["xgmi"] = "unavailable (set-up or self-test against RCCL failed on some rank)"
+        out[name] = r
+    if ar is not None:
+        ar.close()
+    return out
 
 
 def measure_traffic(B, L_kv, KH, H, D, n, fp8):

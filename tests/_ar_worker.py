@@ -62,7 +62,7 @@ def main():
     torch.cuda.synchronize()
     for n, t, want in pending:
         assert torch.equal(t.cpu().view(torch.int16), want.view(torch.int16)), (n, "back-to-back mismatch")
-    for n in (8, 64, 4096, 64 * 2048, 256 * 4096, 256 * 4096 + 8, 2 * 1024 * 1024):
+    for n in (8, 4096, 64 * 2048, 256 * 4096 + 8, 2 * 1024 * 1024):
         for rep in range(3):
             call += 1
             ins, want = expected(world, n, call)
@@ -108,7 +108,7 @@ def main():
     with torch.cuda.graph(g, capture_error_mode="thread_local"):
         for i, t in enumerate(static):
             ar.all_reduce_(t, algos[i])
-    for it in range(5):
+    for it in range(3):
         wants = []
         for k, t in enumerate(static):
             call += 1

@@ -45,6 +45,10 @@ def main():
                cachelens=eng.cachelens.cpu().tolist(),
                local_heads=[eng.model.config.n_head, eng.model.config.n_local_heads],
                ar_status=[eng.model._oneshot.status(), drf.model._oneshot.status()])
+    # bench.py's per-collective report (run by the driver's N > 1 benches): RCCL path here = gloo, xGMI kernels = IPC
+    import bench
+    coll = bench.collective_microbench(group, [("probe", 8, 512)], dev, iters=3)
+    res["collectives"] = coll
     json.dump(res, open(os.path.join(os.environ["MD_OUT"], f"rank{rank}.json"), "w"))
     dist.barrier()
     dist.destroy_process_group()

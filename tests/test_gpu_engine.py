@@ -528,6 +528,9 @@ def test_tp2_on_one_gpu(ckpt_dir, graphs=False):
     assert r0["output"] == r1["output"] and r0["num_nodes"] == r1["num_nodes"] and r0["cachelens"] == r1["cachelens"]
     assert r0["iters"] == r1["iters"] and r0["iters"] > 3
     assert r0["ar_status"] == [0, 0] and r1["ar_status"] == [0, 0]
+    probe = r0["collectives"]["probe"]
+    assert probe["xgmi_timeouts"] == 0 and all(probe[k] > 0 for k in ("rccl_allreduce", "xgmi_oneshot", "xgmi_twoshot",
+                                                                      "xgmi_fused_add_rmsnorm_auto")), probe
     # numerics of the sharded engine: teacher-forced logits (vocab shards concatenated) vs the TP=1 HIP engine
     tgt, drf = _hip("target", ckpt_dir), _hip("snapkv_draft", ckpt_dir)
     ids = gc.synthetic_batches()[0].to(DEV)
