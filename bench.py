@@ -77,6 +77,9 @@ def parse():
     ap.add_argument("--kv-dtype", default="bf16", choices=["bf16", "fp8"],
                     help="full-context KV cache storage (fp8 = OCP e4m3fn, BASELINE configs[4]; default bf16 = the "
                          "reference's)")
+    ap.add_argument("--kv-layout", default="NHD", choices=["NHD", "HND"],
+                    help="page layout of the full-context KV cache: NHD = the reference's flashinfer layout; HND keeps "
+                         "the rows of a kv head contiguous (DESIGN.md section 3.1)")
     ap.add_argument("--draft-tp", type=int, default=4, help="size of the draft sub-group (reference README: 4 of 8)")
     ap.add_argument("--pmc", dest="pmc", action="store_true", default=None,
                     help="measure roofline.traffic live: two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of the "
@@ -104,12 +107,12 @@ class AttnTimer:
         timer = self
         orig = model._attend
 
-        def timed(q_rot, cache, qo_indptr, tab, n, kv_scales=None):
+        def timed(q_rot, cache, qo_indptr, tab, n, *args, **kw):
             if not (timer.enabled and timer.cuda and n == timer.n_verify):
-                return orig(q_rot, cache, qo_indptr, tab, n, kv_scales)
+                return orig(q_rot, cache, qo_indptr, tab, n, *args, **kw)
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s.record()
-            o = orig(q_rot, cache, qo_indptr, tab, n, kv_scales)
+            o = orig(q_rot, cache, qo_indptr, tab, n, *args, **kw)
             e.record()
             timer.pairs.append((s, e))
             return o
@@ -191,6 +194,7 @@ def run(args, dev):
     # message at N=8 (14 MiB inbound per rank) -- and it has only been exercised with processes sharing one GPU.
     setup_seed(123)
 
+    kv_layout = getattr(args, "kv_layout", "NHD")
     selfspec = kind.startswith("selfspec")
     streaming = kind.endswith("stream")            # the draft-side cache: StreamingLLM ring, else SnapKV select
     t_load = time.time()
@@ -198,16 +202,17 @@ def run(args, dev):
         from magicdec_amd.Engine.StreamingLLM.backend import LMBackend as SelfSpecBackend
         engine = SelfSpecBackend(dtype=torch.bfloat16, device=dev, dec_len=G + 1)
         engine.load_model(args.checkpoints / tgt_name / "model.pth", use_tp=use_tp, rank_group=rank_group, group=group)
-        engine.setup_caches(max_batch_size=B, max_seq_length=ML, draft_budget=BUDGET, kv_dtype=args.kv_dtype)
+        engine.setup_caches(max_batch_size=B, max_seq_length=ML, draft_budget=BUDGET, kv_dtype=args.kv_dtype,
+                            kv_layout=kv_layout)
     elif selfspec:
         engine = LMBackend(dtype=torch.bfloat16, device=dev, dec_len=G + 1, draft_dec_len=1)
         engine.load_model(args.checkpoints / tgt_name / "model.pth", use_tp=use_tp, rank_group=rank_group, group=group)
         engine.setup_caches(max_batch_size=B, max_seq_length=ML, draft_budget=BUDGET, window_size=32,
-                            kv_dtype=args.kv_dtype)
+                            kv_dtype=args.kv_dtype, kv_layout=kv_layout)
     else:
         engine = LMBackend(dtype=torch.bfloat16, device=dev, dec_len=G + 1)
         engine.load_model(args.checkpoints / tgt_name / "model.pth", use_tp=use_tp, rank_group=rank_group, group=group)
-        engine.setup_caches(max_batch_size=B, max_seq_length=ML, kv_dtype=args.kv_dtype)
+        engine.setup_caches(max_batch_size=B, max_seq_length=ML, kv_dtype=args.kv_dtype, kv_layout=kv_layout)
     draft = None
     if in_draft and not selfspec:
         draft_tp = len(draft_ranks) > 1 or getattr(args, "force_tp", False)
@@ -400,7 +405,8 @@ def run(args, dev):
     traffic, traffic_source = None, None
     want_pmc = args.pmc if getattr(args, "pmc", None) is not None else args.workload.startswith("cfg")
     if want_pmc and on_gpu and rank == 0:
-        traffic, traffic_source = measure_traffic(B, S + 40 + G + 1, KH_loc, H_loc, D, G + 1, args.kv_dtype == "fp8")
+        traffic, traffic_source = measure_traffic(B, S + 40 + G + 1, KH_loc, H_loc, D, G + 1, args.kv_dtype == "fp8",
+                                                  kv_layout == "HND")
     ar_timeouts = None
     if use_tp:
         ars = [m._oneshot for m in ([engine.model] + ([draft.model] if draft is not None else []))
@@ -410,7 +416,8 @@ def run(args, dev):
         "metric": "decode tokens/s/node + speedup vs autoregressive, Llama-3.1-8B B=64 prefix=16K",
         "value": round(value, 2), "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(dt_replay / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong",
-        "vs_baseline": None, "dtype": "bf16", "kv_cache_dtype": args.kv_dtype, "data": "synthetic",
+        "vs_baseline": None, "dtype": "bf16", "kv_cache_dtype": args.kv_dtype, "kv_cache_layout": kv_layout,
+        "data": "synthetic",
         "config": {"workload": (f"{args.workload}: {tgt_name} self-speculation TP{len(rank_group)}, "
                                 f"{'StreamingLLM' if streaming else 'SnapKV'} draft cache "
                                 f"budget {BUDGET} gamma {G}, B={B} prefix={S} max_len={ML}") if selfspec else
@@ -438,7 +445,7 @@ def run(args, dev):
                                     "tokens_per_iter_per_seq": round(tok_meas / meas_steps / B, 3),
                                     "ms_per_step": round(dt_meas / meas_steps * 1e3, 4)},
         "prefill_s": round(t_pf, 2), "load_s": round(t_load, 2),
-        "roofline": {"kernel": f"paged_attn_kernel<{D},{1 if (G + 1) * (H_loc // KH_loc) <= 16 else 2},false,"
+        "roofline": {"kernel": f"paged_attn_kernel<{D},{1 if (G + 1) * (H_loc // KH_loc) <= 16 else 2},"
                                f"{'true' if args.kv_dtype == 'fp8' else 'false'}> (verify attention, md_paged_attn)",
                      "bound": "hbm",
                      "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -511,7 +518,7 @@ def collective_microbench(group, shapes, dev, iters=30):
     return out
 
 
-def measure_traffic(B, L_kv, KH, H, D, n, fp8):
+def measure_traffic(B, L_kv, KH, H, D, n, fp8, hnd=False):
     """roofline.traffic measured in THIS invocation: two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE -- they do not
     fit one pass on gfx950; --kernel-trace only, no other trace domain) over tools/attn_bench.py, which launches
     md_paged_attn at exactly this run's per-layer shard shape on > 256 MiB of KV per launch (Infinity-Cache cold).
@@ -531,7 +538,7 @@ def measure_traffic(B, L_kv, KH, H, D, n, fp8):
         cmd = ["timeout", "150", "rocprofv3", "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d,
                "-o", "pmc", "--", sys.executable, os.path.join(ROOT, "tools", "attn_bench.py"), "--iters", "4",
                "--B", str(B), "--S", str(L_kv), "--KH", str(KH), "--H", str(H), "--D", str(D), "--n", str(n),
-               "--fp8", "1" if fp8 else "0"]
+               "--fp8", "1" if fp8 else "0", "--hnd", "1" if hnd else "0"]
         env = {k: v for k, v in os.environ.items()
                if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
         env["TMPDIR"] = "/tmp"

@@ -48,6 +48,15 @@ typedef void* md_stream_t; /* hipStream_t */
  * (row "next" 8f-2 of SURVEY.md, BASELINE configs[4]); accuracy is gated in tests/test_gpu_fp8.py. */
 #define MD_KV_BF16 0
 #define MD_KV_FP8_E4M3 1
+/* Page layout flag, OR-ed into the kv_dtype argument of md_append_paged_kv / md_rope_append (first cache) /
+ * md_paged_attn / md_snapkv_select (source cache).  Default (flag absent) is the reference's NHD page
+ * cache[page][2][page_size][KH][D]; MD_KV_LAYOUT_HND selects cache[page][2][KH][page_size][D] (flashinfer's other
+ * layout): the rows of one kv head are contiguous, so a (request, kv head) stream is read in 128-row runs instead of
+ * D*sizeof-byte pieces at a KH*D*sizeof stride -- at KH = 8 that is 128-byte pieces for an fp8 cache, whose loads-only
+ * ceiling is 72.6 % of the HBM peak.  A second cache (md_rope_append), the SnapKV draft cache
+ * and the StreamingLLM ring are always NHD.  Results are bit-identical between the layouts. */
+#define MD_KV_LAYOUT_HND 0x100
+#define MD_KV_DTYPE_MASK 0xff
 
 /* ABI version (bumped on any signature change). */
 int md_abi_version(void);

@@ -126,9 +126,12 @@ class SnapKVTargetBackend(_BackendBase):
 
     @torch.no_grad()
     def setup_caches(self, max_batch_size: int = 1, max_seq_length: int = 2048, draft_budget=0, window_size=32,
-                     kv_dtype="bf16"):
+                     kv_dtype="bf16", kv_layout="NHD"):
         """kv_dtype="fp8": the full-context cache is OCP e4m3fn with static per-head scales calibrated on the
-        first prefill chunk (not in the reference; BASELINE.json configs[4]).  The compressed draft cache stays bf16."""
+        first prefill chunk (not in the reference; BASELINE.json configs[4]).  The compressed draft cache stays bf16.
+        kv_layout="HND": the full-context cache keeps the rows of one kv head contiguous inside a page (the
+        reference's flashinfer wrappers are planned "NHD": Engine/SnapKV/backend.py:30); same results, longer
+        contiguous runs for the verify step's stream (matters for fp8 rows of 128 bytes)."""
         self.max_length, self.batch_size = max_seq_length, max_batch_size
         dev = self.device
         self.page_size = PAGE_SIZE
@@ -146,10 +149,11 @@ class SnapKVTargetBackend(_BackendBase):
             self._d.reset(last_page_len_init=1, full_table=True)
             self.model.setup_caches(num_pages=self.max_num_pages, page_size=PAGE_SIZE, spec=True,
                                     draft_num_pages=self.draft_num_pages, draft_budget=draft_budget,
-                                    window_size=window_size, max_positions=max_seq_length + 256, kv_dtype=kv_dtype)
+                                    window_size=window_size, max_positions=max_seq_length + 256, kv_dtype=kv_dtype,
+                                    kv_layout=kv_layout)
         else:
             self.model.setup_caches(num_pages=self.max_num_pages, page_size=PAGE_SIZE,
-                                    max_positions=max_seq_length + 256, kv_dtype=kv_dtype)
+                                    max_positions=max_seq_length + 256, kv_dtype=kv_dtype, kv_layout=kv_layout)
 
     @torch.no_grad()
     def clear_kv(self):
@@ -432,7 +436,8 @@ class StreamingSelfSpecBackend(_BackendBase, _StreamingMixin):
         self.draft_cachelens = None
 
     @torch.no_grad()
-    def setup_caches(self, max_batch_size: int = 1, max_seq_length: int = 2048, draft_budget=0, kv_dtype="bf16"):
+    def setup_caches(self, max_batch_size: int = 1, max_seq_length: int = 2048, draft_budget=0, kv_dtype="bf16",
+                     kv_layout="NHD"):
         self.draft_budget, self.batch_size = draft_budget, max_batch_size
         dev = self.device
         self.page_size = PAGE_SIZE
@@ -448,7 +453,7 @@ class StreamingSelfSpecBackend(_BackendBase, _StreamingMixin):
         self._d.reset(indptr_stride=self.draft_max_num_pages_per_request)
         self.model.setup_caches(num_pages=self.max_num_pages, page_size=PAGE_SIZE, spec=True,
                                 draft_num_pages=self.draft_max_num_pages, draft_budget=draft_budget, streaming=True,
-                                max_positions=max_seq_length + 256, kv_dtype=kv_dtype)
+                                max_positions=max_seq_length + 256, kv_dtype=kv_dtype, kv_layout=kv_layout)
 
     @torch.no_grad()
     def clear_kv(self):

@@ -142,14 +142,19 @@ class KVCache(nn.Module):
     """Paged caches of one layer: `kv_cache` [pages, 2, 128, KH, D] and, for speculation, `draft_cache`."""
 
     def __init__(self, max_num_pages, page_size, n_heads, head_dim, dtype=torch.bfloat16, draft_max_num_pages=0,
-                 kv_len=0, kv_dtype=torch.bfloat16):
+                 kv_len=0, kv_dtype=torch.bfloat16, kv_layout="NHD"):
         """kv_dtype=float8_e4m3fn stores `kv_cache` as OCP e4m3fn bytes with static per-kv-head scales
-        (`k_scale`, `v_scale`, float32 [KH]; x ~ byte * scale); `draft_cache` is always bf16."""
+        (`k_scale`, `v_scale`, float32 [KH]; x ~ byte * scale); `draft_cache` is always bf16.
+        kv_layout="HND" stores `kv_cache` as [pages, 2, KH, 128, D] (rows of a kv head contiguous: the streaming
+        reads of the verify step become 128-row runs); `draft_cache` is always NHD."""
         super().__init__()
+        if kv_layout not in ops.KV_LAYOUTS:
+            raise ValueError(f"kv_layout must be one of {ops.KV_LAYOUTS}")
+        self.layout = kv_layout
         if max_num_pages > 0:
-            self.register_buffer("kv_cache",
-                                 torch.zeros((max_num_pages, 2, page_size, n_heads, head_dim), dtype=kv_dtype),
-                                 persistent=False)
+            shape = ((max_num_pages, 2, n_heads, page_size, head_dim) if kv_layout == "HND"
+                     else (max_num_pages, 2, page_size, n_heads, head_dim))
+            self.register_buffer("kv_cache", torch.zeros(shape, dtype=kv_dtype), persistent=False)
         self.fp8 = kv_dtype == ops.FP8_DTYPE
         if self.fp8:
             self.register_buffer("k_scale", torch.ones(n_heads, dtype=torch.float32), persistent=False)
@@ -164,6 +169,9 @@ class KVCache(nn.Module):
 
     def scales(self, which="kv_cache"):
         return (self.k_scale, self.v_scale) if (self.fp8 and which == "kv_cache") else None
+
+    def layout_of(self, which="kv_cache"):
+        return self.layout if which == "kv_cache" else "NHD"
 
     def calibrate(self, k, v, margin=FP8_MARGIN):
         """Static scales from the first prefill chunk: K's bound is the largest rotary-pair norm (what any
@@ -252,7 +260,7 @@ class Transformer(nn.Module):
 
     # ------------------------------------------------------------------ setup
     def setup_caches(self, num_pages, page_size=128, spec=False, draft_num_pages=0, draft_budget=0, window_size=32,
-                     max_positions=None, streaming=False, kv_dtype="bf16"):
+                     max_positions=None, streaming=False, kv_dtype="bf16", kv_layout="NHD"):
         """Allocates the per-layer KV slabs and the device-side constants of the step
         (Engine/SnapKV/model.py:127-169 / StreamingLLM/model_draft.py:157-189 without the op registration)."""
         c = self.config
@@ -262,8 +270,8 @@ class Transformer(nn.Module):
             raise NotImplementedError("the gfx950 kernels are bf16")
         if kv_dtype not in KV_DTYPES:
             raise ValueError(f"kv_dtype must be one of {sorted(KV_DTYPES)}")
-        if kv_dtype == "fp8" and streaming and not spec:
-            raise NotImplementedError("the StreamingLLM ring cache is bf16 only (in-place shift + re-rotation)")
+        if (kv_dtype == "fp8" or kv_layout != "NHD") and streaming and not spec:
+            raise NotImplementedError("the StreamingLLM ring cache is bf16 NHD only (in-place shift + re-rotation)")
         head_dim = c.dim // c.n_head
         self.page_size = page_size
         self.spec, self.streaming = spec, streaming
@@ -271,7 +279,7 @@ class Transformer(nn.Module):
         for b in self.layers:
             b.attention.kv_cache = KVCache(num_pages, page_size, c.n_local_heads, head_dim, dtype,
                                            draft_num_pages if spec else 0, kv_len=draft_budget,
-                                           kv_dtype=KV_DTYPES[kv_dtype]).to(dev)
+                                           kv_dtype=KV_DTYPES[kv_dtype], kv_layout=kv_layout).to(dev)
         if max_positions is None:
             max_positions = max(num_pages, draft_num_pages, 1) * page_size + 256
         llama31 = c.high_freq_factor is not None and c.low_freq_factor is not None
@@ -423,9 +431,10 @@ class Transformer(nn.Module):
         dist.all_reduce(all_i, group=self.process_group)
         return ops.tp_argmax_merge(all_v, all_i)
 
-    def _attend(self, q_rot, cache, qo_indptr, tab: PageTable, n, kv_scales=None):
+    def _attend(self, q_rot, cache, qo_indptr, tab: PageTable, n, kv_scales=None, kv_layout="NHD"):
         return ops.paged_attention(q_rot, cache, qo_indptr, tab.indices, tab.indptr, tab.last_page_len, n,
-                                   tab.max_pages, self.workspace, causal=True, kv_scales=kv_scales)
+                                   tab.max_pages, self.workspace, causal=True, kv_scales=kv_scales,
+                                   kv_layout=kv_layout)
 
     # ------------------------------------------------------------------ step variants
     def _std_step(self, idx, offsets, qo_indptr, tab: PageTable, which="kv_cache", tab2: PageTable = None,
@@ -439,6 +448,7 @@ class Transformer(nn.Module):
             cache = getattr(kvc, which)
             cache2 = kvc.draft_cache if tab2 is not None else None
             scales = kvc.scales(which)
+            layout = kvc.layout_of(which)
             if scales is not None and calibrate and not kvc.calibrated:
                 if self.kv_scale_override is not None:
                     kvc.k_scale.copy_(self.kv_scale_override[i][0])
@@ -449,12 +459,12 @@ class Transformer(nn.Module):
             q_rot = ops.rope_append(q, k, v, qo_indptr, offsets, self.rope_table, cache, tab.indices, tab.indptr,
                                     tab.last_page_len, cache2, tab2.indices if tab2 else None,
                                     tab2.indptr if tab2 else None, tab2.last_page_len if tab2 else None, n_max=n,
-                                    kv_scales=scales)
-            o = self._attend(q_rot, cache, qo_indptr, tab, n, scales)
+                                    kv_scales=scales, kv_layout=layout)
+            o = self._attend(q_rot, cache, qo_indptr, tab, n, scales, layout)
             if snap_tab is not None:
                 ops.snapkv_select(q_rot, cache, tab.indices, tab.indptr, self._snap_ctx_len, self.window_size,
                                   self.draft_budget, POOL_KERNEL, kvc.draft_cache, snap_tab.indices, snap_tab.indptr,
-                                  snap_tab.last_page_len, self.workspace, kv_scales=scales)
+                                  snap_tab.last_page_len, self.workspace, kv_scales=scales, kv_layout=layout)
             return o
         return self._run(idx, fn)
 

@@ -31,6 +31,9 @@ def _common(parser, spec=True):
     parser.add_argument('--benchmark', action='store_true', help='Per-phase timing (adds synchronisations).')
     parser.add_argument('--kv_dtype', type=str, default="bf16", choices=["bf16", "fp8"],
                         help='Storage of the full-context KV cache (fp8 = OCP e4m3fn; not in the reference).')
+    parser.add_argument('--kv_layout', type=str, default="NHD", choices=["NHD", "HND"],
+                        help='Page layout of the full-context KV cache (the reference plans flashinfer "NHD"; '
+                             'HND keeps the rows of one kv head contiguous).')
     if spec:
         parser.add_argument('--draft_budget', type=int, default=-1, help='Draft KV budget.')
         parser.add_argument('--gamma', type=int, default=5, help='speculation length')
@@ -96,7 +99,8 @@ def longspec_main(kind: str, argv=None):
     engine.load_model(args.target, use_tp=use_tp, rank_group=args.rank_group, group=global_group)
     if args.compile:
         engine.compile()
-    engine.setup_caches(max_batch_size=BATCH_SIZE, max_seq_length=MAX_LEN_TARGET, kv_dtype=args.kv_dtype)
+    engine.setup_caches(max_batch_size=BATCH_SIZE, max_seq_length=MAX_LEN_TARGET, kv_dtype=args.kv_dtype,
+                        kv_layout=args.kv_layout)
 
     draft = None
     if (not use_tp) or rank in args.draft_rank_group:
@@ -190,10 +194,10 @@ def selfspec_main(kind: str, argv=None):
         engine.compile()
     if streaming:
         engine.setup_caches(max_batch_size=BATCH_SIZE, max_seq_length=MAX_LEN_TARGET, draft_budget=args.draft_budget,
-                            kv_dtype=args.kv_dtype)
+                            kv_dtype=args.kv_dtype, kv_layout=args.kv_layout)
     else:
         engine.setup_caches(max_batch_size=BATCH_SIZE, max_seq_length=MAX_LEN_TARGET, draft_budget=args.draft_budget,
-                            window_size=args.window_size, kv_dtype=args.kv_dtype)
+                            window_size=args.window_size, kv_dtype=args.kv_dtype, kv_layout=args.kv_layout)
     tokenizer = load_tokenizer(args.model_name)
     eot_1, eot_2 = _eot(tokenizer)
     print_(f"eot_1: {eot_1}, eot_2: {eot_2}")
@@ -256,7 +260,8 @@ def baseline_main(argv=None):
     engine.load_model(args.model, use_tp=use_tp, rank_group=args.rank_group, group=global_group)
     if args.compile:
         engine.compile()
-    engine.setup_caches(max_batch_size=args.B, max_seq_length=args.max_len, kv_dtype=args.kv_dtype)
+    engine.setup_caches(max_batch_size=args.B, max_seq_length=args.max_len, kv_dtype=args.kv_dtype,
+                        kv_layout=args.kv_layout)
     tokenizer = load_tokenizer(args.model_name)
     eot_1, eot_2 = _eot(tokenizer)
     print_(f"eot_1: {eot_1}, eot_2: {eot_2}")

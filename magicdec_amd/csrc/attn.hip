@@ -49,7 +49,8 @@ struct AttnParams {
     int64_t q_row_stride;  // elements
     int64_t page_stride;   // elements: 2*page_size*KH*D
     int64_t kv_half;       // elements: page_size*KH*D
-    int slot_stride;       // elements: KH*D
+    int slot_stride;       // elements between consecutive rows of a page: KH*D (NHD pages), D (HND pages)
+    int head_stride;       // elements between kv heads inside a page half: D (NHD), page_size*D (HND)
     int B, H, KH, g, page_size, causal, nsplit, n_qgroups;
     float scale_log2;
     const float* k_scale;  // fp8 KV: per-kv-head dequant scales (K folded into the softmax scale, V into 1/l)
@@ -256,7 +257,7 @@ __global__ __launch_bounds__(256, 2) void paged_attn_kernel(const AttnParams p) 
             kra[kb][s] = row * KROW + (ch << 4);
         }
     const int vra = (lc * 4 + (lq >> 2)) * 32 + (lq & 3) * 8;  // + nb*kVSub + kb*512
-    const unsigned goff = (unsigned)((wrow * p.slot_stride + kvh * D) * EB + wch * 16);  // bytes, per lane
+    const unsigned goff = (unsigned)((wrow * p.slot_stride + kvh * p.head_stride) * EB + wch * 16);  // bytes, per lane
 
     // two tiles in flight per wavefront: register sets A and B alternate (2 x 16 KiB of loads outstanding while a
     // tile is computed -- the loop is latency x bandwidth bound, not compute bound)
@@ -682,7 +683,7 @@ __global__ __launch_bounds__(64 * NW, 2) void prefill_attn_kernel(const AttnPara
 #pragma unroll
         for (int s = 0; s < KS; ++s) kra[kb][s] = (kb * 16 + lq) * KROW + ((s * 4 + lc) << 4);
     const int vra = K_BYTES + (lc * 4 + (lq >> 2)) * 32 + (lq & 3) * 8;
-    const unsigned goff = (unsigned)((wrow * p.slot_stride + kvh * D) * EB + wch * 16);
+    const unsigned goff = (unsigned)((wrow * p.slot_stride + kvh * p.head_stride) * EB + wch * 16);
 
     u32x4 kreg[NLW], vreg[NLW];
     auto issue = [&](int tt) {
@@ -935,6 +936,9 @@ extern "C" int md_paged_attn(const void* q, int64_t q_row_stride, const void* ca
                      ((uintptr_t)out & 7) == 0,
                  "md_paged_attn: q/cache must be 16-byte aligned with a row stride multiple of 8");
     MD_CHECK_ARG(max_pages_per_req > 0, "md_paged_attn: max_pages_per_req must be > 0");
+    MD_CHECK_ARG((kv_dtype & ~(MD_KV_DTYPE_MASK | MD_KV_LAYOUT_HND)) == 0, "md_paged_attn: unknown kv_dtype flags");
+    const bool hnd = (kv_dtype & MD_KV_LAYOUT_HND) != 0;
+    kv_dtype &= MD_KV_DTYPE_MASK;
     MD_CHECK_ARG(kv_dtype == MD_KV_BF16 || (kv_dtype == MD_KV_FP8_E4M3 && k_scale && v_scale),
                  "md_paged_attn: kv_dtype must be MD_KV_BF16 or MD_KV_FP8_E4M3 (with per-head scales)");
     const bool fp8 = kv_dtype == MD_KV_FP8_E4M3;
@@ -951,7 +955,8 @@ extern "C" int md_paged_attn(const void* q, int64_t q_row_stride, const void* ca
     p.page_indptr = page_indptr;
     p.last_page_len = last_page_len;
     p.q_row_stride = q_row_stride;
-    p.slot_stride = KH * D;
+    p.slot_stride = hnd ? D : KH * D;
+    p.head_stride = hnd ? page_size * D : D;
     p.kv_half = (int64_t)page_size * KH * D;
     p.page_stride = 2 * p.kv_half;
     p.B = B;

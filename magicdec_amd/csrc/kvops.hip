@@ -46,6 +46,15 @@ __device__ __forceinline__ int64_t page_row_offset(const int32_t* indices, int p
     return (pid * 2 * page_size + slot) * (int64_t)(KH * D);
 }
 
+// element offset of 8-element chunk c of kv head h of row `pos` of a request (K half; V half = + page_size*KH*D)
+__device__ __forceinline__ int64_t kv_chunk_offset(const int32_t* indices, int pg0, int pos, int page_size, int KH,
+                                                   int D, int h, int c, bool hnd) {
+    const int page = pos / page_size;
+    const int slot = pos - page * page_size;
+    const int64_t base = (int64_t)indices[pg0 + page] * 2 * page_size * KH * D;
+    return hnd ? base + ((int64_t)h * page_size + slot) * D + c * 8 : base + ((int64_t)slot * KH + h) * D + c * 8;
+}
+
 // 8 bf16 -> 8 OCP e4m3fn bytes: q = rne_e4m3(clamp(x * inv_scale, +-448))   (oracle: flashinfer_ref.quantize_fp8)
 __device__ __forceinline__ u32x2 quant8_fp8(const u32x4 x, float inv_scale) {
     float f[8];
@@ -78,7 +87,8 @@ __global__ __launch_bounds__(256) void append_kernel(const bf16_t* __restrict__ 
                                                      int64_t ks, int64_t vs, const int32_t* append_indptr,
                                                      void* cache, const int32_t* indices,
                                                      const int32_t* indptr, const int32_t* last, int KH, int D,
-                                                     int page_size, const float* k_scale, const float* v_scale) {
+                                                     int page_size, const float* k_scale, const float* v_scale,
+                                                     int hnd) {
     const int b = blockIdx.y, j = blockIdx.x;
     const int a0 = append_indptr[b];
     const int n_b = append_indptr[b + 1] - a0;
@@ -91,7 +101,6 @@ __global__ __launch_bounds__(256) void append_kernel(const bf16_t* __restrict__ 
         note_overflow();
         return;
     }
-    const int64_t dst = page_row_offset(indices, pg0, pos, page_size, KH, D);
     const int64_t half = (int64_t)page_size * KH * D;
     const int nvec = KH * D / 8;
     const u32x4* ksrc = reinterpret_cast<const u32x4*>(k + (int64_t)(a0 + j) * ks);
@@ -99,8 +108,9 @@ __global__ __launch_bounds__(256) void append_kernel(const bf16_t* __restrict__ 
     const int cpr = D / 8;
     for (int i = threadIdx.x; i < nvec; i += blockDim.x) {
         const int h = i / cpr;
-        store8<FP8>(cache, dst + i * 8, ksrc[i], FP8 ? 1.0f / k_scale[h] : 1.f);
-        store8<FP8>(cache, dst + half + i * 8, vsrc[i], FP8 ? 1.0f / v_scale[h] : 1.f);
+        const int64_t dst = kv_chunk_offset(indices, pg0, pos, page_size, KH, D, h, i - h * cpr, hnd != 0);
+        store8<FP8>(cache, dst, ksrc[i], FP8 ? 1.0f / k_scale[h] : 1.f);
+        store8<FP8>(cache, dst + half, vsrc[i], FP8 ? 1.0f / v_scale[h] : 1.f);
     }
 }
 
@@ -167,7 +177,7 @@ __global__ __launch_bounds__(256) void rope_append_kernel(const bf16_t* __restri
                                                           const int32_t* offsets, int H, int KH, int D,
                                                           const float* __restrict__ cos_sin, int max_pos,
                                                           PageTable t1, PageTable t2, int page_size,
-                                                          const float* k_scale, const float* v_scale) {
+                                                          const float* k_scale, const float* v_scale, int hnd) {
     const int b = blockIdx.y, j = blockIdx.x;
     const int a0 = indptr[b];
     const int n_b = indptr[b + 1] - a0;
@@ -184,7 +194,8 @@ __global__ __launch_bounds__(256) void rope_append_kernel(const bf16_t* __restri
     const int len1 = req_len(t1.indptr, t1.last, b, page_size, &pg0);
     const int p1 = len1 - n_b + j;
     const bool over1 = p1 >= req_capacity(t1.indptr, b, page_size);
-    const int64_t d1 = (p1 >= 0 && !over1) ? page_row_offset(t1.indices, pg0, p1, page_size, KH, D) : -1;
+    const bool ok1 = p1 >= 0 && !over1;
+    const int pg1 = pg0;
     if (over1) note_overflow();
     int64_t d2 = -1;
     if (t2.cache) {
@@ -205,12 +216,19 @@ __global__ __launch_bounds__(256) void rope_append_kernel(const bf16_t* __restri
             const u32x4 x = *reinterpret_cast<const u32x4*>(k + (int64_t)row * ks + ii * 8);
             const u32x4 y = rope8(x, cs + c * 8);
             // the first cache may be fp8 (target); a second cache (self-spec draft cache) is always bf16
-            if (d1 >= 0) store8<FP8>(t1.cache, d1 + ii * 8, y, FP8 ? 1.0f / k_scale[ii / cpr] : 1.f);
+            const int h = ii / cpr;
+            if (ok1)
+                store8<FP8>(t1.cache, kv_chunk_offset(t1.indices, pg1, p1, page_size, KH, D, h, c, hnd != 0), y,
+                            FP8 ? 1.0f / k_scale[h] : 1.f);
             if (d2 >= 0) store8<false>(t2.cache, d2 + ii * 8, y, 1.f);
         } else {
             const int ii = i - nq - nk;
             const u32x4 x = *reinterpret_cast<const u32x4*>(v + (int64_t)row * vs + ii * 8);
-            if (d1 >= 0) store8<FP8>(t1.cache, d1 + half + ii * 8, x, FP8 ? 1.0f / v_scale[ii / cpr] : 1.f);
+            const int h = ii / cpr;
+            if (ok1)
+                store8<FP8>(t1.cache,
+                            kv_chunk_offset(t1.indices, pg1, p1, page_size, KH, D, h, ii - h * cpr, hnd != 0) + half,
+                            x, FP8 ? 1.0f / v_scale[h] : 1.f);
             if (d2 >= 0) store8<false>(t2.cache, d2 + half + ii * 8, x, 1.f);
         }
     }
@@ -245,16 +263,19 @@ extern "C" int md_append_paged_kv(const void* k, const void* v, int64_t k_row_st
                  "md_append_paged_kv: bad shape B=%d n_max=%d KH=%d D=%d", B, n_max, KH, D);
     MD_CHECK_ARG(aligned16(k) && aligned16(v) && aligned16(cache) && k_row_stride % 8 == 0 && v_row_stride % 8 == 0,
                  "md_append_paged_kv: k/v/cache must be 16-byte aligned, row strides multiples of 8");
+    const int hnd = (kv_dtype & MD_KV_LAYOUT_HND) ? 1 : 0;
+    MD_CHECK_ARG((kv_dtype & ~(MD_KV_DTYPE_MASK | MD_KV_LAYOUT_HND)) == 0, "md_append_paged_kv: unknown kv_dtype flags");
+    kv_dtype &= MD_KV_DTYPE_MASK;
     MD_CHECK_ARG(kv_dtype == MD_KV_BF16 || (kv_dtype == MD_KV_FP8_E4M3 && k_scale && v_scale),
                  "md_append_paged_kv: kv_dtype must be MD_KV_BF16 or MD_KV_FP8_E4M3 (with per-head scales)");
     if (kv_dtype == MD_KV_FP8_E4M3)
         hipLaunchKernelGGL((append_kernel<true>), dim3(n_max, B), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)k,
                            (const bf16_t*)v, k_row_stride, v_row_stride, append_indptr, cache, page_indices,
-                           page_indptr, last_page_len, KH, D, page_size, k_scale, v_scale);
+                           page_indptr, last_page_len, KH, D, page_size, k_scale, v_scale, hnd);
     else
         hipLaunchKernelGGL((append_kernel<false>), dim3(n_max, B), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)k,
                            (const bf16_t*)v, k_row_stride, v_row_stride, append_indptr, cache, page_indices,
-                           page_indptr, last_page_len, KH, D, page_size, k_scale, v_scale);
+                           page_indptr, last_page_len, KH, D, page_size, k_scale, v_scale, hnd);
     MD_CHECK_LAUNCH("md_append_paged_kv");
     return MD_OK;
 }
@@ -318,6 +339,9 @@ extern "C" int md_rope_append(const void* q, const void* k, const void* v, int64
                      aligned16(cos_sin) && (!cache2 || aligned16(cache2)) && q_row_stride % 8 == 0 &&
                      k_row_stride % 8 == 0 && v_row_stride % 8 == 0,
                  "md_rope_append: tensors must be 16-byte aligned, row strides multiples of 8");
+    const int hnd = (kv_dtype & MD_KV_LAYOUT_HND) ? 1 : 0;
+    MD_CHECK_ARG((kv_dtype & ~(MD_KV_DTYPE_MASK | MD_KV_LAYOUT_HND)) == 0, "md_rope_append: unknown kv_dtype flags");
+    kv_dtype &= MD_KV_DTYPE_MASK;
     MD_CHECK_ARG(kv_dtype == MD_KV_BF16 || (kv_dtype == MD_KV_FP8_E4M3 && k_scale && v_scale),
                  "md_rope_append: kv_dtype must be MD_KV_BF16 or MD_KV_FP8_E4M3 (with per-head scales)");
     PageTable t1{cache, page_indices, page_indptr, last_page_len};
@@ -325,11 +349,11 @@ extern "C" int md_rope_append(const void* q, const void* k, const void* v, int64
     if (kv_dtype == MD_KV_FP8_E4M3)
         hipLaunchKernelGGL((rope_append_kernel<true>), dim3(n_max, B), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)q,
                            (const bf16_t*)k, (const bf16_t*)v, q_row_stride, k_row_stride, v_row_stride, (bf16_t*)q_out,
-                           indptr, offsets, H, KH, D, cos_sin, max_pos, t1, t2, page_size, k_scale, v_scale);
+                           indptr, offsets, H, KH, D, cos_sin, max_pos, t1, t2, page_size, k_scale, v_scale, hnd);
     else
         hipLaunchKernelGGL((rope_append_kernel<false>), dim3(n_max, B), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)q,
                            (const bf16_t*)k, (const bf16_t*)v, q_row_stride, k_row_stride, v_row_stride, (bf16_t*)q_out,
-                           indptr, offsets, H, KH, D, cos_sin, max_pos, t1, t2, page_size, k_scale, v_scale);
+                           indptr, offsets, H, KH, D, cos_sin, max_pos, t1, t2, page_size, k_scale, v_scale, hnd);
     MD_CHECK_LAUNCH("md_rope_append");
     return MD_OK;
 }

@@ -33,7 +33,8 @@ struct SnapParams {
     unsigned short* aws;    // [B][H][S-W] bf16 bits
     int B, H, KH, g, W, S, L, nch, page_size;
     int64_t page_stride;
-    int slot_stride;
+    int slot_stride;      // elements between rows of a page: KH*D (NHD) or D (HND)
+    int head_stride;      // elements between kv heads: D (NHD) or page_size*D (HND)
 };
 
 // K fragment (A operand) of 16 consecutive columns (kv positions) col0..col0+15 for head kvh:
@@ -46,7 +47,7 @@ __device__ __forceinline__ void load_kfrag(const SnapParams& p, int b, int kvh, 
     if (col < p.S) {
         const int page = col / p.page_size, slot = col - page * p.page_size;
         const int64_t pid = p.page_indices[p.page_indptr[b] + page];
-        const int64_t off = pid * p.page_stride + (int64_t)slot * p.slot_stride + kvh * D + lc * 8;   // elements
+        const int64_t off = pid * p.page_stride + (int64_t)slot * p.slot_stride + (int64_t)kvh * p.head_stride + lc * 8;   // elements
         if constexpr (FP8) {
             const unsigned char* kp = reinterpret_cast<const unsigned char*>(p.cache) + off;
 #pragma unroll
@@ -366,6 +367,7 @@ struct GatherParams {
     const int32_t* dlast;
     const int32_t* idx;  // [B][KH][topk]
     int KH, D, page_size, S, W, budget, topk;
+    int src_hnd;         // source pages are [2][KH][page_size][D] instead of [2][page_size][KH][D]
 };
 
 template <bool FP8>
@@ -375,7 +377,8 @@ __global__ __launch_bounds__(64) void snapkv_gather_kernel(const GatherParams p)
     const int row_elems = p.KH * p.D;
     const int sp = src / p.page_size, ss = src - sp * p.page_size;
     const int64_t spid = p.page_indices[p.page_indptr[b] + sp];
-    const int64_t soff = (spid * 2 * p.page_size + ss) * row_elems + kvh * p.D;
+    const int64_t soff = p.src_hnd ? spid * 2 * p.page_size * row_elems + ((int64_t)kvh * p.page_size + ss) * p.D
+                                   : (spid * 2 * p.page_size + ss) * row_elems + kvh * p.D;
     const int dp0 = p.dindptr[b];
     const int dnp = p.dindptr[b + 1] - dp0;
     const int dlen = dnp > 0 ? (dnp - 1) * p.page_size + p.dlast[b] : 0;
@@ -461,6 +464,9 @@ extern "C" int md_snapkv_select(const void* q_win, const void* cache, const int3
     MD_CHECK_ARG(workspace_bytes >= md_snapkv_workspace_bytes(B, H, KH, ctx_len, window) &&
                      (((uintptr_t)workspace) & 255) == 0,
                  "md_snapkv_select: workspace too small or not 256-byte aligned");
+    MD_CHECK_ARG((kv_dtype & ~(MD_KV_DTYPE_MASK | MD_KV_LAYOUT_HND)) == 0, "md_snapkv_select: unknown kv_dtype flags");
+    const bool hnd = (kv_dtype & MD_KV_LAYOUT_HND) != 0;
+    kv_dtype &= MD_KV_DTYPE_MASK;
     MD_CHECK_ARG(kv_dtype == MD_KV_BF16 || (kv_dtype == MD_KV_FP8_E4M3 && k_scale && v_scale),
                  "md_snapkv_select: kv_dtype must be MD_KV_BF16 or MD_KV_FP8_E4M3 (with per-head scales)");
     const bool fp8 = kv_dtype == MD_KV_FP8_E4M3;
@@ -481,7 +487,8 @@ extern "C" int md_snapkv_select(const void* q_win, const void* cache, const int3
     p.L = L;
     p.nch = (ctx_len + kChunkCols - 1) / kChunkCols;
     p.page_size = page_size;
-    p.slot_stride = KH * D;
+    p.slot_stride = hnd ? D : KH * D;
+    p.head_stride = hnd ? page_size * D : D;
     p.page_stride = 2 * (int64_t)page_size * KH * D;
     unsigned char* ws = (unsigned char*)workspace;
     p.partials = (double*)ws;
@@ -537,6 +544,7 @@ extern "C" int md_snapkv_select(const void* q_win, const void* cache, const int3
     gp.W = window;
     gp.budget = budget;
     gp.topk = topk;
+    gp.src_hnd = hnd ? 1 : 0;
     if (fp8)
         hipLaunchKernelGGL((snapkv_gather_kernel<true>), dim3(budget, KH, B), dim3(64), 0, st, gp);
     else

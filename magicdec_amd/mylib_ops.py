@@ -47,8 +47,9 @@ class PagedAttentionPlan:
 
     def __init__(self, float_workspace_buffer=None, kv_layout="NHD", use_cuda_graph=False, qo_indptr_buf=None,
                  paged_kv_indptr_buf=None, paged_kv_indices_buf=None, paged_kv_last_page_len_buf=None):
-        if kv_layout != "NHD":
-            raise ValueError("only the NHD page layout [pages, 2, page_size, KH, D] is supported")
+        if kv_layout not in ops.KV_LAYOUTS:
+            raise ValueError(f"kv_layout must be one of {ops.KV_LAYOUTS} (flashinfer's two page layouts)")
+        self.kv_layout = kv_layout
         self._ws = None
         self._plan = None
         self.kv_scales = None      # (k_scale, v_scale) for an fp8 cache
@@ -70,13 +71,14 @@ class PagedAttentionPlan:
         p = self._plan
         if p is None:
             raise RuntimeError("PagedAttentionPlan.run before plan()")
-        if q.shape[1] != p["H"] or q.shape[2] != p["D"] or kv_cache.shape[3] != p["KH"] or kv_cache.shape[2] != p["page_size"]:
+        page_size, KH, _ = ops._kv_geom(kv_cache, self.kv_layout)
+        if q.shape[1] != p["H"] or q.shape[2] != p["D"] or KH != p["KH"] or page_size != p["page_size"]:
             raise ValueError("q / kv_cache do not match the planned head geometry")
         if self._ws is None:
             self._ws = ops.AttnWorkspace(q.device)
         return ops.paged_attention(q, kv_cache, p["qo"], p["indices"], p["indptr"], p["last"], p["n_max"],
                                    p["max_pages"], self._ws, causal=p["causal"], sm_scale=p["sm_scale"],
-                                   kv_scales=self.kv_scales)
+                                   kv_scales=self.kv_scales, kv_layout=self.kv_layout)
 
 
 class _Registry:

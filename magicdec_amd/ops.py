@@ -22,24 +22,39 @@ from ._lib import MagicDecHipError, check  # noqa: F401
 
 PAGE_SIZE = 128
 MD_KV_BF16, MD_KV_FP8_E4M3 = 0, 1      # include/magicdec_hip.h
+MD_KV_LAYOUT_HND = 0x100
 FP8_DTYPE = torch.float8_e4m3fn
+KV_LAYOUTS = ("NHD", "HND")
 
 
-def _kv_args(kv_cache, kv_scales):
-    """(kv_dtype, k_scale ptr, v_scale ptr) for a paged cache: bf16 caches take no scales, e4m3fn caches
-    need per-kv-head float32 dequantisation scales `(k_scale[KH], v_scale[KH])`."""
+def _kv_geom(kv_cache, kv_layout):
+    """(page_size, KH, D) of a paged cache [pages, 2, page_size, KH, D] ("NHD", the reference's layout:
+    Engine/SnapKV/backend.py:30) or [pages, 2, KH, page_size, D] ("HND", rows of a kv head contiguous)."""
+    if kv_layout not in KV_LAYOUTS:
+        raise ValueError(f"kv_layout must be one of {KV_LAYOUTS}, got {kv_layout!r}")
+    if kv_cache.dim() != 5 or kv_cache.shape[1] != 2 or not kv_cache.is_contiguous():
+        raise ValueError("paged KV cache must be a contiguous [pages, 2, ., ., D] tensor")
+    if kv_layout == "HND":
+        return kv_cache.shape[3], kv_cache.shape[2], kv_cache.shape[4]
+    return kv_cache.shape[2], kv_cache.shape[3], kv_cache.shape[4]
+
+
+def _kv_args(kv_cache, kv_scales, kv_layout="NHD"):
+    """(kv_dtype | layout flag, k_scale ptr, v_scale ptr) for a paged cache: bf16 caches take no scales, e4m3fn
+    caches need per-kv-head float32 dequantisation scales `(k_scale[KH], v_scale[KH])`."""
+    flag = MD_KV_LAYOUT_HND if kv_layout == "HND" else 0
     if kv_cache.dtype == torch.bfloat16:
-        return MD_KV_BF16, None, None
+        return MD_KV_BF16 | flag, None, None
     if kv_cache.dtype != FP8_DTYPE:
         raise TypeError(f"paged KV cache must be bfloat16 or float8_e4m3fn, got {kv_cache.dtype}")
     if kv_scales is None:
         raise ValueError("an fp8 KV cache needs kv_scales=(k_scale, v_scale)")
     ks, vs = kv_scales
-    KH = kv_cache.shape[3]
+    KH = _kv_geom(kv_cache, kv_layout)[1]
     for t in (ks, vs):
         if t.dtype != torch.float32 or t.numel() != KH or not t.is_contiguous() or not t.is_cuda:
             raise ValueError("kv scales must be contiguous float32 [KH] tensors on the GPU")
-    return MD_KV_FP8_E4M3, _p(ks), _p(vs)
+    return MD_KV_FP8_E4M3 | flag, _p(ks), _p(vs)
 
 
 def _p(t):
@@ -71,19 +86,19 @@ def _row_stride(t):
 
 # ----------------------------------------------------------------------------- K4
 def update_kv(k, v, kv_append_indptr, kv_cache, kv_page_indices, kv_page_indptr, kv_page_lastlen, n_max=None,
-              kv_scales=None):
+              kv_scales=None, kv_layout="NHD"):
     """mylib::update_kv (Engine/utils.py:31-54).  In place on kv_cache."""
     _gpu(k, v, kv_cache)
     B = kv_page_indptr.numel() - 1
-    KH, D = kv_cache.shape[3], kv_cache.shape[4]
+    page_size, KH, D = _kv_geom(kv_cache, kv_layout)
     if n_max is None:
         n_max = (k.shape[0] + B - 1) // B if B > 0 else 0
         n_max = max(n_max, 1)
     lib = _lib.load()
     check(lib.md_append_paged_kv(_p(k), _p(v), _row_stride(k), _row_stride(v), _p(_i32(kv_append_indptr)),
                                  _p(kv_cache), _p(_i32(kv_page_indices)), _p(_i32(kv_page_indptr)),
-                                 _p(_i32(kv_page_lastlen)), B, n_max, KH, D, kv_cache.shape[2],
-                                 *_kv_args(kv_cache, kv_scales), _stream()),
+                                 _p(_i32(kv_page_lastlen)), B, n_max, KH, D, page_size,
+                                 *_kv_args(kv_cache, kv_scales, kv_layout), _stream()),
           "md_append_paged_kv")
 
 
@@ -133,9 +148,9 @@ def rope(q, k, indptr, offsets, table: RopeTable, n_max=None):
 
 def rope_append(q, k, v, indptr, offsets, table: RopeTable, kv_cache, page_indices, page_indptr, last_page_len,
                 kv_cache2=None, page_indices2=None, page_indptr2=None, last_page_len2=None, n_max=None,
-                kv_scales=None):
+                kv_scales=None, kv_layout="NHD"):
     """Fused mylib::rope + mylib::update_kv (+ second cache for self-spec verify).  Returns rotated q.
-    kv_cache may be fp8 (with kv_scales); kv_cache2 is always bf16."""
+    kv_cache may be fp8 (with kv_scales) and/or HND (kv_layout); kv_cache2 is always bf16 NHD."""
     _gpu(q, k, v, kv_cache, kv_cache2)
     B = indptr.numel() - 1
     H, D = q.shape[1], q.shape[2]
@@ -148,7 +163,8 @@ def rope_append(q, k, v, indptr, offsets, table: RopeTable, kv_cache, page_indic
                              _p(_i32(indptr)), _p(_i32(offsets)), B, n_max, H, KH, D, _p(table.table), table.max_pos,
                              _p(kv_cache), _p(_i32(page_indices)), _p(_i32(page_indptr)), _p(_i32(last_page_len)),
                              _p(kv_cache2), _p(page_indices2), _p(page_indptr2), _p(last_page_len2),
-                             kv_cache.shape[2], *_kv_args(kv_cache, kv_scales), _stream()), "md_rope_append")
+                             _kv_geom(kv_cache, kv_layout)[0], *_kv_args(kv_cache, kv_scales, kv_layout), _stream()),
+          "md_rope_append")
     return q_out
 
 
@@ -169,15 +185,15 @@ class AttnWorkspace:
 
 
 def paged_attention(q, kv_cache, qo_indptr, page_indices, page_indptr, last_page_len, n_max, max_pages_per_req,
-                    workspace: AttnWorkspace, causal=True, sm_scale=None, out=None, kv_scales=None):
+                    workspace: AttnWorkspace, causal=True, sm_scale=None, out=None, kv_scales=None,
+                    kv_layout="NHD"):
     """mylib::target_decode / target_prefill / draft_decode / draft_prefill
     (Engine/SnapKV/backend.py:56-107): flashinfer BatchPrefillWithPagedKVCacheWrapper.run with the
     plan() arguments passed explicitly."""
     _gpu(q, kv_cache)
     B = page_indptr.numel() - 1
     H, D = q.shape[1], q.shape[2]
-    KH = kv_cache.shape[3]
-    page_size = kv_cache.shape[2]
+    page_size, KH, _ = _kv_geom(kv_cache, kv_layout)
     if sm_scale is None:
         sm_scale = 1.0 / math.sqrt(D)
     if out is None:
@@ -187,7 +203,8 @@ def paged_attention(q, kv_cache, qo_indptr, page_indices, page_indptr, last_page
     ws = workspace.get(nbytes)
     check(lib.md_paged_attn(_p(q), _row_stride(q), _p(kv_cache), _p(out), _p(_i32(qo_indptr)), _p(_i32(page_indices)),
                             _p(_i32(page_indptr)), _p(_i32(last_page_len)), B, n_max, H, KH, D, page_size,
-                            1 if causal else 0, float(sm_scale), max_pages_per_req, *_kv_args(kv_cache, kv_scales),
+                            1 if causal else 0, float(sm_scale), max_pages_per_req,
+                            *_kv_args(kv_cache, kv_scales, kv_layout),
                             _p(ws), ws.numel(), _stream()),
           "md_paged_attn")
     return out
@@ -196,13 +213,14 @@ def paged_attention(q, kv_cache, qo_indptr, page_indices, page_indptr, last_page
 # ----------------------------------------------------------------------------- K6
 def snapkv_select(q_win, kv_cache, page_indices, page_indptr, ctx_len, window, budget, pool_kernel, draft_cache,
                   draft_page_indices, draft_page_indptr, draft_last_page_len, workspace: AttnWorkspace,
-                  return_scores=False, kv_scales=None):
+                  return_scores=False, kv_scales=None, kv_layout="NHD"):
     """Attention.gen_draft_kv (Engine/SnapKV/model.py:389-439): writes budget rows per request and kv head
-    into draft_cache; returns the selected positions [B, KH, budget-window] int32 (reference order)."""
+    into draft_cache; returns the selected positions [B, KH, budget-window] int32 (reference order).
+    kv_layout describes kv_cache (the source); draft_cache is always bf16 NHD."""
     _gpu(q_win, kv_cache, draft_cache)
     B = page_indptr.numel() - 1
     H, D = q_win.shape[1], q_win.shape[2]
-    KH = kv_cache.shape[3]
+    page_size, KH, _ = _kv_geom(kv_cache, kv_layout)
     if not q_win.is_contiguous():
         q_win = q_win.contiguous()
     idx = torch.empty((B, KH, budget - window), dtype=torch.int32, device=q_win.device)
@@ -213,10 +231,10 @@ def snapkv_select(q_win, kv_cache, page_indices, page_indptr, ctx_len, window, b
     ws = workspace.get(nbytes + 512)
     off = (-ws.data_ptr()) % 256
     check(lib.md_snapkv_select(_p(q_win), _p(kv_cache), _p(_i32(page_indices)), _p(_i32(page_indptr)), B, H, KH, D,
-                               kv_cache.shape[2], ctx_len, window, budget, pool_kernel, _p(draft_cache),
+                               page_size, ctx_len, window, budget, pool_kernel, _p(draft_cache),
                                _p(_i32(draft_page_indices)), _p(_i32(draft_page_indptr)), _p(_i32(draft_last_page_len)),
-                               _p(idx), *_kv_args(kv_cache, kv_scales), ctypes.c_void_p(ws.data_ptr() + off), nbytes,
-                               _stream()), "md_snapkv_select")
+                               _p(idx), *_kv_args(kv_cache, kv_scales, kv_layout), ctypes.c_void_p(ws.data_ptr() + off),
+                               nbytes, _stream()), "md_snapkv_select")
     if return_scores:
         soff = lib.md_snapkv_scores_offset(B, H, KH, ctx_len, window)
         n = B * KH * (ctx_len - window)

@@ -21,6 +21,15 @@ def _append(k, v, ip, cache, indices, indptr, last, kv_scales):
         fr.append_paged_kv_cache(k, v, ip, cache, indices, indptr, last)
 
 
+def _nhd(cache, kv_layout):
+    """NHD view [pages, 2, page_size, KH, D] of a cache; for an HND cache a permuted view of the same memory (index
+    writes through it land in the HND tensor)."""
+    if kv_layout == "HND":
+        return cache.permute(0, 1, 3, 2, 4)
+    assert kv_layout == "NHD", kv_layout
+    return cache
+
+
 def _deq(cache, kv_scales):
     return fr.dequantize_cache_fp8(cache, *kv_scales) if cache.dtype == FP8_DTYPE else cache
 
@@ -41,8 +50,8 @@ class AttnWorkspace:
         return None
 
 
-def update_kv(k, v, ip, cache, indices, indptr, last, n_max=None, kv_scales=None):
-    _append(k, v, ip, cache, indices, indptr, last, kv_scales)
+def update_kv(k, v, ip, cache, indices, indptr, last, n_max=None, kv_scales=None, kv_layout="NHD"):
+    _append(k, v, ip, _nhd(cache, kv_layout), indices, indptr, last, kv_scales)
 
 
 def rope(q, k, indptr, offsets, table, n_max=None):
@@ -53,23 +62,24 @@ def rope(q, k, indptr, offsets, table, n_max=None):
 
 
 def rope_append(q, k, v, indptr, offsets, table, cache, indices, iptr, last, cache2=None, indices2=None, iptr2=None,
-                last2=None, n_max=None, kv_scales=None):
+                last2=None, n_max=None, kv_scales=None, kv_layout="NHD"):
     rq, rk = fr.apply_rope(q, k, indptr, offsets, table.table)
-    _append(rk, v, indptr, cache, indices, iptr, last, kv_scales)
+    _append(rk, v, indptr, _nhd(cache, kv_layout), indices, iptr, last, kv_scales)
     if cache2 is not None:
         fr.append_paged_kv_cache(rk, v, indptr, cache2, indices2, iptr2, last2)
     return rq
 
 
 def paged_attention(q, cache, qo_indptr, indices, indptr, last, n_max, max_pages, workspace, causal=True,
-                    sm_scale=None, out=None, kv_scales=None):
+                    sm_scale=None, out=None, kv_scales=None, kv_layout="NHD"):
+    cache = _nhd(cache, kv_layout)
     return fr.batch_prefill_paged(q, _deq(cache, kv_scales), qo_indptr, indices, indptr, last, q.shape[1],
                                   cache.shape[3], q.shape[2], causal=causal, sm_scale=sm_scale)
 
 
 def snapkv_select(q_win, cache, indices, indptr, ctx_len, window, budget, pool_kernel, draft_cache, dindices, dindptr,
-                  dlast, workspace, return_scores=False, kv_scales=None):
-    cache = _deq(cache, kv_scales)          # fp8: rows are gathered as bf16(byte * scale)
+                  dlast, workspace, return_scores=False, kv_scales=None, kv_layout="NHD"):
+    cache = _deq(_nhd(cache, kv_layout), kv_scales)          # fp8: rows are gathered as bf16(byte * scale)
     B = indptr.numel() - 1
     H, KH = q_win.shape[1], cache.shape[3]
     g = H // KH

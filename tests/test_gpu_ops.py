@@ -241,6 +241,53 @@ def test_append_and_fused_rope_append_bit_exact(ops):
     assert torch.equal(bits(c2.cpu()), bits(ref_cache)) and torch.equal(bits(c3.cpu()), bits(ref_cache))
 
 
+def check_append_overflow(ops, layout, fp8=False):
+    """One page mapped, lengths say 130 rows and 4 are appended (rows 126..129): the two rows beyond the page are
+    dropped and counted (md_page_overflow_count), rows 126/127 land, no other page is touched; attention over the same
+    table clamps the length to the mapped page instead of reading a page that is not there."""
+    KH, D, H, n = 2, 64, 8, 4
+    d = lambda t: t.to(DEV)
+    g = torch.Generator().manual_seed(11)
+    k = d(torch.randn(n, KH, D, generator=g).to(BF))
+    v = d(torch.randn(n, KH, D, generator=g).to(BF))
+    q = d(torch.randn(n, H, D, generator=g).to(BF))
+    dt = torch.float8_e4m3fn if fp8 else BF
+    scales = (d(torch.tensor([0.05, 0.04])), d(torch.tensor([0.03, 0.06]))) if fp8 else None
+    shape = (3, 2, KH, 128, D) if layout == "HND" else (3, 2, 128, KH, D)
+    rows = (lambda c, half, sl: c[1, half, :, sl]) if layout == "HND" else (lambda c, half, sl: c[1, half, sl])
+    ip = d(torch.tensor([0, n], dtype=torch.int32))
+    tabs = (d(torch.tensor([1], dtype=torch.int32)), d(torch.tensor([0, 1], dtype=torch.int32)),
+            d(torch.tensor([130], dtype=torch.int32)))
+    tab = ops.RopeTable(2048, D, 10000.0, 1.0, device=DEV)
+    ops.page_overflow_count(reset=True)
+    for fused in (False, True):
+        one = torch.zeros(shape, dtype=dt, device=DEV)
+        if fused:
+            ops.rope_append(q, k, v, ip, d(torch.tensor([126], dtype=torch.int32)), tab, one, *tabs, kv_scales=scales,
+                            kv_layout=layout)
+        else:
+            ops.update_kv(k, v, ip, one, *tabs, kv_scales=scales, kv_layout=layout)
+        torch.cuda.synchronize()
+        assert ops.page_overflow_count(reset=True) == 2, (layout, fused)
+        f = one.float()
+        assert f[0].abs().sum().item() == 0 and f[2].abs().sum().item() == 0
+        for half in (0, 1):
+            assert rows(f, half, slice(0, 126)).abs().sum().item() == 0
+            assert (rows(f, half, slice(126, 128)).abs().sum(-1) > 0).all()
+    assert ops.page_overflow_count(reset=False) == 0
+    ws = ops.AttnWorkspace(DEV)
+    qo = d(torch.tensor([0, n], dtype=torch.int32))
+    o130 = ops.paged_attention(q, one, qo, *tabs, n, 1, ws, kv_scales=scales, kv_layout=layout)
+    o128 = ops.paged_attention(q, one, qo, tabs[0], tabs[1], d(torch.tensor([128], dtype=torch.int32)), n, 1, ws,
+                               kv_scales=scales, kv_layout=layout)
+    assert not torch.isnan(o130.float()).any()
+    assert torch.equal(bits(o130.cpu()), bits(o128.cpu()))
+
+
+def test_append_beyond_mapped_pages_is_dropped_and_counted(ops):
+    check_append_overflow(ops, "NHD")
+
+
 # ----------------------------------------------------------------------------------------- small fused ops
 def _ulp_close(a, b, ulps=1):
     """bf16 tensors equal up to `ulps` units in the last place."""

@@ -595,3 +595,58 @@ def test_fp8_kv_cache_host_logic(cpu_ops_patched, ckpt_dir):
         d = LMBackend_Draft(dtype=torch.bfloat16, device="cpu")
         d.load_model(ckpt_dir / "tinytgt" / "model.pth", use_tp=False)
         d.model.setup_caches(num_pages=4, streaming=True, draft_budget=gc.BUDGET, kv_dtype="fp8")
+
+
+def test_hnd_page_layout_host_logic(cpu_ops_patched, ckpt_dir):
+    """kv_layout="HND" (flashinfer's other page layout; the reference plans "NHD"): the full-context cache is allocated
+    [pages, 2, KH, 128, D], the compressed draft cache stays NHD, every op on the full cache is told the layout, and the
+    engine's tokens / lengths / cache contents equal the NHD engine's (the cache up to the permutation)."""
+    from magicdec_amd import harness, ops
+    from magicdec_amd.Engine.SnapKV.backend import LMBackend
+    ids = next(iter(gc.synthetic_batches()))
+    res = {}
+    for layout in ops.KV_LAYOUTS:
+        eng = LMBackend(dtype=torch.bfloat16, device="cpu", dec_len=gc.GAMMA + 1, draft_dec_len=1)
+        eng.load_model(ckpt_dir / "tinytgt" / "model.pth", use_tp=False)
+        eng.setup_caches(max_batch_size=gc.B, max_seq_length=gc.MAX_LEN, draft_budget=gc.BUDGET, kv_layout=layout)
+        kvc = eng.model.layers[0].attention.kv_cache
+        assert kvc.layout_of("kv_cache") == layout and kvc.layout_of("draft_cache") == "NHD"
+        assert tuple(kvc.kv_cache.shape[2:4]) == ((eng.model.config.n_local_heads, 128) if layout == "HND"
+                                                  else (128, eng.model.config.n_local_heads))
+        assert kvc.draft_cache.shape[2] == 128
+        st, _ = harness.run_selfspec_batch(eng, ids, gc.GAMMA, gc.MAX_LEN, gc.EOT_1, gc.EOT_2, False)
+        res[layout] = (st.output.clone(), st.num_nodes.clone(), eng.cachelens.clone(),
+                       [b.attention.kv_cache.kv_cache.clone() for b in eng.model.layers])
+    for a, b in zip(res["NHD"][:3], res["HND"][:3]):
+        assert torch.equal(a, b)
+    for a, b in zip(res["NHD"][3], res["HND"][3]):
+        assert torch.equal(a.permute(0, 1, 3, 2, 4), b)
+    # argument plumbing of the C-ABI flag
+    c = torch.zeros(2, 2, 4, 128, 64, dtype=torch.bfloat16)
+    assert ops._kv_geom(c, "HND") == (128, 4, 64) and ops._kv_geom(c.permute(0, 1, 3, 2, 4).contiguous(), "NHD") == (128, 4, 64)
+    assert ops._kv_args(c, None, "HND")[0] == ops.MD_KV_BF16 | ops.MD_KV_LAYOUT_HND == 0x100
+    assert ops._kv_args(c, None)[0] == ops.MD_KV_BF16
+    with pytest.raises(ValueError):
+        ops._kv_geom(c, "DNH")
+    with pytest.raises(NotImplementedError):
+        from magicdec_amd.Engine.StreamingLLM.backend_draft import LMBackend_Draft
+        d = LMBackend_Draft(dtype=torch.bfloat16, device="cpu")
+        d.load_model(ckpt_dir / "tinytgt" / "model.pth", use_tp=False)
+        d.model.setup_caches(num_pages=4, streaming=True, draft_budget=gc.BUDGET, kv_layout="HND")
+
+
+def test_c_abi_rejects_unknown_kv_dtype_flags():
+    """kv_dtype carries the storage type in its low byte and MD_KV_LAYOUT_HND (0x100) as a flag; anything else is
+    refused before a kernel is launched (host pointers are enough to reach the check)."""
+    import ctypes
+    from magicdec_amd import _lib
+    lib = _lib.load()
+    buf = torch.zeros(1 << 12, dtype=torch.uint8)
+    p = ctypes.c_void_p(buf.data_ptr())
+    assert buf.data_ptr() % 16 == 0
+    for bad in (0x200, 0x102 | 0x400, 2, 0x102):
+        rc = lib.md_append_paged_kv(p, p, 64, 64, p, p, p, p, p, 1, 1, 1, 64, 128, bad, p, p, None)
+        assert rc < 0, hex(bad)
+        assert "md_append_paged_kv" in lib.md_last_error_string().decode()
+        rc = lib.md_paged_attn(p, 64, p, p, p, p, p, p, 1, 1, 1, 1, 64, 128, 1, 0.125, 1, bad, p, p, p, 256, None)
+        assert rc < 0 and "md_paged_attn" in lib.md_last_error_string().decode(), hex(bad)

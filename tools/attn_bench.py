@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from magicdec_amd import ops
 
 ap = argparse.ArgumentParser()
-for k, v in dict(B=64, S=16036, KH=8, H=32, D=128, n=4, iters=20, layers=2, wgs=0, fp8=0).items():
+for k, v in dict(B=64, S=16036, KH=8, H=32, D=128, n=4, iters=20, layers=2, wgs=0, fp8=0, hnd=0).items():
     ap.add_argument(f"--{k}", type=int, default=v)
 a = ap.parse_args()
 if a.wgs:
@@ -22,6 +22,9 @@ scales = None
 if a.fp8:
     caches = [c.to(torch.float8_e4m3fn) for c in caches]
     scales = (torch.full((a.KH,), 0.5, device=dev), torch.full((a.KH,), 0.25, device=dev))
+layout = "HND" if a.hnd else "NHD"
+if a.hnd:                                     # same values, rows of one kv head contiguous inside a page
+    caches = [c.permute(0, 1, 3, 2, 4).contiguous() for c in caches]
 q = torch.randn(a.B * a.n, a.H, a.D, device=dev, generator=g, dtype=torch.float32).to(torch.bfloat16)
 indices = torch.arange(a.B * mp, dtype=torch.int32, device=dev)
 indptr = torch.arange(a.B + 1, dtype=torch.int32, device=dev) * mp
@@ -29,12 +32,14 @@ last = torch.full((a.B,), a.S - (mp - 1) * 128, dtype=torch.int32, device=dev)
 qo = torch.arange(a.B + 1, dtype=torch.int32, device=dev) * a.n
 ws = ops.AttnWorkspace(dev)
 for i in range(3):
-    ops.paged_attention(q, caches[i % a.layers], qo, indices, indptr, last, a.n, mp, ws, kv_scales=scales)
+    ops.paged_attention(q, caches[i % a.layers], qo, indices, indptr, last, a.n, mp, ws, kv_scales=scales,
+                        kv_layout=layout)
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
 for i in range(a.iters):
-    ops.paged_attention(q, caches[i % a.layers], qo, indices, indptr, last, a.n, mp, ws, kv_scales=scales)
+    ops.paged_attention(q, caches[i % a.layers], qo, indices, indptr, last, a.n, mp, ws, kv_scales=scales,
+                        kv_layout=layout)
 e1.record()
 torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / a.iters
@@ -43,4 +48,4 @@ flops = 4.0 * a.B * a.n * a.H * a.D * (a.S - a.n / 2.0)          # causal: row i
 if a.n >= 32:
     print(f"  prefill view: {flops / ms / 1e9:.1f} TFLOP/s = {flops / ms / 1e9 / 25:.2f}% of 2.5 PFLOP/s dense bf16")
 print(f"md_paged_attn B={a.B} S={a.S} KH={a.KH} H={a.H} D={a.D} n={a.n}: {ms:.4f} ms  {nbytes / ms / 1e6:.1f} GB/s  "
-      f"{nbytes / ms / 1e6 / 80:.2f}% of 8 TB/s  (alg bytes {nbytes}) wgs={a.wgs} fp8={a.fp8} map={os.environ.get('MD_ATTN_MAP', '0')}")
+      f"{nbytes / ms / 1e6 / 80:.2f}% of 8 TB/s  (alg bytes {nbytes}) wgs={a.wgs} fp8={a.fp8} layout={layout} map={os.environ.get('MD_ATTN_MAP', '0')}")

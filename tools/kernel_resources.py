@@ -47,8 +47,7 @@ def main():
         n = re.sub(r"\(.*", "", n)
         print(f"{r[0]:12} {r[2]:4d} {r[3]:4d} {r[4]:4d} {r[5]:6d} {r[6]:6d} {r[7]:10d} {r[8]:7d} {r[9]:5d}  {n}")
     clean = lambda n: re.sub(r"\(.*", "", re.sub(r"\(anonymous namespace\)::", "", n))
-    print(f"\n{len(rows)} kernels; kernels with VGPR spills: {[clean(n) for r, n in zip(rows, names) if r[5]] or 'none'}"
-          "   (paged_attn_kernel<.., true, ..> = the retired wave-private prefill variant, development A/B switch only)")
+    print(f"\n{len(rows)} kernels; kernels with VGPR spills: {[clean(n) for r, n in zip(rows, names) if r[5]] or 'none'}")
     return 0
 
 
