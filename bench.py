@@ -297,29 +297,45 @@ def run(args, dev):
             return harness.selfspec_iteration(engine, st, G, eot_1, eot_2, S + 80, next_double, streaming, forced)
         return harness.longspec_iteration(engine, draft, st, G, eot_1, eot_2, S + 80, next_double, forced, bcast)
 
+    debug_iters = os.environ.get("MAGICDEC_BENCH_DEBUG_ITERS", "0") == "1"
+
     def run_spec(n_warm, n_steps, forced_table):
         restore()
         nd = False
         tokens = torch.zeros((), dtype=torch.long, device=dev)
         timer.enabled = False
         for i in range(n_warm):
+            # exactly the statements of a timed step: the first execution of any torch op in a process loads its code
+            # object (the token counter's int sum + add cost 18.6 ms in the first timed iteration when the warm-up
+            # loop did not run them: profiles/r02_bench_first_iteration.txt)
             term, nd = iteration(nd, forced_table[i] if forced_table is not None else None)
+            tokens += st.accept_nums.sum()
             if term:
                 restore()
                 nd = False
+        tokens.zero_()
         timer.pairs.clear()
         timer.enabled = True
         barrier()
         t0 = time.perf_counter()
+        stamps = []
         for i in range(n_steps):
             term, nd = iteration(nd, forced_table[n_warm + i] if forced_table is not None else None)
             tokens += st.accept_nums.sum()
+            stamps.append((time.perf_counter(), bool(term), bool(nd)))   # the iteration ended with a host read
             if term:
                 restore()
                 nd = False
         barrier()
         dt = time.perf_counter() - t0
         timer.enabled = False
+        if debug_iters and rank == 0:
+            prev, out = t0, []
+            for t, te, d2 in stamps:
+                out.append(f"{(t - prev) * 1e3:.2f}{'T' if te else ''}{'d' if d2 else ''}")
+                prev = t
+            print(f"[bench debug] {n_steps} iterations in {dt * 1e3:.1f} ms (+{(time.perf_counter() - t0 - dt) * 1e3:.1f}): "
+                  + " ".join(out), file=sys.stderr, flush=True)
         return dt, int(tokens.item())
 
     def prime():
@@ -347,6 +363,9 @@ def run(args, dev):
     gen = torch.Generator(device=dev if on_gpu else "cpu").manual_seed(2024)
     forced = truncated_geometric(args.alpha, G, (args.warmup + args.steps, B), gen, dev)
     dt_replay, tok_replay = run_spec(args.warmup, args.steps, forced)
+    if debug_iters:                      # development: is the first timed region slower than a repeat of itself?
+        for _ in range(2):
+            run_spec(args.warmup, args.steps, forced)
     if args.graphs:
         # HIP events cannot be recorded inside a replayed graph: time the verify-attention launches in an eager
         # pass of the same iterations (same kernels, same shapes, same stream) right after the timed region

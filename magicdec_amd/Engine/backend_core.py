@@ -26,6 +26,17 @@ PAGE_SIZE = 128    # Engine/SnapKV/backend.py:31
 CHUNK = 128        # Engine/SnapKV/backend.py:236
 
 
+def default_kv_layout():
+    """Page layout of the full-context cache when setup_caches() is not told one: the reference's "NHD"
+    (Engine/SnapKV/backend.py:30) unless MAGICDEC_KV_LAYOUT=HND.  Tokens are identical either way (the layout moves
+    bytes, not arithmetic); HND reads the verify stream in longer runs."""
+    import os
+    v = os.environ.get("MAGICDEC_KV_LAYOUT", "NHD").upper()
+    if v not in ("NHD", "HND"):
+        raise ValueError(f"MAGICDEC_KV_LAYOUT must be NHD or HND, got {v!r}")
+    return v
+
+
 def _pages_per_request(max_batch_size, max_seq_length, page_size=PAGE_SIZE):
     """Engine/SnapKV/backend.py:32-35."""
     n = max_batch_size * max_seq_length // page_size
@@ -126,12 +137,13 @@ class SnapKVTargetBackend(_BackendBase):
 
     @torch.no_grad()
     def setup_caches(self, max_batch_size: int = 1, max_seq_length: int = 2048, draft_budget=0, window_size=32,
-                     kv_dtype="bf16", kv_layout="NHD"):
+                     kv_dtype="bf16", kv_layout=None):
         """kv_dtype="fp8": the full-context cache is OCP e4m3fn with static per-head scales calibrated on the
         first prefill chunk (not in the reference; BASELINE.json configs[4]).  The compressed draft cache stays bf16.
         kv_layout="HND": the full-context cache keeps the rows of one kv head contiguous inside a page (the
         reference's flashinfer wrappers are planned "NHD": Engine/SnapKV/backend.py:30); same results, longer
-        contiguous runs for the verify step's stream (matters for fp8 rows of 128 bytes)."""
+        contiguous runs for the verify step's stream (matters for fp8 rows of 128 bytes).  None = default_kv_layout()."""
+        kv_layout = default_kv_layout() if kv_layout is None else kv_layout
         self.max_length, self.batch_size = max_seq_length, max_batch_size
         dev = self.device
         self.page_size = PAGE_SIZE
@@ -437,7 +449,8 @@ class StreamingSelfSpecBackend(_BackendBase, _StreamingMixin):
 
     @torch.no_grad()
     def setup_caches(self, max_batch_size: int = 1, max_seq_length: int = 2048, draft_budget=0, kv_dtype="bf16",
-                     kv_layout="NHD"):
+                     kv_layout=None):
+        kv_layout = default_kv_layout() if kv_layout is None else kv_layout
         self.draft_budget, self.batch_size = draft_budget, max_batch_size
         dev = self.device
         self.page_size = PAGE_SIZE

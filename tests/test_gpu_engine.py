@@ -411,6 +411,8 @@ def test_cfg5_layout_lockstep_qwen_selfspec_snapkv_fp8_cache():
     # report how many bytes differ (1-ulp bf16 differences of k/v can move an fp8 rounding)
     kc = e.model.layers[0].attention.kv_cache
     hip = kc.kv_cache.float().cpu()
+    if kc.layout == "HND":                     # MAGICDEC_KV_LAYOUT=HND: back to [pages, 2, 128, KH, D]
+        hip = hip.permute(0, 1, 3, 2, 4).contiguous()
     hip[:, 0] *= kc.k_scale.cpu().view(1, 1, -1, 1)
     hip[:, 1] *= kc.v_scale.cpu().view(1, 1, -1, 1)
     ref = eng.eng.caches[0]

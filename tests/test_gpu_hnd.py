@@ -93,7 +93,7 @@ def test_hnd_append_and_fused_rope_append(ops, fp8):
     tab = ops.RopeTable(2048, D, 10000.0, 1.0, device=DEV)
     g = torch.Generator().manual_seed(4)
     qkv = torch.randn(B * n, (H + 2 * KH) * D, generator=g).to(BF)
-    d = lambda t: t.to(DEV)
+    d = lambda t: t.to(DEV).clone()
     dqkv = d(qkv)
     dq = dqkv[:, :H * D].unflatten(1, (H, D))
     dk = dqkv[:, H * D:(H + KH) * D].unflatten(1, (KH, D))

@@ -650,3 +650,22 @@ def test_c_abi_rejects_unknown_kv_dtype_flags():
         assert "md_append_paged_kv" in lib.md_last_error_string().decode()
         rc = lib.md_paged_attn(p, 64, p, p, p, p, p, p, 1, 1, 1, 1, 64, 128, 1, 0.125, 1, bad, p, p, p, 256, None)
         assert rc < 0 and "md_paged_attn" in lib.md_last_error_string().decode(), hex(bad)
+
+
+def test_default_kv_layout_env(monkeypatch, cpu_ops_patched, ckpt_dir):
+    """setup_caches() without kv_layout: the reference's NHD, or what MAGICDEC_KV_LAYOUT says."""
+    from magicdec_amd.Engine import backend_core
+    from magicdec_amd.Engine.SnapKV.backend import LMBackend
+    monkeypatch.delenv("MAGICDEC_KV_LAYOUT", raising=False)
+    assert backend_core.default_kv_layout() == "NHD"
+    monkeypatch.setenv("MAGICDEC_KV_LAYOUT", "hnd")
+    assert backend_core.default_kv_layout() == "HND"
+    eng = LMBackend(dtype=torch.bfloat16, device="cpu", dec_len=gc.GAMMA + 1, draft_dec_len=1)
+    eng.load_model(ckpt_dir / "tinytgt" / "model.pth", use_tp=False)
+    eng.setup_caches(max_batch_size=gc.B, max_seq_length=gc.MAX_LEN, draft_budget=gc.BUDGET)
+    assert eng.model.layers[0].attention.kv_cache.layout == "HND"
+    eng.setup_caches(max_batch_size=gc.B, max_seq_length=gc.MAX_LEN, draft_budget=gc.BUDGET, kv_layout="NHD")
+    assert eng.model.layers[0].attention.kv_cache.layout == "NHD"
+    monkeypatch.setenv("MAGICDEC_KV_LAYOUT", "DNH")
+    with pytest.raises(ValueError):
+        backend_core.default_kv_layout()
