@@ -59,7 +59,19 @@ TINY = {
     "tiny70b": (dict(block_size=4096, n_layer=2, n_head=16, n_local_heads=2, dim=2048, intermediate_size=2048,
                      vocab_size=2048, rope_base=500000.0, scaling_factor=8, high_freq_factor=4, low_freq_factor=1,
                      original_max_position_embeddings=8192), 22, 0.1),
+    # four kv heads (g = 4, D = 64): shards evenly over TP4 (target) and TP2 (draft sub-group), the README's
+    # "target on all ranks, draft on half of them" topology in miniature
+    "tinykh4": (dict(block_size=4096, n_layer=2, n_head=16, n_local_heads=4, dim=1024, intermediate_size=1024,
+                     vocab_size=2048, rope_base=500000.0, scaling_factor=8, high_freq_factor=4, low_freq_factor=1,
+                     original_max_position_embeddings=8192), 24, 0.1),
 }
+
+
+def tp_world(tag):
+    """World size of a TP scenario from its tag: ..._tp2 -> 2, ..._tp4d2 (target TP4, draft TP2) -> 4; else 0."""
+    import re
+    m = re.search(r"_tp(\d+)(?:d\d+)?$", tag)
+    return int(m.group(1)) if m else 0
 
 
 def bits(t):
@@ -379,7 +391,7 @@ def _tp_cpu_shims():
 def run_script(script, argv, classes, vocab, prefix_len, n_seq, tag):
     """Run a reference benchmark script unmodified under runpy, tracing Engine method calls."""
     inject_configs()
-    if tag.endswith("_tp2"):
+    if tp_world(tag):
         _tp_cpu_shims()
     import transformers
     transformers.AutoTokenizer = StubTokenizer
@@ -440,6 +452,8 @@ def run_script(script, argv, classes, vocab, prefix_len, n_seq, tag):
                                                           snapkv_topk=topk_calls)))
     elif topk_calls:     # ... but each rank resolves the top-k ties of ITS kv heads: needed to replay rank r
         (GOLD / f"{tag}_topk_rank{lr}.json").write_text(json.dumps(dict(snapkv_topk=topk_calls)))
+    elif lr == tp_world(tag) - 1:   # a rank outside the draft sub-group: target calls only, tokens by broadcast
+        (GOLD / f"{tag}_trace_rank{lr}.json").write_text(json.dumps(dict(trace=trace, final=final)))
 
 
 def scen_run(tag):
@@ -483,6 +497,14 @@ def scen_run(tag):
         run_script("tests/SnapKV/longspec_benchmark.py",
                    ["--target", str(ck["tinytgt"]), "--model", str(ck["tinytgt"]), "--draft_budget", "129",
                     "--draft_rank_group", "0", "1"] + common2,
+                   [("Engine.SnapKV.backend", "LMBackend", ["encode", "inference"]),
+                    ("Engine.SnapKV.backend_draft", "LMBackend_Draft", ["encode", "inference"])], vocab, S, 6 * B, tag)
+    elif tag == "run_longspec_snapkv_tp4d2":  # README.md:69's topology in miniature: target on all 4 ranks, SnapKV draft
+        # on the sub-group {0, 1}; the gamma draft tokens reach ranks 2, 3 by broadcast (longspec_benchmark.py:189)
+        common4 = [c for c in common[:-2]] + ["--rank_group", "0", "1", "2", "3"]
+        run_script("tests/SnapKV/longspec_benchmark.py",
+                   ["--target", str(ck["tinykh4"]), "--model", str(ck["tinykh4"]), "--draft_budget", "129",
+                    "--draft_rank_group", "0", "1"] + common4,
                    [("Engine.SnapKV.backend", "LMBackend", ["encode", "inference"]),
                     ("Engine.SnapKV.backend_draft", "LMBackend_Draft", ["encode", "inference"])], vocab, S, 6 * B, tag)
     elif tag == "run_longspec_stream_70b":    # configs[3]'s layout in miniature: 70B-like target (g=8) + a different,
@@ -630,7 +652,7 @@ SCENARIOS = {"int8_quant": scen_int8_quant, "pg19": scen_pg19, "convert_hf": sce
 RUNS = ["run_longspec_snapkv", "run_longspec_snapkv_rej", "run_longspec_stream", "run_selfspec_snapkv",
         "run_selfspec_stream", "run_baseline", "run_longspec_stream_tp2", "run_longspec_snapkv_tp2",
         "run_selfspec_snapkv_tp2", "run_selfspec_snapkv_qwen", "run_selfspec_snapkv_70b",
-        "run_longspec_stream_70b", "run_selfspec_stream_tp2"]
+        "run_longspec_stream_70b", "run_selfspec_stream_tp2", "run_longspec_snapkv_tp4d2"]
 
 
 def _spawn_tp(scenario, world=2):
@@ -657,8 +679,8 @@ def main():
             print("==", s, flush=True)
             subprocess.run([sys.executable, "-m", "oracle.gen_golden", "--scenario", s], cwd=str(ROOT), check=True)
         return
-    if a.scenario.endswith("_tp2") and os.environ.get("MD_GOLDEN_CHILD") != "1":
-        _spawn_tp(a.scenario)
+    if tp_world(a.scenario) and os.environ.get("MD_GOLDEN_CHILD") != "1":
+        _spawn_tp(a.scenario, tp_world(a.scenario))
         return
     torch.manual_seed(0)
     with torch.inference_mode():

@@ -23,6 +23,10 @@ TINY = {
     "tiny70b": (RefConfig(n_layer=2, n_head=16, n_local_heads=2, dim=2048, intermediate_size=2048, vocab_size=2048,
                           rope_base=500000.0, scaling_factor=8, high_freq_factor=4, low_freq_factor=1,
                           original_max_position_embeddings=8192), 22, 0.1),
+    # four kv heads (g = 4, D = 64): shards evenly over TP4 (target) and a TP2 draft sub-group
+    "tinykh4": (RefConfig(n_layer=2, n_head=16, n_local_heads=4, dim=1024, intermediate_size=1024, vocab_size=2048,
+                          rope_base=500000.0, scaling_factor=8, high_freq_factor=4, low_freq_factor=1,
+                          original_max_position_embeddings=8192), 24, 0.1),
 }
 B, S, MAX_LEN, GAMMA, BUDGET, EOT_1, EOT_2 = 2, 416, 512, 3, 129, 2, 0
 

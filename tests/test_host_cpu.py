@@ -382,25 +382,34 @@ from magicdec_amd.Engine.SnapKV.backend_draft import LMBackend_Draft
 from tests.test_host_cpu import Tracer
 ck = Path(os.environ["MD_CKPT"])
 gc.register_tiny(model_core)
-rank, group, dgroup = init_dist([0, 1])
-kind = os.environ["MD_KIND"]                      # fixture name: run_longspec_snapkv_tp2 | run_selfspec_snapkv_tp2
-# each rank replays the reference's tie resolution for ITS kv heads (torch.topk's tie order is implementation-defined)
-if "snapkv" in kind:
+draft_ranks = [int(x) for x in os.environ.get("MD_DRAFT_RANKS", "0,1").split(",")]
+model = os.environ.get("MD_MODEL", "tinytgt")
+rank, group, dgroup = init_dist(draft_ranks)
+world = dist.get_world_size()
+ranks = list(range(world))
+kind = os.environ["MD_KIND"]                      # fixture name: run_longspec_snapkv_tp2 | run_selfspec_snapkv_tp2 | ...
+# each rank replays the reference's tie resolution for ITS kv heads (torch.topk's tie order is implementation-defined);
+# in the longspec layout only the draft sub-group runs the SnapKV select
+if "snapkv" in kind and (rank in draft_ranks or not kind.startswith("run_longspec")):
     name = f"{kind}.json" if rank == 0 else f"{kind}_topk_rank{rank}.json"
     cpu_ops.TOPK_REPLAY.update(table=gc.load_json(name)["snapkv_topk"], pos=0)
 log = []
 last = None
 if kind.startswith("run_longspec"):
     eng = LMBackend(dtype=torch.bfloat16, device="cpu", dec_len=gc.GAMMA + 1)
-    eng.load_model(ck / "tinytgt" / "model.pth", use_tp=True, rank_group=[0, 1], group=group)
+    eng.load_model(ck / model / "model.pth", use_tp=True, rank_group=ranks, group=group)
     eng.setup_caches(max_batch_size=gc.B, max_seq_length=gc.MAX_LEN)
-    drf = LMBackend_Draft(dtype=torch.bfloat16, device="cpu", draft_budget=gc.BUDGET)
-    drf.load_model(ck / "tinytgt" / "model.pth", use_tp=True, rank_group=[0, 1], group=dgroup)
-    drf.setup_caches(max_batch_size=gc.B, max_seq_length=gc.MAX_LEN, draft_budget=gc.BUDGET)
+    td = None
+    if rank in draft_ranks:                       # tests/SnapKV/longspec_benchmark.py:96-103
+        drf = LMBackend_Draft(dtype=torch.bfloat16, device="cpu", draft_budget=gc.BUDGET)
+        drf.load_model(ck / model / "model.pth", use_tp=len(draft_ranks) > 1, rank_group=draft_ranks, group=dgroup)
+        drf.setup_caches(max_batch_size=gc.B, max_seq_length=gc.MAX_LEN, draft_budget=gc.BUDGET)
+        td = Tracer(drf, "SnapKV.LMBackend_Draft", log, ("encode", "inference"))
     te = Tracer(eng, "SnapKV.LMBackend", log, ("encode", "inference"))
-    td = Tracer(drf, "SnapKV.LMBackend_Draft", log, ("encode", "inference"))
+    bcast = (draft_ranks[0], group) if len(draft_ranks) != world else None      # longspec_benchmark.py:189
     for b_ids in gc.synthetic_batches():
-        last, _ = harness.run_longspec_batch(te, td, b_ids, gc.GAMMA, gc.MAX_LEN, gc.EOT_1, gc.EOT_2, barrier=dist.barrier)
+        last, _ = harness.run_longspec_batch(te, td, b_ids, gc.GAMMA, gc.MAX_LEN, gc.EOT_1, gc.EOT_2, bcast=bcast,
+                                             barrier=dist.barrier)
 elif "snapkv" in kind:
     eng = LMBackend(dtype=torch.bfloat16, device="cpu", dec_len=gc.GAMMA + 1, draft_dec_len=1)
     eng.load_model(ck / "tinytgt" / "model.pth", use_tp=True, rank_group=[0, 1], group=group)
@@ -447,6 +456,37 @@ def test_tensor_parallel_snapkv_matches_reference_tp2_trace(kind, ckpt_dir):
         got = json.load(open(os.path.join(out, f"rank{r}.json")))
         _compare(got["trace"], j["trace"])
         assert got["final"] == j["final"]
+
+
+def test_tensor_parallel_tp4_target_with_tp2_draft_subgroup_matches_reference_trace(ckpt_dir):
+    """The reference README's topology (README.md:69: target on all ranks, draft on a sub-group) in miniature: target
+    TP4 + SnapKV draft TP2 on ranks {0, 1} over gloo, world_size 4, four-kv-head model.  Ranks 2 and 3 hold no draft
+    model and receive the gamma draft tokens by broadcast (tests/SnapKV/longspec_benchmark.py:176-189).  Rank 0's
+    Engine-call trace (target + draft) and rank 3's (target only) and every rank's final output equal the REAL
+    reference's run of the same command (oracle/gen_golden.py run_longspec_snapkv_tp4d2) bit for bit."""
+    import json
+    kind = "run_longspec_snapkv_tp4d2"
+    out = tempfile.mkdtemp(prefix="md_tp4_")
+    script = os.path.join(out, "worker.py")
+    Path(script).write_text(TP_SNAPKV_WORKER)
+    port = 29300 + (os.getpid() % 500)
+    procs = []
+    for r in range(4):
+        env = dict(os.environ, LOCAL_RANK=str(r), LOCAL_WORLD_SIZE="4", RANK=str(r), WORLD_SIZE="4",
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), MD_ROOT=str(ROOT), MD_CKPT=str(ckpt_dir), MD_OUT=out,
+                   MD_KIND=kind, MD_DRAFT_RANKS="0,1", MD_MODEL="tinykh4", OMP_NUM_THREADS="2")
+        procs.append(subprocess.Popen([sys.executable, script], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    logs = [p.communicate(timeout=1500)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(logs)
+    j = gc.load_json(f"{kind}.json")
+    j3 = gc.load_json(f"{kind}_trace_rank3.json")
+    got = [json.load(open(os.path.join(out, f"rank{r}.json"))) for r in range(4)]
+    _compare(got[0]["trace"], j["trace"])
+    _compare(got[3]["trace"], j3["trace"])
+    assert sum(1 for r in j["trace"] if "cachelen_update" in r) > 10          # two-token draft steps occurred
+    assert not any(r["cls"].endswith("LMBackend_Draft") for r in got[2]["trace"] + got[3]["trace"])
+    for r in range(4):
+        assert got[r]["final"] == j["final"]
 
 
 # ------------------------------------------------------------------ checkpoint ingestion (SURVEY 8f-3)
