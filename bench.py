@@ -77,9 +77,11 @@ def parse():
     ap.add_argument("--kv-dtype", default="bf16", choices=["bf16", "fp8"],
                     help="full-context KV cache storage (fp8 = OCP e4m3fn, BASELINE configs[4]; default bf16 = the "
                          "reference's)")
-    ap.add_argument("--kv-layout", default="NHD", choices=["NHD", "HND"],
-                    help="page layout of the full-context KV cache: NHD = the reference's flashinfer layout; HND keeps "
-                         "the rows of a kv head contiguous (DESIGN.md section 3.1)")
+    ap.add_argument("--kv-layout", default="HND", choices=["NHD", "HND"],
+                    help="page layout of the full-context KV cache: HND (default here) keeps the rows of a kv head "
+                         "contiguous -- same tokens, verify attention 85 %% instead of 82 %% of the HBM peak (bf16), 81 %% "
+                         "instead of 71 %% (fp8), profiles/r02_layout_ab.txt; NHD = the reference's flashinfer layout and "
+                         "the Engine API's default (DESIGN.md section 3.1)")
     ap.add_argument("--draft-tp", type=int, default=4, help="size of the draft sub-group (reference README: 4 of 8)")
     ap.add_argument("--pmc", dest="pmc", action="store_true", default=None,
                     help="measure roofline.traffic live: two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of the "
@@ -194,7 +196,7 @@ def run(args, dev):
     # message at N=8 (14 MiB inbound per rank) -- and it has only been exercised with processes sharing one GPU.
     setup_seed(123)
 
-    kv_layout = getattr(args, "kv_layout", "NHD")
+    kv_layout = getattr(args, "kv_layout", "HND")
     selfspec = kind.startswith("selfspec")
     streaming = kind.endswith("stream")            # the draft-side cache: StreamingLLM ring, else SnapKV select
     t_load = time.time()
