@@ -479,16 +479,59 @@ def run(args, dev):
         # after every number of the line has been taken: what one per-layer collective of this run costs, RCCL against
         # the xGMI kernels (never run over real links before the first multi-GPU bench: this is where they get measured)
         dim_t = engine.model.tok_embeddings.weight.shape[1]
-        try:
-            coll = collective_microbench(group, [("verify", B * (G + 1), dim_t), ("autoregressive", B, dim_t)], dev)
-        except Exception as e:  # noqa: BLE001 -- a report, never a reason to lose the line
-            coll = {"error": f"{type(e).__name__}: {e}"}
+        coll = collective_microbench_isolated([("verify", B * (G + 1), dim_t), ("autoregressive", B, dim_t)])
         if rank == 0:
             line["collectives_us"] = coll
     if use_tp:
         dist.barrier()
         dist.destroy_process_group()
     return line if rank == 0 else None
+
+
+def collective_microbench_isolated(shapes, iters=30, timeout_s=240, dry=False):
+    """collective_microbench in one CHILD process per rank (tools/collective_bench.py): same ranks and GPUs, a
+    rendezvous port of its own, the parents waiting on the host (a GPU-side barrier would spin on the CUs the children
+    are timing).  The xGMI kernels map peer memory and had never run over real links before the first multi-GPU bench;
+    whatever they do -- fault, hang, disagree with RCCL -- costs this report, not the benchmark's line.  Collective
+    over the ranks of the job (every rank must call it); returns the report on rank 0 (None elsewhere); failures are
+    reported as {"error": ...}."""
+    import subprocess
+    import tempfile
+    rank = int(os.environ.get("RANK", "0"))
+    base = int(os.environ.get("MASTER_PORT", "29500"))
+    port = 20000 + (base * 7 + 1234) % 20000
+    if port == base:
+        port += 1
+    env = {k: v for k, v in os.environ.items() if not k.startswith("TORCHELASTIC_")}   # the child hosts its own store
+    env["MASTER_PORT"] = str(port)
+    env.setdefault("MASTER_ADDR", "127.0.0.1")
+    out = os.path.join(tempfile.gettempdir(), f"md_collectives_{base}_{os.getpid()}.json")
+    cmd = [sys.executable, os.path.join(ROOT, "tools", "collective_bench.py"), "--shapes",
+           ",".join(f"{n}:{r}:{d}" for n, r, d in shapes), "--iters", str(iters), "--out", out] + (["--dry"] if dry else [])
+    err = None
+    try:
+        p = subprocess.Popen(cmd, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, cwd=ROOT)
+        try:
+            _, stderr = p.communicate(timeout=timeout_s)
+            if p.returncode != 0:
+                err = f"child exited with {p.returncode}: {stderr.decode(errors='replace')[-400:]}"
+        except subprocess.TimeoutExpired:
+            p.kill()                      # this exact child (never by pattern)
+            p.communicate()
+            err = f"child timed out after {timeout_s} s"
+    except OSError as e:
+        err = f"{type(e).__name__}: {e}"
+    if rank != 0:
+        return None
+    try:
+        with open(out) as f:
+            res = json.load(f)
+        os.remove(out)
+        if err is not None and isinstance(res, dict):
+            res["rank0_child"] = err
+        return res
+    except (OSError, ValueError):
+        return {"error": err or "the rank-0 child wrote no report"}
 
 
 def collective_microbench(group, shapes, dev, iters=30):

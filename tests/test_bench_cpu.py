@@ -53,3 +53,37 @@ def test_bench_control_flow_on_cpu(world, draft_tp, workload):
     assert line["n_gpus"] == world and line["steps"] == 6 and line["value"] > 0
     assert line["unit"] == "tokens/s" and line["higher_is_better"] is True and line["vs_baseline"] is None
     assert set(line["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
+
+
+def test_collective_report_runs_in_child_processes():
+    """bench.collective_microbench_isolated: every rank starts tools/collective_bench.py with a rendezvous port of its
+    own, waits on the host and rank 0 returns the children's report; a child that never completes (here: its peer is
+    missing) is killed after the time-out and reported, the caller carries on.  (--dry: rendezvous + barrier over gloo.)"""
+    import json
+    import subprocess
+    import sys
+    import tempfile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import json, sys; sys.path.insert(0, %r); import bench; "
+            "print('RESULT ' + json.dumps(bench.collective_microbench_isolated([('probe', 8, 16)], iters=2, "
+            "timeout_s=float(sys.argv[1]), dry=True)))" % root)
+    port = 23000 + os.getpid() % 4000
+
+    def parent(rank, world, timeout):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), LOCAL_WORLD_SIZE=str(world),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="2",
+                   TORCHELASTIC_USE_AGENT_STORE="True")      # what torchrun exports; the children must not inherit it
+        return subprocess.Popen([sys.executable, "-c", code, str(timeout)], env=env, stdout=subprocess.PIPE,
+                                stderr=subprocess.STDOUT, cwd=tempfile.gettempdir())
+    procs = [parent(r, 2, 120) for r in range(2)]
+    outs = [p.communicate(timeout=300)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+    res = [json.loads(o.split("RESULT ", 1)[1].splitlines()[0]) for o in outs]
+    assert res[0] == {"dry": True, "world": 2, "shapes": ["probe"]} and res[1] is None
+    # a lone rank 0 of a 2-rank job: its child blocks in the rendezvous, is killed, and the failure is the report
+    port += 1
+    p = parent(0, 2, 8)
+    out = p.communicate(timeout=300)[0].decode()
+    assert p.returncode == 0, out
+    r = json.loads(out.split("RESULT ", 1)[1].splitlines()[0])
+    assert "timed out" in r["error"], r
