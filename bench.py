@@ -479,6 +479,8 @@ def run(args, dev):
         # after every number of the line has been taken: what one per-layer collective of this run costs, RCCL against
         # the xGMI kernels (never run over real links before the first multi-GPU bench: this is where they get measured)
         dim_t = engine.model.tok_embeddings.weight.shape[1]
+        dist.barrier()             # rank 0 arrives late (PMC passes): the children's time-out starts for all ranks together
+        _sync(dev)
         coll = collective_microbench_isolated([("verify", B * (G + 1), dim_t), ("autoregressive", B, dim_t)])
         if rank == 0:
             line["collectives_us"] = coll
