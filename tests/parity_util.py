@@ -23,6 +23,24 @@ U_BF16 = 2.0 ** -8            # unit round-off of bf16: relative error of round-
 ATTN_BOUND_SLACK = 1.05
 
 
+class capped_threads:
+    """`with capped_threads():` -- at most `n` intra-op threads for a float64 YARDSTICK computation (never for an
+    oracle whose bits are compared): on the GPU boxes' 256-core hosts torch's default pool makes small float64
+    matmuls tens of times slower than 16 threads do (bench.py's cpu_baseline measured the same)."""
+
+    def __init__(self, n=16):
+        self.n = n
+
+    def __enter__(self):
+        self.prev = torch.get_num_threads()
+        if self.prev > self.n:
+            torch.set_num_threads(self.n)
+
+    def __exit__(self, *exc):
+        if torch.get_num_threads() != self.prev:
+            torch.set_num_threads(self.prev)
+
+
 def bf16_ulp(x):
     """Spacing of bf16 numbers at |x| (tensor, float64)."""
     ax = x.abs().clamp_min(2.0 ** -126)
@@ -39,6 +57,13 @@ def dense_attention_f64(q, cache, qo_indptr, indices, indptr, last, H, KH, D, ca
     out = torch.zeros(rows, H, D, dtype=torch.float64)
     bnd = torch.zeros(rows, H, D, dtype=torch.float64)
     B = indptr.numel() - 1
+    with capped_threads():
+        _dense_attention_f64_rows(out, bnd, q, cache, qo_indptr, indices, indptr, last, KH, g, D, causal, sm_scale, B)
+    return out, bnd
+
+
+def _dense_attention_f64_rows(out, bnd, q, cache, qo_indptr, indices, indptr, last, KH, g, D, causal, sm_scale, B):
+    H = KH * g
     for b in range(B):
         q0, q1 = int(qo_indptr[b]), int(qo_indptr[b + 1])
         m = q1 - q0
@@ -57,7 +82,6 @@ def dense_attention_f64(q, cache, qo_indptr, indices, indptr, last, H, KH, D, ca
         p = torch.nan_to_num(torch.softmax(s, dim=-1), nan=0.0)
         out[q0:q1] = torch.einsum("hgml,lhd->mhgd", p, v.double()).reshape(m, H, D)
         bnd[q0:q1] = torch.einsum("hgml,lhd->mhgd", p, v.double().abs()).reshape(m, H, D)
-    return out, bnd
 
 
 def check_attention(tag, out_hip, out_oracle, ref64, bound64):

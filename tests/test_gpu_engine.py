@@ -25,6 +25,7 @@ from oracle import harness_ref as hr
 from oracle import magicdec_ref as mr
 from tests import golden_cfg as gc
 from tests.conftest import parity_report
+from tests.parity_util import capped_threads
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -120,7 +121,8 @@ def replay(log, engines, alt_engines):
         out = getattr(e, rec["fn"])(rec["ids"].to(DEV), **kw).cpu()
         mr.LINEAR_MODE = "fp64"
         try:
-            getattr(a, rec["fn"])(rec["ids"].clone(), **kwa)
+            with capped_threads():          # the float64 yardstick only; the oracle's own run keeps torch's default
+                getattr(a, rec["fn"])(rec["ids"].clone(), **kwa)
         finally:
             mr.LINEAR_MODE = "fp32"
         for k, v in rec["post"].items():
