@@ -25,6 +25,7 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import re
 import runpy
 import subprocess
 import sys
@@ -452,7 +453,8 @@ def run_script(script, argv, classes, vocab, prefix_len, n_seq, tag):
                                                           snapkv_topk=topk_calls)))
     elif topk_calls:     # ... but each rank resolves the top-k ties of ITS kv heads: needed to replay rank r
         (GOLD / f"{tag}_topk_rank{lr}.json").write_text(json.dumps(dict(snapkv_topk=topk_calls)))
-    elif lr == tp_world(tag) - 1:   # a rank outside the draft sub-group: target calls only, tokens by broadcast
+    elif lr == tp_world(tag) - 1 and re.search(r"_tp\d+d\d+$", tag):   # a rank outside the draft sub-group: target
+        # calls only, draft tokens by broadcast
         (GOLD / f"{tag}_trace_rank{lr}.json").write_text(json.dumps(dict(trace=trace, final=final)))
 
 
@@ -518,6 +520,12 @@ def scen_run(tag):
     elif tag == "run_selfspec_stream_tp2":
         run_script("tests/StreamingLLM/selfspec_benchmark.py",
                    ["--model", str(ck["tinytgt"]), "--draft_budget", "129"] + common[:-2] + ["--rank_group", "0", "1"],
+                   [("Engine.StreamingLLM.backend", "LMBackend", ["encode", "draft_encode", "speculate", "verify"])],
+                   vocab, S, 6 * B, tag)
+    elif tag == "run_selfspec_stream_tp3":    # UNEVEN kv-head shards: 4 kv heads over 3 ranks -> 2, 1, 1 (Engine/tp.py:36-52
+        # gives the remainder to the lowest ranks); wqkv / wo slices and the per-rank caches differ in size
+        run_script("tests/StreamingLLM/selfspec_benchmark.py",
+                   ["--model", str(ck["tinykh4"]), "--draft_budget", "129"] + common[:-2] + ["--rank_group", "0", "1", "2"],
                    [("Engine.StreamingLLM.backend", "LMBackend", ["encode", "draft_encode", "speculate", "verify"])],
                    vocab, S, 6 * B, tag)
     elif tag == "run_selfspec_snapkv_tp2":    # BASELINE configs[4]'s layout in miniature: TP self-speculation, SnapKV cache
@@ -652,7 +660,8 @@ SCENARIOS = {"int8_quant": scen_int8_quant, "pg19": scen_pg19, "convert_hf": sce
 RUNS = ["run_longspec_snapkv", "run_longspec_snapkv_rej", "run_longspec_stream", "run_selfspec_snapkv",
         "run_selfspec_stream", "run_baseline", "run_longspec_stream_tp2", "run_longspec_snapkv_tp2",
         "run_selfspec_snapkv_tp2", "run_selfspec_snapkv_qwen", "run_selfspec_snapkv_70b",
-        "run_longspec_stream_70b", "run_selfspec_stream_tp2", "run_longspec_snapkv_tp4d2"]
+        "run_longspec_stream_70b", "run_selfspec_stream_tp2", "run_longspec_snapkv_tp4d2",
+        "run_selfspec_stream_tp3"]
 
 
 def _spawn_tp(scenario, world=2):

@@ -172,13 +172,34 @@ ALL = ["RopeTable", "AttnWorkspace", "update_kv", "rope", "rope_append", "paged_
        "accept_rollback"]
 
 
+def model_linear(self, x2d, lin, swiglu_w13=None):
+    """Stand-in for Transformer._linear (the GEMMs are device ops too).  The product evaluates w1 | w3 as ONE GEMM over
+    the fused operand; the reference as two (Engine/SnapKV/model.py:451-455).  On the GPU that is the same arithmetic per
+    output element, but torch's CPU GEMM is not column-independent for every shape (at M = 256 the [684, 1024] product
+    and the two [342, 1024] products differ in ~10 elements: blocking), which would flip near-tie tokens of the
+    uneven-shard TP=3 trace.  The stand-in therefore splits the fused operand like the reference."""
+    if swiglu_w13 is not None:
+        w, s = swiglu_w13
+        inter = w.shape[0] // 2
+        h1 = mr.linear(x2d, w[:inter], None, s[:inter] if s is not None else None)
+        h3 = mr.linear(x2d, w[inter:], None, s[inter:] if s is not None else None)
+        return silu_mul(h1, h3)
+    return mr.linear(x2d, lin.weight, lin.bias, getattr(lin, "scales", None))
+
+
 def install(monkeypatch=None):
-    """Patch magicdec_amd.ops in place (with pytest's monkeypatch when given, else permanently for a subprocess)."""
+    """Patch magicdec_amd.ops (and the model's GEMM dispatch) in place -- with pytest's monkeypatch when given, else
+    permanently for a subprocess."""
     import sys
     from magicdec_amd import ops
+    from magicdec_amd.Engine import model_core
     me = sys.modules[__name__]
     for name in ALL:
         if monkeypatch is not None:
             monkeypatch.setattr(ops, name, getattr(me, name))
         else:
             setattr(ops, name, getattr(me, name))
+    if monkeypatch is not None:
+        monkeypatch.setattr(model_core.Transformer, "_linear", model_linear)
+    else:
+        model_core.Transformer._linear = model_linear

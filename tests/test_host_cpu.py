@@ -412,7 +412,7 @@ if kind.startswith("run_longspec"):
                                              barrier=dist.barrier)
 elif "snapkv" in kind:
     eng = LMBackend(dtype=torch.bfloat16, device="cpu", dec_len=gc.GAMMA + 1, draft_dec_len=1)
-    eng.load_model(ck / "tinytgt" / "model.pth", use_tp=True, rank_group=[0, 1], group=group)
+    eng.load_model(ck / model / "model.pth", use_tp=True, rank_group=ranks, group=group)
     eng.setup_caches(max_batch_size=gc.B, max_seq_length=gc.MAX_LEN, draft_budget=gc.BUDGET)
     te = Tracer(eng, "SnapKV.LMBackend", log, ("encode", "draft_encode", "speculate", "verify"))
     for b_ids in gc.synthetic_batches():
@@ -420,12 +420,13 @@ elif "snapkv" in kind:
 else:
     from magicdec_amd.Engine.StreamingLLM.backend import LMBackend as StreamSelf
     eng = StreamSelf(dtype=torch.bfloat16, device="cpu", dec_len=gc.GAMMA + 1)
-    eng.load_model(ck / "tinytgt" / "model.pth", use_tp=True, rank_group=[0, 1], group=group)
+    eng.load_model(ck / model / "model.pth", use_tp=True, rank_group=ranks, group=group)
     eng.setup_caches(max_batch_size=gc.B, max_seq_length=gc.MAX_LEN, draft_budget=gc.BUDGET)
     te = Tracer(eng, "StreamingLLM.LMBackend", log, ("encode", "draft_encode", "speculate", "verify"))
     for b_ids in gc.synthetic_batches():
         last, _ = harness.run_selfspec_batch(te, b_ids, gc.GAMMA, gc.MAX_LEN, gc.EOT_1, gc.EOT_2, True)
-json.dump(dict(trace=log, final=dict(output=last.output.tolist(), num_nodes=last.num_nodes.tolist())),
+json.dump(dict(trace=log, final=dict(output=last.output.tolist(), num_nodes=last.num_nodes.tolist()),
+               local_heads=[eng.model.config.n_head, eng.model.config.n_local_heads]),
           open(os.path.join(os.environ["MD_OUT"], f"rank{rank}.json"), "w"))
 dist.barrier()
 dist.destroy_process_group()
@@ -456,6 +457,33 @@ def test_tensor_parallel_snapkv_matches_reference_tp2_trace(kind, ckpt_dir):
         got = json.load(open(os.path.join(out, f"rank{r}.json")))
         _compare(got["trace"], j["trace"])
         assert got["final"] == j["final"]
+
+
+def test_tensor_parallel_uneven_kv_head_shards_match_reference_tp3_trace(ckpt_dir):
+    """KH % tp != 0 (SURVEY 8e "Constraint"): four kv heads over three ranks -> shards of 2, 1, 1 kv heads
+    (Engine/tp.py:36-52), i.e. differently sized wqkv / wo slices and KV caches per rank.  StreamingLLM self-speculation
+    over gloo, world_size 3: every rank's Engine-call trace and final output equal the REAL reference's TP=3 run
+    (oracle/gen_golden.py run_selfspec_stream_tp3) bit for bit."""
+    import json
+    kind = "run_selfspec_stream_tp3"
+    out = tempfile.mkdtemp(prefix="md_tp3_")
+    script = os.path.join(out, "worker.py")
+    Path(script).write_text(TP_SNAPKV_WORKER)
+    port = 29200 + (os.getpid() % 500)
+    procs = []
+    for r in range(3):
+        env = dict(os.environ, LOCAL_RANK=str(r), LOCAL_WORLD_SIZE="3", RANK=str(r), WORLD_SIZE="3",
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), MD_ROOT=str(ROOT), MD_CKPT=str(ckpt_dir), MD_OUT=out,
+                   MD_KIND=kind, MD_DRAFT_RANKS="0,1,2", MD_MODEL="tinykh4", OMP_NUM_THREADS="2")
+        procs.append(subprocess.Popen([sys.executable, script], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    logs = [p.communicate(timeout=1500)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(logs)
+    j = gc.load_json(f"{kind}.json")
+    got = [json.load(open(os.path.join(out, f"rank{r}.json"))) for r in range(3)]
+    assert [g["local_heads"] for g in got] == [[8, 2], [4, 1], [4, 1]]
+    for g in got:
+        _compare(g["trace"], j["trace"])
+        assert g["final"] == j["final"]
 
 
 def test_tensor_parallel_tp4_target_with_tp2_draft_subgroup_matches_reference_trace(ckpt_dir):
