@@ -655,6 +655,93 @@ def scen_int8_quant():
     print({k: (v if not isinstance(v, list) else len(v)) for k, v in out.items()})
 
 
+# ------------------------------------------------------------------------------------ benchmark=True ("run, then undo
+# the length updates", Engine/SnapKV/backend.py:140-143 and twins): no reference script passes it, so the engines are
+# driven directly with a fixed program of calls; tests/test_host_cpu.py runs the same program on the product
+BENCHFLAG_PROGRAMS = {
+    # name: (engines {key: (module, class, ctor kwargs, setup_caches kwargs)}, program [(key, fn, ncols, kwargs)])
+    "benchflag_snapkv_self": (
+        {"T": ("Engine.SnapKV.backend", "LMBackend", dict(dec_len=4, draft_dec_len=1), dict(max_seq_length=512, draft_budget=129))},
+        [("T", "encode", 416, {}), ("T", "speculate", 1, dict(benchmark=True)), ("T", "speculate", 1, {}),
+         ("T", "speculate", 1, dict(benchmark=True)), ("T", "speculate", 1, {}), ("T", "speculate", 1, {}),
+         ("T", "verify", 4, dict(benchmark=True)), ("T", "verify", 4, {}), ("T", "speculate", 1, {}),
+         ("T", "verify", 4, dict(benchmark=True))]),
+    "benchflag_longspec_snapkv": (
+        {"T": ("Engine.SnapKV.backend", "LMBackend", dict(dec_len=4), dict(max_seq_length=512)),
+         "D": ("Engine.SnapKV.backend_draft", "LMBackend_Draft", dict(draft_budget=129), dict(max_seq_length=512, draft_budget=129))},
+        [("T", "encode", 416, {}), ("D", "encode", 416, {}), ("D", "inference", 1, dict(benchmark=True)),
+         ("D", "inference", 1, {}), ("D", "inference", 2, dict(benchmark=True, cachelen_update=[1, 2])),
+         ("D", "inference", 2, dict(cachelen_update=[2, 1])), ("D", "inference", 1, {}),
+         ("T", "inference", 4, dict(benchmark=True)), ("T", "inference", 4, {}), ("T", "inference", 1, dict(benchmark=True)),
+         ("T", "inference", 1, {})]),
+    "benchflag_longspec_stream": (
+        {"D": ("Engine.StreamingLLM.backend_draft", "LMBackend_Draft", dict(), dict(draft_budget=129))},
+        [("D", "encode", 416, {}), ("D", "inference", 1, dict(benchmark=True)), ("D", "inference", 1, {}),
+         ("D", "inference", 2, dict(benchmark=True, cachelen_update=[1, 2])),
+         ("D", "inference", 2, dict(cachelen_update=[2, 1])), ("D", "inference", 1, {})]),
+    "benchflag_stream_self": (
+        {"T": ("Engine.StreamingLLM.backend", "LMBackend", dict(dec_len=4), dict(max_seq_length=512, draft_budget=129))},
+        [("T", "encode", 416, {}), ("T", "draft_encode", 416, {}), ("T", "speculate", 1, dict(benchmark=True)),
+         ("T", "speculate", 1, {}), ("T", "speculate", 2, dict(benchmark=True, cachelen_update=[1, 2])),
+         ("T", "speculate", 2, dict(cachelen_update=[2, 1])), ("T", "speculate", 1, {}),
+         ("T", "verify", 4, dict(benchmark=True)), ("T", "verify", 4, {})]),
+}
+BENCHFLAG_ATTRS = ["cachelens", "paged_kv_last_page_len", "paged_kv_indptr", "draft_cachelens",
+                   "draft_paged_kv_last_page_len", "draft_paged_kv_indptr"]
+
+
+def benchflag_inputs(ncols, call_index, vocab=2048, B=2):
+    """Token ids of call `call_index` of a program (seeded; the same function is used by the product-side test)."""
+    g = torch.Generator().manual_seed(1000 + call_index)
+    ids = torch.randint(4, vocab, (B, ncols), generator=g)
+    if ncols > 8:
+        ids[:, 0] = 1
+    return ids
+
+
+def scen_benchflag(tag):
+    inject_configs()
+    tmp = tempfile.mkdtemp(prefix="magicdec_ckpt_")
+    ck = write_checkpoints(tmp)
+    engines_spec, program = BENCHFLAG_PROGRAMS[tag]
+    engines = {}
+    for key, (mod, cls, ctor, caches) in engines_spec.items():
+        e = getattr(ref_import.module(mod), cls)(dtype=BF16, device="cpu", **ctor)
+        e.load_model(ck["tinytgt"], use_tp=False)
+        e.setup_caches(max_batch_size=2, **caches)
+        engines[key] = e
+    trace = []
+    topk_calls = []          # torch.topk's order among (near-)equal scores is implementation-defined: recorded so that
+    orig_topk = torch.Tensor.topk     # a replay can put the same rows in the same order into the draft cache
+
+    def tk(self, k, dim=-1, **kw):
+        r = orig_topk(self, k, dim=dim, **kw)
+        if self.dim() == 3:
+            topk_calls.append(r.indices.tolist())
+        return r
+    torch.Tensor.topk = tk
+    for i, (key, fn, ncols, kw) in enumerate(program):
+        e = engines[key]
+        ids = benchflag_inputs(ncols, i)
+        kwargs = dict(kw)
+        if "cachelen_update" in kwargs:
+            kwargs["cachelen_update"] = torch.tensor(kwargs["cachelen_update"])
+        r = getattr(e, fn)(ids, **kwargs)
+        rec = dict(key=key, fn=fn, benchmark=bool(kw.get("benchmark", False)),
+                   out=r.tolist() if r.shape[1] <= 8 else r[:, -1:].tolist())
+        for at in BENCHFLAG_ATTRS:
+            if hasattr(e, at) and getattr(e, at) is not None:
+                rec[at] = getattr(e, at).tolist()
+        trace.append(rec)
+    (GOLD / f"{tag}.json").write_text(json.dumps(dict(
+        engines={k: dict(module=m, cls=c, ctor=ct, caches=ca) for k, (m, c, ct, ca) in engines_spec.items()},
+        program=[dict(key=k, fn=f, ncols=n, kwargs=kw) for k, f, n, kw in program],
+        inputs="call i: torch.randint(4, 2048, (2, ncols), generator=manual_seed(1000 + i)); column 0 = 1 if ncols > 8",
+        trace=trace, snapkv_topk=topk_calls)))
+    torch.Tensor.topk = orig_topk
+    print(tag, len(trace), "calls", len(topk_calls), "top-k calls")
+
+
 SCENARIOS = {"int8_quant": scen_int8_quant, "pg19": scen_pg19, "convert_hf": scen_convert_hf, "mylib_schemas": scen_mylib_schemas, "snapkv_select": scen_snapkv_select, "stream_prefill": scen_stream_prefill,
              "accept_loop": scen_accept_loop, "tp_shapes": scen_tp_shapes}
 RUNS = ["run_longspec_snapkv", "run_longspec_snapkv_rej", "run_longspec_stream", "run_selfspec_snapkv",
@@ -684,7 +771,7 @@ def main():
     a = ap.parse_args()
     GOLD.mkdir(parents=True, exist_ok=True)
     if a.scenario is None:
-        for s in list(SCENARIOS) + RUNS:
+        for s in list(SCENARIOS) + list(BENCHFLAG_PROGRAMS) + RUNS:
             print("==", s, flush=True)
             subprocess.run([sys.executable, "-m", "oracle.gen_golden", "--scenario", s], cwd=str(ROOT), check=True)
         return
@@ -693,7 +780,9 @@ def main():
         return
     torch.manual_seed(0)
     with torch.inference_mode():
-        if a.scenario in SCENARIOS:
+        if a.scenario in BENCHFLAG_PROGRAMS:
+            scen_benchflag(a.scenario)
+        elif a.scenario in SCENARIOS:
             SCENARIOS[a.scenario]()
         else:
             scen_run(a.scenario)

@@ -64,3 +64,12 @@ def load_json(name):
 
 def from_bits(a):
     return torch.from_numpy(a.astype(np.int16)).view(torch.bfloat16)
+
+
+def benchflag_inputs(ncols, call_index, vocab=2048, batch=B):
+    """Token ids of call `call_index` of a benchflag_* fixture's program (oracle/gen_golden.py:benchflag_inputs)."""
+    g = torch.Generator().manual_seed(1000 + call_index)
+    ids = torch.randint(4, vocab, (batch, ncols), generator=g)
+    if ncols > 8:
+        ids[:, 0] = 1
+    return ids

@@ -737,3 +737,40 @@ def test_default_kv_layout_env(monkeypatch, cpu_ops_patched, ckpt_dir):
     monkeypatch.setenv("MAGICDEC_KV_LAYOUT", "DNH")
     with pytest.raises(ValueError):
         backend_core.default_kv_layout()
+
+
+@pytest.mark.parametrize("tag", ["benchflag_snapkv_self", "benchflag_longspec_snapkv", "benchflag_longspec_stream",
+                                 "benchflag_stream_self"])
+def test_benchmark_flag_runs_then_undoes_the_length_updates_like_the_reference(tag, cpu_ops_patched, ckpt_dir):
+    """`benchmark=True` of every Engine method ("run, then undo the cache-length / page-table updates",
+    Engine/SnapKV/backend.py:140-143, backend_draft.py:139-142 and the StreamingLLM twins) -- no reference script passes
+    it, so the fixtures were made by driving the REAL reference engines with a fixed program of calls (normal and
+    benchmark calls interleaved, one- and two-token draft steps with cachelen_update); the product's engines run the
+    same program: tokens and every length / page-table vector after each call are identical."""
+    import importlib
+    j = gc.load_json(f"{tag}.json")
+    if j["snapkv_topk"]:      # the reference's resolution of torch.topk ties (row ORDER in the draft cache)
+        cpu_ops.TOPK_REPLAY.update(table=j["snapkv_topk"], pos=0)
+    engines = {}
+    for key, spec in j["engines"].items():
+        cls = getattr(importlib.import_module("magicdec_amd." + spec["module"]), spec["cls"])
+        e = cls(dtype=torch.bfloat16, device="cpu", **spec["ctor"])
+        e.load_model(ckpt_dir / "tinytgt" / "model.pth", use_tp=False)
+        e.setup_caches(max_batch_size=gc.B, **spec["caches"])
+        engines[key] = e
+    attrs = ["cachelens", "paged_kv_last_page_len", "paged_kv_indptr", "draft_cachelens", "draft_paged_kv_last_page_len",
+             "draft_paged_kv_indptr"]
+    n_bench = 0
+    for i, (step, want) in enumerate(zip(j["program"], j["trace"])):
+        e = engines[step["key"]]
+        kw = dict(step["kwargs"])
+        if "cachelen_update" in kw:
+            kw["cachelen_update"] = torch.tensor(kw["cachelen_update"])
+        r = getattr(e, step["fn"])(gc.benchflag_inputs(step["ncols"], i), **kw)
+        got = r.tolist() if r.shape[1] <= 8 else r[:, -1:].tolist()
+        assert got == want["out"], (i, step, got, want["out"])
+        for at in attrs:
+            if at in want:
+                assert getattr(e, at).tolist() == want[at], (i, step, at, getattr(e, at).tolist(), want[at])
+        n_bench += int(want["benchmark"])
+    assert n_bench >= 2
