@@ -470,6 +470,13 @@ def scen_run(tag):
                     "--draft_rank_group", "0"] + common,
                    [("Engine.SnapKV.backend", "LMBackend", ["encode", "inference"]),
                     ("Engine.SnapKV.backend_draft", "LMBackend_Draft", ["encode", "inference"])], vocab, S, 6 * B, tag)
+    elif tag == "run_longspec_snapkv_fullkv":  # --draft_budget -1 (the script's DEFAULT): the draft model decodes over its
+        # full KV cache, no SnapKV select (Engine/SnapKV/backend_draft.py:15: is_compress False); different draft weights
+        run_script("tests/SnapKV/longspec_benchmark.py",
+                   ["--target", str(ck["tinytgt"]), "--model", str(ck["tinydrf"]), "--draft_budget", "-1",
+                    "--draft_rank_group", "0"] + common,
+                   [("Engine.SnapKV.backend", "LMBackend", ["encode", "inference"]),
+                    ("Engine.SnapKV.backend_draft", "LMBackend_Draft", ["encode", "inference"])], vocab, S, 6 * B, tag)
     elif tag == "run_longspec_snapkv_rej":    # different draft model (frequent rejections); gamma=1 because the
         # SnapKV draft table is never rolled back by the harness (it rebinds draft.paged_kv_last_page_len, the
         # compressed path uses draft_paged_kv_last_page_len) and would overflow its spare page at gamma=3
@@ -551,6 +558,19 @@ def scen_run(tag):
                    ["--model", str(ck["tinytgt"]), "--B", str(B), "--prefix_len", str(S), "--max_len", str(ML),
                     "--rank_group", "0"],
                    [("Engine.SnapKV.backend", "LMBackend", ["encode", "inference"])], vocab, S, 6 * B, tag)
+    elif tag == "run_baseline_68m_b1":
+        # BASELINE.json configs[0] ("llama-68m autoregressive baseline_benchmark.py on CPU, B=1 prefix=128"): the reference's
+        # OWN "68m" table entry (Engine/SnapKV/model.py:67: MHA, 12 heads, dim 768, vocab 32000), seeded random weights,
+        # B = 1 (0-d tensors after the script's squeeze()s), prefix_len 129 (a multiple of 128 overflows the page)
+        from oracle.magicdec_ref import RefConfig as RC
+        cfg68 = RC(n_layer=2, n_head=12, n_local_heads=12, dim=768, intermediate_size=3072, vocab_size=32000)
+        d = Path(tmp) / "llama-68m"
+        d.mkdir(parents=True, exist_ok=True)
+        torch.save(init_state_dict(cfg68, 68, wo_scale=0.1), d / "model.pth")
+        run_script("tests/baseline_benchmark.py",
+                   ["--model", str(d / "model.pth"), "--B", "1", "--prefix_len", "129", "--max_len", "256",
+                    "--rank_group", "0"],
+                   [("Engine.SnapKV.backend", "LMBackend", ["encode", "inference"])], 32000, 129, 7, tag)
     else:
         raise SystemExit(f"unknown scenario {tag}")
 
@@ -748,7 +768,8 @@ RUNS = ["run_longspec_snapkv", "run_longspec_snapkv_rej", "run_longspec_stream",
         "run_selfspec_stream", "run_baseline", "run_longspec_stream_tp2", "run_longspec_snapkv_tp2",
         "run_selfspec_snapkv_tp2", "run_selfspec_snapkv_qwen", "run_selfspec_snapkv_70b",
         "run_longspec_stream_70b", "run_selfspec_stream_tp2", "run_longspec_snapkv_tp4d2",
-        "run_selfspec_stream_tp3"]
+        "run_selfspec_stream_tp3", "run_baseline_68m_b1",
+        "run_longspec_snapkv_fullkv"]
 
 
 def _spawn_tp(scenario, world=2):

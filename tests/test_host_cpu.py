@@ -173,7 +173,7 @@ def _compare(trace, ref):
 
 
 @pytest.mark.parametrize("kind,gamma", [("longspec_snapkv", 3), ("longspec_snapkv_rej", 1), ("longspec_stream", 3),
-                                        ("longspec_stream_70b", 3)])
+                                        ("longspec_stream_70b", 3), ("longspec_snapkv_fullkv", 3)])
 def test_product_longspec_host_logic_matches_reference_trace(kind, gamma, cpu_ops_patched, ckpt_dir):
     from magicdec_amd import harness
     from magicdec_amd.Engine.SnapKV.backend import LMBackend
@@ -183,9 +183,11 @@ def test_product_longspec_host_logic_matches_reference_trace(kind, gamma, cpu_op
     eng.setup_caches(max_batch_size=gc.B, max_seq_length=gc.MAX_LEN)
     if "snapkv" in kind:
         from magicdec_amd.Engine.SnapKV.backend_draft import LMBackend_Draft
-        drf = LMBackend_Draft(dtype=torch.bfloat16, device="cpu", draft_budget=gc.BUDGET)
-        drf.load_model(ckpt_dir / ("tinydrf" if kind.endswith("rej") else "tinytgt") / "model.pth", use_tp=False)
-        drf.setup_caches(max_batch_size=gc.B, max_seq_length=gc.MAX_LEN, draft_budget=gc.BUDGET)
+        budget = -1 if kind.endswith("fullkv") else gc.BUDGET      # -1: the draft decodes over its full KV (script default)
+        drf = LMBackend_Draft(dtype=torch.bfloat16, device="cpu", draft_budget=budget)
+        drf.load_model(ckpt_dir / ("tinydrf" if kind.endswith(("rej", "fullkv")) else "tinytgt") / "model.pth",
+                       use_tp=False)
+        drf.setup_caches(max_batch_size=gc.B, max_seq_length=gc.MAX_LEN, draft_budget=budget)
         cpu_ops.TOPK_REPLAY.update(table=j["snapkv_topk"], pos=0)
         dcls = "SnapKV.LMBackend_Draft"
     else:
@@ -774,3 +776,33 @@ def test_benchmark_flag_runs_then_undoes_the_length_updates_like_the_reference(t
                 assert getattr(e, at).tolist() == want[at], (i, step, at, getattr(e, at).tolist(), want[at])
         n_bench += int(want["benchmark"])
     assert n_bench >= 2
+
+
+def test_baseline_configs0_llama68m_batch1_matches_reference_trace(cpu_ops_patched):
+    """BASELINE.json configs[0] (the reference's own CPU-runnable case): baseline_benchmark.py on the reference's "68m"
+    table entry (MHA: 12 heads, dim 768, vocab 32000), B = 1, prefix_len 129, max_len 256, seeded random weights.  The
+    product's autoregressive loop reproduces the REAL reference's trace (oracle/gen_golden.py run_baseline_68m_b1):
+    every encode / inference call's token and cache lengths over 7 sequences, and the final output."""
+    from magicdec_amd import harness
+    from magicdec_amd.Engine.SnapKV.backend import LMBackend
+    from oracle.magicdec_ref import RefConfig, init_state_dict
+    j = gc.load_json("run_baseline_68m_b1.json")
+    cfg = RefConfig(n_layer=2, n_head=12, n_local_heads=12, dim=768, intermediate_size=3072, vocab_size=32000)
+    d = Path(tempfile.mkdtemp(prefix="md_68m_")) / "llama-68m"          # the directory name selects the "68m" entry
+    d.mkdir(parents=True)
+    torch.save(init_state_dict(cfg, 68, wo_scale=0.1), d / "model.pth")
+    eng = LMBackend(dtype=torch.bfloat16, device="cpu")
+    eng.load_model(d / "model.pth", use_tp=False)
+    c = eng.model.config
+    assert (c.n_head, c.n_local_heads, c.dim, c.vocab_size, c.head_dim) == (12, 12, 768, 32000, 64)
+    eng.setup_caches(max_batch_size=1, max_seq_length=256)
+    g = torch.Generator().manual_seed(123)
+    ids = torch.randint(4, 32000, (7, 129), generator=g)
+    ids[:, 0] = 1
+    log = []
+    te = Tracer(eng, "SnapKV.LMBackend", log, ("encode", "inference"))
+    out = None
+    for b in range(7):
+        out, _, _ = harness.run_baseline_batch(te, ids[b:b + 1], 256, gc.EOT_1, gc.EOT_2)
+    _compare(log, j["trace"])
+    assert out.tolist() == j["final"]["output"]
