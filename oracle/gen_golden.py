@@ -477,6 +477,24 @@ def scen_run(tag):
                     "--draft_rank_group", "0"] + common,
                    [("Engine.SnapKV.backend", "LMBackend", ["encode", "inference"]),
                     ("Engine.SnapKV.backend_draft", "LMBackend_Draft", ["encode", "inference"])], vocab, S, 6 * B, tag)
+    elif tag in ("run_longspec_snapkv_b1", "run_selfspec_stream_b1"):
+        # B = 1, the scripts' default batch size: the loop bodies' squeeze()s yield 0-d tensors there
+        # (tests/SnapKV/longspec_benchmark.py:273-279); 8 sequences so that two timed batches remain after the warm-up
+        common_b1 = ["--B", "1"] + common[2:]
+        if tag == "run_longspec_snapkv_b1":
+            # gamma = 1: at gamma = 3 the reference's never-rolled-back SnapKV draft table overflows its spare page in the
+            # sixth sequence (see run_longspec_snapkv_rej); accept_nums still reaches gamma + 1 (the two-token draft step)
+            common_b1 = [c if c != str(G) else "1" for c in common_b1]
+            run_script("tests/SnapKV/longspec_benchmark.py",
+                       ["--target", str(ck["tinytgt"]), "--model", str(ck["tinytgt"]), "--draft_budget", "129",
+                        "--draft_rank_group", "0"] + common_b1,
+                       [("Engine.SnapKV.backend", "LMBackend", ["encode", "inference"]),
+                        ("Engine.SnapKV.backend_draft", "LMBackend_Draft", ["encode", "inference"])], vocab, S, 8, tag)
+        else:
+            run_script("tests/StreamingLLM/selfspec_benchmark.py",
+                       ["--model", str(ck["tinytgt"]), "--draft_budget", "129"] + common_b1,
+                       [("Engine.StreamingLLM.backend", "LMBackend", ["encode", "draft_encode", "speculate", "verify"])],
+                       vocab, S, 8, tag)
     elif tag == "run_longspec_snapkv_rej":    # different draft model (frequent rejections); gamma=1 because the
         # SnapKV draft table is never rolled back by the harness (it rebinds draft.paged_kv_last_page_len, the
         # compressed path uses draft_paged_kv_last_page_len) and would overflow its spare page at gamma=3
@@ -769,7 +787,7 @@ RUNS = ["run_longspec_snapkv", "run_longspec_snapkv_rej", "run_longspec_stream",
         "run_selfspec_snapkv_tp2", "run_selfspec_snapkv_qwen", "run_selfspec_snapkv_70b",
         "run_longspec_stream_70b", "run_selfspec_stream_tp2", "run_longspec_snapkv_tp4d2",
         "run_selfspec_stream_tp3", "run_baseline_68m_b1",
-        "run_longspec_snapkv_fullkv"]
+        "run_longspec_snapkv_fullkv", "run_longspec_snapkv_b1", "run_selfspec_stream_b1"]
 
 
 def _spawn_tp(scenario, world=2):

@@ -806,3 +806,44 @@ def test_baseline_configs0_llama68m_batch1_matches_reference_trace(cpu_ops_patch
         out, _, _ = harness.run_baseline_batch(te, ids[b:b + 1], 256, gc.EOT_1, gc.EOT_2)
     _compare(log, j["trace"])
     assert out.tolist() == j["final"]["output"]
+
+
+@pytest.mark.parametrize("kind", ["longspec_snapkv_b1", "selfspec_stream_b1"])
+def test_batch_size_one_matches_reference_trace(kind, cpu_ops_patched, ckpt_dir):
+    """B = 1, the default batch size of the reference's scripts (their loop bodies' squeeze()s yield 0-d tensors there,
+    tests/SnapKV/longspec_benchmark.py:273-279): longspec with a SnapKV draft (gamma = 1: accept_nums in {1, 2}, two-token
+    draft steps) and StreamingLLM self-speculation (gamma = 3) over 8 sequences equal the REAL reference's traces."""
+    from magicdec_amd import harness
+    j = gc.load_json(f"run_{kind}.json")
+    gamma = int(j["argv"][j["argv"].index("--gamma") + 1])
+    g = torch.Generator().manual_seed(123)
+    ids = torch.randint(4, 2048, (8, gc.S), generator=g)
+    ids[:, 0] = 1
+    log = []
+    last = None
+    if kind.startswith("longspec"):
+        from magicdec_amd.Engine.SnapKV.backend import LMBackend
+        from magicdec_amd.Engine.SnapKV.backend_draft import LMBackend_Draft
+        eng = LMBackend(dtype=torch.bfloat16, device="cpu", dec_len=gamma + 1)
+        eng.load_model(ckpt_dir / "tinytgt" / "model.pth", use_tp=False)
+        eng.setup_caches(max_batch_size=1, max_seq_length=gc.MAX_LEN)
+        drf = LMBackend_Draft(dtype=torch.bfloat16, device="cpu", draft_budget=gc.BUDGET)
+        drf.load_model(ckpt_dir / "tinytgt" / "model.pth", use_tp=False)
+        drf.setup_caches(max_batch_size=1, max_seq_length=gc.MAX_LEN, draft_budget=gc.BUDGET)
+        cpu_ops.TOPK_REPLAY.update(table=j["snapkv_topk"], pos=0)
+        te = Tracer(eng, "SnapKV.LMBackend", log, ("encode", "inference"))
+        td = Tracer(drf, "SnapKV.LMBackend_Draft", log, ("encode", "inference"))
+        for b in range(8):
+            last, _ = harness.run_longspec_batch(te, td, ids[b:b + 1], gamma, gc.MAX_LEN, gc.EOT_1, gc.EOT_2)
+    else:
+        from magicdec_amd.Engine.StreamingLLM.backend import LMBackend
+        eng = LMBackend(dtype=torch.bfloat16, device="cpu", dec_len=gamma + 1)
+        eng.load_model(ckpt_dir / "tinytgt" / "model.pth", use_tp=False)
+        eng.setup_caches(max_batch_size=1, max_seq_length=gc.MAX_LEN, draft_budget=gc.BUDGET)
+        te = Tracer(eng, "StreamingLLM.LMBackend", log, ("encode", "draft_encode", "speculate", "verify"))
+        for b in range(8):
+            last, _ = harness.run_selfspec_batch(te, ids[b:b + 1], gamma, gc.MAX_LEN, gc.EOT_1, gc.EOT_2, True)
+    _compare(log, j["trace"])
+    assert last.output.tolist() == j["final"]["output"]
+    assert last.num_nodes.tolist() == j["final"]["num_nodes"]
+    assert sum(1 for r in j["trace"] if "cachelen_update" in r) > 50
