@@ -205,6 +205,51 @@ def scen_stream_prefill():
     np.savez_compressed(GOLD / "stream_prefill.npz", **out)
 
 
+def scen_stream_prefill_b513():
+    """The same KVCache.prefill at BASELINE configs[3]'s draft budget (513 -> 5 pages per request, two kv heads): the
+    eviction shifts rows across several pages.  Cache snapshots of this size do not belong in the repository: the
+    fixture holds the per-chunk bookkeeping and SHA-256 digests of the cache / rotated-cache bytes; the inputs are
+    regenerated from the seed (torch.Generator(7), one randn per chunk for k, one for v)."""
+    import hashlib
+    ref_import.module("Engine.utils")
+    M = ref_import.module("Engine.StreamingLLM.model_draft")
+    fr = sys.modules["flashinfer"]
+    B, KH, D, budget = 2, 2, 64, 513
+    ppr = budget // 128 + 1
+    table = fr.rope_table(2048, D, 10000.0, 1.0)
+
+    def rope(q, k, indptr, offsets):
+        return fr.apply_rope(q, k, indptr, offsets, table)
+    kvc = M.KVCache(B * ppr, 128, KH, D, BF16, budget)
+    g = torch.Generator().manual_seed(7)
+    sha = lambda t: hashlib.sha256(t.contiguous().view(torch.int16).numpy().tobytes()).hexdigest()
+    steps = []
+    ctx, npr = 0, 0
+    S = 128 * 9 + 37
+    for st in range(0, S, 128):
+        n = min(128, S - st)
+        is_last = n != 128
+        k = torch.randn(B * n, KH, D, generator=g).to(BF16)
+        v = torch.randn(B * n, KH, D, generator=g).to(BF16)
+        if ctx + n <= budget:       # StreamingLLM/backend_draft.py:155-160
+            npr += 1
+            last = n
+        else:
+            npr = ppr
+            last = budget % 128
+        indices = torch.cat([torch.arange(i * ppr, i * ppr + npr, dtype=torch.int32) for i in range(B)])
+        indptr = (torch.arange(B + 1) * npr).to(torch.int32)
+        lastt = torch.full((B,), last, dtype=torch.int32)
+        append_indptr = (torch.arange(B + 1) * n).to(torch.int32)
+        rot = kvc.prefill(k, v, append_indptr, indices, indptr, lastt, B, torch.tensor(ctx), n, KH, D, rope, is_last)
+        steps.append(dict(ctx=ctx, n=n, is_last=int(is_last), npr=npr, last=last, cache_sha256=sha(kvc.kv_cache),
+                          rot_sha256=sha(rot)))
+        ctx = min(ctx + n, budget)
+    (GOLD / "stream_prefill_b513.json").write_text(json.dumps(dict(
+        meta=dict(B=B, KH=KH, D=D, budget=budget, ppr=ppr, rope_positions=2048, seed=7), steps=steps)))
+    print("stream_prefill_b513", len(steps), "chunks")
+
+
 # ------------------------------------------------------------------------------------ accept_loop
 def _loop_body_source(script, first_marker, last_marker):
     """The verify-loop body text, read from the reference at generation time (never stored in the repo)."""
@@ -780,7 +825,7 @@ def scen_benchflag(tag):
     print(tag, len(trace), "calls", len(topk_calls), "top-k calls")
 
 
-SCENARIOS = {"int8_quant": scen_int8_quant, "pg19": scen_pg19, "convert_hf": scen_convert_hf, "mylib_schemas": scen_mylib_schemas, "snapkv_select": scen_snapkv_select, "stream_prefill": scen_stream_prefill,
+SCENARIOS = {"int8_quant": scen_int8_quant, "pg19": scen_pg19, "convert_hf": scen_convert_hf, "mylib_schemas": scen_mylib_schemas, "snapkv_select": scen_snapkv_select, "stream_prefill": scen_stream_prefill, "stream_prefill_b513": scen_stream_prefill_b513,
              "accept_loop": scen_accept_loop, "tp_shapes": scen_tp_shapes}
 RUNS = ["run_longspec_snapkv", "run_longspec_snapkv_rej", "run_longspec_stream", "run_selfspec_snapkv",
         "run_selfspec_stream", "run_baseline", "run_longspec_stream_tp2", "run_longspec_snapkv_tp2",

@@ -413,6 +413,41 @@ def test_streaming_shift_and_rotate_match_reference_cache_bytes(ops, golden_dir)
         assert torch.equal(bits(dst.cpu()), bits(gc.from_bits(z[f"rot{step}"]))), f"rot step {step}"
 
 
+def test_streaming_shift_and_rotate_at_budget_513_match_reference_digests(ops):
+    """The same at BASELINE configs[3]'s draft budget (513 rows = 5 pages per request, two kv heads): the eviction moves
+    rows across page boundaries.  Expected values: SHA-256 digests of the REAL reference's cache / rotated cache after
+    every chunk (tests/golden/stream_prefill_b513.json; inputs regenerated from its seed)."""
+    import hashlib
+    j = gc.load_json("stream_prefill_b513.json")
+    m = j["meta"]
+    B, KH, D, budget, ppr = m["B"], m["KH"], m["D"], m["budget"], m["ppr"]
+    tab = ops.RopeTable(m["rope_positions"], D, 10000.0, 1.0, device=DEV)
+    sha = lambda t: hashlib.sha256(t.cpu().contiguous().view(torch.int16).numpy().tobytes()).hexdigest()
+    g = torch.Generator().manual_seed(m["seed"])
+    cache = torch.zeros(B * ppr, 2, 128, KH, D, dtype=BF, device=DEV)
+    rot = torch.empty_like(cache)
+    for i, st in enumerate(j["steps"]):
+        ctx, n, is_last, npr, last = st["ctx"], st["n"], st["is_last"], st["npr"], st["last"]
+        k = torch.randn(B * n, KH, D, generator=g).to(BF).to(DEV)
+        v = torch.randn(B * n, KH, D, generator=g).to(BF).to(DEV)
+        if ctx + n <= budget:
+            indices = torch.cat([torch.arange(r * ppr, r * ppr + npr, dtype=torch.int32) for r in range(B)]).to(DEV)
+            indptr = (torch.arange(B + 1) * npr).to(torch.int32).to(DEV)
+            ops.update_kv(k, v, (torch.arange(B + 1) * n).to(torch.int32).to(DEV), cache, indices, indptr,
+                          torch.full((B,), last, dtype=torch.int32, device=DEV))
+            valid = ctx + n
+        else:
+            ops.streaming_shift_append(k, v, cache, n, budget, 16, ppr)
+            valid = budget
+        overflow_last = (ctx + n > budget) and bool(is_last)
+        dst = cache if overflow_last else rot
+        if not overflow_last:
+            rot.copy_(cache)
+        ops.streaming_rotate(cache, dst, B, valid, ppr, tab)
+        assert sha(cache) == st["cache_sha256"], f"cache after chunk {i}"
+        assert sha(dst) == st["rot_sha256"], f"rotated cache after chunk {i}"
+
+
 # ----------------------------------------------------------------------------------------- SnapKV select
 def _snapkv_alt_oracle(q, k, v, g, W, budget):
     """The oracle with correctly rounded (float64-accumulated) QK^T scores: a second valid implementation of the

@@ -210,3 +210,32 @@ def test_baseline_matches_reference_script():
         last = hr.baseline_batch(eng, ids, gc.MAX_LEN, gc.EOT_1, gc.EOT_2, trace)
     _check_trace(trace, j["trace"], rename)
     assert last["output"].tolist() == j["final"]["output"]
+
+
+def test_streaming_prefill_cache_bytes_budget_513():
+    """KVCache.prefill at configs[3]'s draft budget (513 = 5 pages per request, two kv heads; eviction across several
+    pages): after every chunk the oracle's cache and rotated cache hash to the REAL reference's digests
+    (oracle/gen_golden.py stream_prefill_b513; inputs regenerated from the fixture's seed)."""
+    import hashlib
+    j = gc.load_json("stream_prefill_b513.json")
+    m = j["meta"]
+    B, KH, D, budget, ppr = m["B"], m["KH"], m["D"], m["budget"], m["ppr"]
+    table = fr.rope_table(m["rope_positions"], D, 10000.0, 1.0)
+
+    def rope(q, k, indptr, offsets):
+        return fr.apply_rope(q, k, indptr, offsets, table)
+    sha = lambda t: hashlib.sha256(t.contiguous().view(torch.int16).numpy().tobytes()).hexdigest()
+    g = torch.Generator().manual_seed(m["seed"])
+    cache = torch.zeros(B * ppr, 2, 128, KH, D, dtype=torch.bfloat16)
+    evicted = 0
+    for i, st in enumerate(j["steps"]):
+        n, npr = st["n"], st["npr"]
+        k = torch.randn(B * n, KH, D, generator=g).to(torch.bfloat16)
+        v = torch.randn(B * n, KH, D, generator=g).to(torch.bfloat16)
+        tab = dict(indices=torch.cat([torch.arange(b * ppr, b * ppr + npr, dtype=torch.int32) for b in range(B)]),
+                   indptr=(torch.arange(B + 1) * npr).to(torch.int32), last=torch.full((B,), st["last"], dtype=torch.int32))
+        rot = mr.streaming_prefill_kv(cache, k, v, B, st["ctx"], n, budget, tab, rope, bool(st["is_last"]))
+        assert sha(cache) == st["cache_sha256"], i
+        assert sha(rot) == st["rot_sha256"], i
+        evicted += int(st["ctx"] + n > budget)
+    assert evicted >= 4 and j["steps"][-1]["is_last"] == 1
