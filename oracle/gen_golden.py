@@ -393,6 +393,36 @@ def scen_tp_shapes():
     (GOLD / "tp_shapes.json").write_text(json.dumps(res))
 
 
+def scen_tp_shapes_kh4():
+    """apply_tp (Engine/tp.py:184-207) of the four-kv-head model over 2, 3 (uneven: 2 | 1 | 1 kv heads; torch.chunk of
+    1024 ffn rows -> 342 | 342 | 340, of 2048 vocab rows -> 683 | 683 | 682) and 4 ranks: per-rank tensor shapes and sums."""
+    tp = ref_import.module("Engine.tp")
+    M = ref_import.module("Engine.SnapKV.model")
+    inject_configs()
+    cfg, seed, wo_scale = ref_cfg("tinykh4")
+    sd = init_state_dict(cfg, seed, wo_scale=wo_scale)
+    import torch.distributed as dist
+    res = {"shard": []}
+    for world in (2, 3, 4):
+        for r in range(world):
+            os.environ["LOCAL_RANK"] = str(r)
+            model = M.Transformer.from_name("tinykh4")
+            model.load_state_dict(sd, assign=True)
+            orig_ws, orig_rk = dist.get_world_size, dist.get_rank
+            dist.get_world_size = lambda g=None: world
+            dist.get_rank = lambda g=None: r
+            try:
+                tp.apply_tp(model, list(range(world)), group="G")
+            finally:
+                dist.get_world_size, dist.get_rank = orig_ws, orig_rk
+            shapes = {k: list(v.shape) for k, v in model.state_dict().items()}
+            sums = {k: float(v.float().sum()) for k, v in model.state_dict().items()}
+            res["shard"].append(dict(world=world, rank=r, shapes=shapes, sums=sums,
+                                     cfg=[model.config.n_head, model.config.n_local_heads, model.config.dim]))
+    (GOLD / "tp_shapes_kh4.json").write_text(json.dumps(res))
+    print("tp_shapes_kh4", len(res["shard"]), "shards")
+
+
 # ------------------------------------------------------------------------------------ run_* (whole scripts)
 class StubTokenizer:
     eos_token = "</s>"
@@ -826,7 +856,7 @@ def scen_benchflag(tag):
 
 
 SCENARIOS = {"int8_quant": scen_int8_quant, "pg19": scen_pg19, "convert_hf": scen_convert_hf, "mylib_schemas": scen_mylib_schemas, "snapkv_select": scen_snapkv_select, "stream_prefill": scen_stream_prefill, "stream_prefill_b513": scen_stream_prefill_b513,
-             "accept_loop": scen_accept_loop, "tp_shapes": scen_tp_shapes}
+             "accept_loop": scen_accept_loop, "tp_shapes": scen_tp_shapes, "tp_shapes_kh4": scen_tp_shapes_kh4}
 RUNS = ["run_longspec_snapkv", "run_longspec_snapkv_rej", "run_longspec_stream", "run_selfspec_snapkv",
         "run_selfspec_stream", "run_baseline", "run_longspec_stream_tp2", "run_longspec_snapkv_tp2",
         "run_selfspec_snapkv_tp2", "run_selfspec_snapkv_qwen", "run_selfspec_snapkv_70b",

@@ -847,3 +847,29 @@ def test_batch_size_one_matches_reference_trace(kind, cpu_ops_patched, ckpt_dir)
     assert last.output.tolist() == j["final"]["output"]
     assert last.num_nodes.tolist() == j["final"]["num_nodes"]
     assert sum(1 for r in j["trace"] if "cachelen_update" in r) > 50
+
+
+def test_product_apply_tp_shards_equal_the_reference(monkeypatch, ckpt_dir):
+    """magicdec_amd.Engine.tp.apply_tp against the reference's (tests/golden/tp_shapes_kh4.json: four kv heads over 2,
+    3 -- uneven -- and 4 ranks): every parameter of every rank has the reference's shape and sum, the config is
+    rewritten to the same local head counts / dim."""
+    import torch.distributed as dist
+    from magicdec_amd.Engine import model_core, tp
+    j = gc.load_json("tp_shapes_kh4.json")
+    gc.register_tiny(model_core)
+    _, sd = gc.tiny("tinykh4")
+    for rec in j["shard"]:
+        world, r = rec["world"], rec["rank"]
+        monkeypatch.setenv("LOCAL_RANK", str(r))
+        monkeypatch.setenv("RANK", str(r))
+        monkeypatch.setattr(dist, "get_world_size", lambda g=None, w=world: w)
+        monkeypatch.setattr(dist, "get_rank", lambda g=None, rr=r: rr)
+        model = model_core.Transformer.from_name("tinykh4")
+        model.load_state_dict(sd, assign=True)
+        tp.apply_tp(model, list(range(world)), group="G")
+        c = model.config
+        assert [c.n_head, c.n_local_heads, c.dim] == rec["cfg"], (world, r)
+        got = model.state_dict()
+        for name, shape in rec["shapes"].items():
+            assert list(got[name].shape) == shape, (world, r, name, list(got[name].shape), shape)
+            assert abs(float(got[name].float().sum()) - rec["sums"][name]) <= 1e-3 * (1 + abs(rec["sums"][name])), name

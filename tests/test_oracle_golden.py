@@ -239,3 +239,17 @@ def test_streaming_prefill_cache_bytes_budget_513():
         assert sha(rot) == st["rot_sha256"], i
         evicted += int(st["ctx"] + n > budget)
     assert evicted >= 4 and j["steps"][-1]["is_last"] == 1
+
+
+def test_tp_shards_four_kv_heads_over_2_3_4_ranks():
+    """Per-rank shapes and sums of the reference's apply_tp on the four-kv-head model, incl. the uneven three-rank split
+    (2 | 1 | 1 kv heads, 342 | 342 | 340 ffn rows, 683 | 683 | 682 vocab rows): the oracle's shard_state_dict agrees."""
+    j = gc.load_json("tp_shapes_kh4.json")
+    cfg, sd = gc.tiny("tinykh4")
+    assert {(r["world"], r["rank"]) for r in j["shard"]} == {(w, r) for w in (2, 3, 4) for r in range(w)}
+    for rec in j["shard"]:
+        ssd, local = mr.shard_state_dict(sd, cfg, rec["rank"], rec["world"])
+        assert [local.n_head, local.n_local_heads, local.dim] == rec["cfg"]
+        for name, shape in rec["shapes"].items():
+            assert list(ssd[name].shape) == shape, (rec["world"], rec["rank"], name)
+            assert abs(float(ssd[name].float().sum()) - rec["sums"][name]) <= 1e-3 * (1 + abs(rec["sums"][name])), name
