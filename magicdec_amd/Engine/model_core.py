@@ -74,8 +74,8 @@ class ModelArgs:
         if name in transformer_configs:
             return cls(**transformer_configs[name])
         hits = [c for c in transformer_configs if c.lower() in str(name).lower()]
-        if not hits:
-            raise KeyError(f"no transformer config matches '{name}'")
+        if not hits:       # the reference indexes an empty list here (IndexError); same exception type, with a message
+            raise IndexError(f"no transformer config matches '{name}' (known: {', '.join(transformer_configs)})")
         hits.sort(key=len, reverse=True)
         if len(hits) > 1:
             assert len(hits[0]) != len(hits[1]), name

@@ -393,6 +393,41 @@ def scen_tp_shapes():
     (GOLD / "tp_shapes.json").write_text(json.dumps(res))
 
 
+MODEL_PATH_NAMES = ["Meta-Llama-3.1-8B", "Meta-Llama-3.1-8B-Instruct", "Meta-Llama-3.1-70B", "Llama-3.2-1B",
+                    "Llama-3.2-3B", "Qwen2.5-7B", "Qwen2.5-14B", "Qwen2.5-32B", "llama-68m", "JackFram/llama-68m",
+                    "Llama-2-7b-hf", "Llama-2-7B-32K", "Llama-2-13b-hf", "Llama-2-70b-hf", "Mistral-7B-v0.1",
+                    "Yarn-Llama-2-7b-128k", "TinyLlama-1.1B", "llama-160m", "Meta-Llama-3-8B", "Meta-Llama-3-70B"]
+
+
+def scen_model_configs():
+    """The model zoo at the config level: every entry of the reference's transformer_configs (the four model modules
+    hold the same table) resolved through ModelArgs (derived intermediate_size / head_dim / n_local_heads), and the
+    fuzzy lookup ModelArgs.from_name (Engine/SnapKV/model.py:46-58) for the checkpoint directory names users pass."""
+    mods = [ref_import.module(m) for m in ("Engine.SnapKV.model", "Engine.SnapKV.model_draft",
+                                           "Engine.StreamingLLM.model", "Engine.StreamingLLM.model_draft")]
+    assert all(m.transformer_configs == mods[0].transformer_configs for m in mods)
+    M = mods[0]
+    fields = ["block_size", "vocab_size", "n_layer", "n_head", "dim", "intermediate_size", "n_local_heads", "head_dim",
+              "rope_base", "norm_eps", "scaling_factor", "low_freq_factor", "high_freq_factor",
+              "original_max_position_embeddings", "qkv_bias"]
+    res = {"table": {}, "lookup": {}}
+    for name in M.transformer_configs:
+        a = M.ModelArgs.from_name(name)
+        res["table"][name] = {f: getattr(a, f, None) for f in fields}
+    import contextlib
+    import io
+    for path in MODEL_PATH_NAMES:
+        try:
+            with contextlib.redirect_stdout(io.StringIO()):
+                a = M.ModelArgs.from_name(path)
+            res["lookup"][path] = {f: getattr(a, f, None) for f in fields}
+        except Exception as e:  # noqa: BLE001 -- an ambiguous / unknown name: the product must fail the same way
+            res["lookup"][path] = {"error": type(e).__name__}
+    (GOLD / "model_configs.json").write_text(json.dumps(res))
+    print("model_configs", len(res["table"]), "entries,", len(res["lookup"]), "lookups,",
+          sum(1 for v in res["lookup"].values() if "error" in v), "errors")
+
+
 def scen_tp_shapes_kh4():
     """apply_tp (Engine/tp.py:184-207) of the four-kv-head model over 2, 3 (uneven: 2 | 1 | 1 kv heads; torch.chunk of
     1024 ffn rows -> 342 | 342 | 340, of 2048 vocab rows -> 683 | 683 | 682) and 4 ranks: per-rank tensor shapes and sums."""
@@ -856,7 +891,8 @@ def scen_benchflag(tag):
 
 
 SCENARIOS = {"int8_quant": scen_int8_quant, "pg19": scen_pg19, "convert_hf": scen_convert_hf, "mylib_schemas": scen_mylib_schemas, "snapkv_select": scen_snapkv_select, "stream_prefill": scen_stream_prefill, "stream_prefill_b513": scen_stream_prefill_b513,
-             "accept_loop": scen_accept_loop, "tp_shapes": scen_tp_shapes, "tp_shapes_kh4": scen_tp_shapes_kh4}
+             "accept_loop": scen_accept_loop, "tp_shapes": scen_tp_shapes, "tp_shapes_kh4": scen_tp_shapes_kh4,
+             "model_configs": scen_model_configs}
 RUNS = ["run_longspec_snapkv", "run_longspec_snapkv_rej", "run_longspec_stream", "run_selfspec_snapkv",
         "run_selfspec_stream", "run_baseline", "run_longspec_stream_tp2", "run_longspec_snapkv_tp2",
         "run_selfspec_snapkv_tp2", "run_selfspec_snapkv_qwen", "run_selfspec_snapkv_70b",

@@ -873,3 +873,29 @@ def test_product_apply_tp_shards_equal_the_reference(monkeypatch, ckpt_dir):
         for name, shape in rec["shapes"].items():
             assert list(got[name].shape) == shape, (world, r, name, list(got[name].shape), shape)
             assert abs(float(got[name].float().sum()) - rec["sums"][name]) <= 1e-3 * (1 + abs(rec["sums"][name])), name
+
+
+def test_model_zoo_config_table_and_name_lookup_equal_the_reference(capsys):
+    """Every entry of the reference's transformer_configs resolved through ModelArgs (derived intermediate_size, head_dim,
+    n_local_heads, RoPE scaling fields, qkv_bias), and ModelArgs.from_name's fuzzy lookup of 20 checkpoint directory
+    names (incl. the two that match no entry and must fail the same way): tests/golden/model_configs.json, recorded
+    from the reference's four model modules (which hold one identical table)."""
+    from magicdec_amd.Engine.model_core import ModelArgs, transformer_configs
+    j = gc.load_json("model_configs.json")
+    assert set(transformer_configs) == set(j["table"])
+    for name, want in j["table"].items():
+        a = ModelArgs.from_name(name)
+        got = {f: getattr(a, f, None) for f in want}
+        assert got == want, (name, {f: (got[f], want[f]) for f in want if got[f] != want[f]})
+    n_err = 0
+    for path, want in j["lookup"].items():
+        if "error" in want:
+            with pytest.raises(Exception) as ei:
+                ModelArgs.from_name(path)
+            assert type(ei.value).__name__ == want["error"], (path, type(ei.value).__name__, want["error"])
+            n_err += 1
+            continue
+        a = ModelArgs.from_name(path)
+        got = {f: getattr(a, f, None) for f in want}
+        assert got == want, (path, {f: (got[f], want[f]) for f in want if got[f] != want[f]})
+    assert n_err == 2 and len(j["lookup"]) == 20
