@@ -46,6 +46,13 @@ def _eot(tokenizer):
     return eot_1, eot_2
 
 
+def _avg_len(num_gen_tokens, target_steps, batch_size):
+    """"avg generate len per sentence" exactly as the reference prints it: its token counter is a 0-d int64 tensor, so
+    the two divisions happen in float32 (tests/SnapKV/longspec_benchmark.py:307 prints 2.6111111640930176, not
+    2.611111111111111)."""
+    return (torch.tensor(num_gen_tokens) / target_steps / batch_size).item()
+
+
 def _device():
     return 'cuda' if torch.cuda.is_available() else 'cpu'
 
@@ -142,12 +149,16 @@ def longspec_main(kind: str, argv=None):
             for i in range(BATCH_SIZE):
                 print_("Sequence ", i)
                 print_(tokenizer.decode(st.output[i, args.prefix_len:st.num_nodes[i]]))
-        print_("total time :{:.5f}s, time per iter :{:.5f}s, decoding step: {}, large model step: {}, avg latency: {}".format(
-            total_time, total_time / target_steps, num_gen_tokens, target_steps, total_time / num_gen_tokens * BATCH_SIZE))
+        if kind == "SnapKV":   # only tests/SnapKV/longspec_benchmark.py:305 prints the latency; the StreamingLLM twin (:302) not
+            print_("total time :{:.5f}s, time per iter :{:.5f}s, decoding step: {}, large model step: {}, avg latency: {}".format(
+                total_time, total_time / target_steps, num_gen_tokens, target_steps, total_time / num_gen_tokens * BATCH_SIZE))
+        else:
+            print_("total time :{:.5f}s, time per iter :{:.5f}s, decoding step: {}, large model step: {}".format(
+                total_time, total_time / target_steps, num_gen_tokens, target_steps))
         if args.benchmark:     # tests/SnapKV/longspec_benchmark.py:305-307
             print_("target time :{:.5f}s, draft time :{:.5f}s, verify loop : {}, avg generate len per sentence: {}".format(
                 timers.target / target_steps, timers.draft / target_steps, timers.verify_loop / target_steps,
-                num_gen_tokens / target_steps / BATCH_SIZE))
+                _avg_len(num_gen_tokens, target_steps, BATCH_SIZE)))
         if step < 5:
             total_time, num_gen_tokens, target_steps = 0.0, 0, 0
             if timers is not None:
@@ -224,7 +235,7 @@ def selfspec_main(kind: str, argv=None):
         if args.benchmark:     # tests/SnapKV/selfspec_benchmark.py (same line as the longspec script)
             print_("target time :{:.5f}s, draft time :{:.5f}s, verify loop : {}, avg generate len per sentence: {}".format(
                 timers.target / target_steps, timers.draft / target_steps, timers.verify_loop / target_steps,
-                num_gen_tokens / target_steps / BATCH_SIZE))
+                _avg_len(num_gen_tokens, target_steps, BATCH_SIZE)))
         if step < 5:
             total_time, num_gen_tokens, target_steps = 0.0, 0, 0
             if timers is not None:

@@ -545,11 +545,12 @@ def run_script(script, argv, classes, vocab, prefix_len, n_seq, tag):
     torch.Tensor.topk = tk
     old = sys.argv
     sys.argv = [script] + argv
-    outputs = []
-    # capture per-batch final `output`/`num_nodes`: the scripts print after each batch; hook print
-    import builtins
+    import contextlib
+    import io
+    captured = io.StringIO()
     try:
-        g = runpy.run_path(str(Path(ref_import.REFERENCE_ROOT) / script), run_name="__main__")
+        with (contextlib.redirect_stdout(captured) if tag.startswith("cli_") else contextlib.nullcontext()):
+            g = runpy.run_path(str(Path(ref_import.REFERENCE_ROOT) / script), run_name="__main__")
     finally:
         sys.argv = old
         torch.Tensor.topk = orig_topk
@@ -557,6 +558,13 @@ def run_script(script, argv, classes, vocab, prefix_len, n_seq, tag):
     for key in ("output", "num_nodes"):
         if key in g and torch.is_tensor(g[key]):
             final[key] = g[key].tolist()
+    if tag.startswith("cli_"):       # what a user SEES: the scripts' printed lines with the wall-clock numbers masked
+        (GOLD / f"{tag}.json").write_text(json.dumps(dict(
+            script=script, args=[a for a in argv if "magicdec_ckpt_" not in a], models=[Path(a).parent.name for a in argv
+                                                                                     if "magicdec_ckpt_" in a],
+            stdout=cli_lines(captured.getvalue()), snapkv_topk=topk_calls)))
+        print(tag, len(cli_lines(captured.getvalue())), "lines")
+        return
     lr = int(os.environ.get("LOCAL_RANK", "0"))
     if lr == 0:          # TP runs: the replicated state is identical on every rank
         (GOLD / f"{tag}.json").write_text(json.dumps(dict(argv=argv, trace=trace, final=final,
@@ -566,6 +574,25 @@ def run_script(script, argv, classes, vocab, prefix_len, n_seq, tag):
     elif lr == tp_world(tag) - 1 and re.search(r"_tp\d+d\d+$", tag):   # a rank outside the draft sub-group: target
         # calls only, draft tokens by broadcast
         (GOLD / f"{tag}_trace_rank{lr}.json").write_text(json.dumps(dict(trace=trace, final=final)))
+
+
+CLI_KEEP = ("Using device", "eot_1", "Sequence", "total time", "target time", "Final tokens per second",
+            "Tokens per second")
+
+
+def cli_lines(text):
+    """The lines of a benchmark script's stdout that are its user-visible report (device, EOT ids, decoded sequences,
+    per-batch and final summaries) with the wall-clock dependent numbers replaced by <t>; counts and the
+    tokens-per-sentence average stay.  tests/test_host_cpu.py applies the same function to the product's output."""
+    out = []
+    for ln in text.splitlines():
+        ln = ln.rstrip()
+        if not (ln.startswith(CLI_KEEP) or re.fullmatch(r"[0-9 ]+", ln)):
+            continue
+        ln = re.sub(r"(total time :|time per iter :|target time :|draft time :)[0-9.eE+-]+s", r"\1<t>s", ln)
+        ln = re.sub(r"(avg latency: |verify loop : |Final tokens per second :|Tokens per second :)[0-9.eE+-]+", r"\1<t>", ln)
+        out.append(ln)
+    return out
 
 
 def scen_run(tag):
@@ -605,6 +632,22 @@ def scen_run(tag):
                        ["--model", str(ck["tinytgt"]), "--draft_budget", "129"] + common_b1,
                        [("Engine.StreamingLLM.backend", "LMBackend", ["encode", "draft_encode", "speculate", "verify"])],
                        vocab, S, 8, tag)
+    elif tag.startswith("cli_"):
+        # the five entry points as a user runs them: --printoutput (decoded sequences) and, where the script has it,
+        # --benchmark (per-phase line); 14 sequences = 7 batches of 2 (the first 5/6 are the scripts' warm-up)
+        model_args = {"cli_longspec_snapkv": ("tests/SnapKV/longspec_benchmark.py", True, "Engine.SnapKV.backend_draft"),
+                      "cli_longspec_stream": ("tests/StreamingLLM/longspec_benchmark.py", True, "Engine.StreamingLLM.backend_draft"),
+                      "cli_selfspec_snapkv": ("tests/SnapKV/selfspec_benchmark.py", False, None),
+                      "cli_selfspec_stream": ("tests/StreamingLLM/selfspec_benchmark.py", False, None),
+                      "cli_baseline": ("tests/baseline_benchmark.py", False, None)}[tag]
+        script, two_models, _ = model_args
+        argv = (["--target", str(ck["tinytgt"])] if two_models else []) + ["--model", str(ck["tinytgt"])]
+        if tag == "cli_baseline":
+            argv += ["--B", str(B), "--prefix_len", str(S), "--max_len", str(ML), "--rank_group", "0", "--printoutput"]
+        else:
+            argv += ["--draft_budget", "129"] + (["--draft_rank_group", "0"] if two_models else []) + common + \
+                    ["--printoutput", "--benchmark"]
+        run_script(script, argv, [], vocab, S, 7 * B, tag)
     elif tag == "run_longspec_snapkv_rej":    # different draft model (frequent rejections); gamma=1 because the
         # SnapKV draft table is never rolled back by the harness (it rebinds draft.paged_kv_last_page_len, the
         # compressed path uses draft_paged_kv_last_page_len) and would overflow its spare page at gamma=3
@@ -898,7 +941,8 @@ RUNS = ["run_longspec_snapkv", "run_longspec_snapkv_rej", "run_longspec_stream",
         "run_selfspec_snapkv_tp2", "run_selfspec_snapkv_qwen", "run_selfspec_snapkv_70b",
         "run_longspec_stream_70b", "run_selfspec_stream_tp2", "run_longspec_snapkv_tp4d2",
         "run_selfspec_stream_tp3", "run_baseline_68m_b1",
-        "run_longspec_snapkv_fullkv", "run_longspec_snapkv_b1", "run_selfspec_stream_b1"]
+        "run_longspec_snapkv_fullkv", "run_longspec_snapkv_b1", "run_selfspec_stream_b1", "cli_longspec_snapkv",
+        "cli_longspec_stream", "cli_selfspec_snapkv", "cli_selfspec_stream", "cli_baseline"]
 
 
 def _spawn_tp(scenario, world=2):
