@@ -648,6 +648,20 @@ def scen_run(tag):
             argv += ["--draft_budget", "129"] + (["--draft_rank_group", "0"] if two_models else []) + common + \
                     ["--printoutput", "--benchmark"]
         run_script(script, argv, [], vocab, S, 7 * B, tag)
+    elif tag == "run_longspec_snapkv_b257":   # the headline draft budget (257 rows = 3 draft pages per request)
+        run_script("tests/SnapKV/longspec_benchmark.py",
+                   ["--target", str(ck["tinytgt"]), "--model", str(ck["tinytgt"]), "--draft_budget", "257",
+                    "--draft_rank_group", "0"] + common,
+                   [("Engine.SnapKV.backend", "LMBackend", ["encode", "inference"]),
+                    ("Engine.SnapKV.backend_draft", "LMBackend_Draft", ["encode", "inference"])], vocab, S, 6 * B, tag)
+    elif tag == "run_longspec_stream_noevict":  # prompt shorter than the StreamingLLM budget (513 > 416 + 96): the draft
+        # cache never evicts, neither in prefill nor in decode
+        run_script("tests/StreamingLLM/longspec_benchmark.py",
+                   ["--target", str(ck["tinytgt"]), "--model", str(ck["tinytgt"]), "--draft_budget", "513",
+                    "--draft_rank_group", "0"] + common,
+                   [("Engine.SnapKV.backend", "LMBackend", ["encode", "inference"]),
+                    ("Engine.StreamingLLM.backend_draft", "LMBackend_Draft", ["encode", "inference"])], vocab, S, 6 * B,
+                   tag)
     elif tag == "run_longspec_snapkv_rej":    # different draft model (frequent rejections); gamma=1 because the
         # SnapKV draft table is never rolled back by the harness (it rebinds draft.paged_kv_last_page_len, the
         # compressed path uses draft_paged_kv_last_page_len) and would overflow its spare page at gamma=3
@@ -941,7 +955,8 @@ RUNS = ["run_longspec_snapkv", "run_longspec_snapkv_rej", "run_longspec_stream",
         "run_selfspec_snapkv_tp2", "run_selfspec_snapkv_qwen", "run_selfspec_snapkv_70b",
         "run_longspec_stream_70b", "run_selfspec_stream_tp2", "run_longspec_snapkv_tp4d2",
         "run_selfspec_stream_tp3", "run_baseline_68m_b1",
-        "run_longspec_snapkv_fullkv", "run_longspec_snapkv_b1", "run_selfspec_stream_b1", "cli_longspec_snapkv",
+        "run_longspec_snapkv_fullkv", "run_longspec_snapkv_b1", "run_selfspec_stream_b1", "run_longspec_snapkv_b257",
+        "run_longspec_stream_noevict", "cli_longspec_snapkv",
         "cli_longspec_stream", "cli_selfspec_snapkv", "cli_selfspec_stream", "cli_baseline"]
 
 

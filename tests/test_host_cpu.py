@@ -173,7 +173,8 @@ def _compare(trace, ref):
 
 
 @pytest.mark.parametrize("kind,gamma", [("longspec_snapkv", 3), ("longspec_snapkv_rej", 1), ("longspec_stream", 3),
-                                        ("longspec_stream_70b", 3), ("longspec_snapkv_fullkv", 3)])
+                                        ("longspec_stream_70b", 3), ("longspec_snapkv_fullkv", 3),
+                                        ("longspec_snapkv_b257", 3), ("longspec_stream_noevict", 3)])
 def test_product_longspec_host_logic_matches_reference_trace(kind, gamma, cpu_ops_patched, ckpt_dir):
     from magicdec_amd import harness
     from magicdec_amd.Engine.SnapKV.backend import LMBackend
@@ -183,7 +184,8 @@ def test_product_longspec_host_logic_matches_reference_trace(kind, gamma, cpu_op
     eng.setup_caches(max_batch_size=gc.B, max_seq_length=gc.MAX_LEN)
     if "snapkv" in kind:
         from magicdec_amd.Engine.SnapKV.backend_draft import LMBackend_Draft
-        budget = -1 if kind.endswith("fullkv") else gc.BUDGET      # -1: the draft decodes over its full KV (script default)
+        budget = int(j["argv"][j["argv"].index("--draft_budget") + 1])    # 129, 257 (3 draft pages) or -1 = the draft
+        # decodes over its full KV (the script default)
         drf = LMBackend_Draft(dtype=torch.bfloat16, device="cpu", draft_budget=budget)
         drf.load_model(ckpt_dir / ("tinydrf" if kind.endswith(("rej", "fullkv")) else "tinytgt") / "model.pth",
                        use_tp=False)
@@ -194,7 +196,8 @@ def test_product_longspec_host_logic_matches_reference_trace(kind, gamma, cpu_op
         from magicdec_amd.Engine.StreamingLLM.backend_draft import LMBackend_Draft
         drf = LMBackend_Draft(dtype=torch.bfloat16, device="cpu")
         drf.load_model(ckpt_dir / ("tinydrf" if kind.endswith("70b") else "tinytgt") / "model.pth", use_tp=False)
-        drf.setup_caches(max_batch_size=gc.B, draft_budget=gc.BUDGET)
+        # 129, or 513 > prefix + generated tokens: the StreamingLLM cache never evicts
+        drf.setup_caches(max_batch_size=gc.B, draft_budget=int(j["argv"][j["argv"].index("--draft_budget") + 1]))
         dcls = "StreamingLLM.LMBackend_Draft"
     log = []
     te = Tracer(eng, "SnapKV.LMBackend", log, ("encode", "inference"))
