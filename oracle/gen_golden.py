@@ -662,6 +662,27 @@ def scen_run(tag):
                    [("Engine.SnapKV.backend", "LMBackend", ["encode", "inference"]),
                     ("Engine.StreamingLLM.backend_draft", "LMBackend_Draft", ["encode", "inference"])], vocab, S, 6 * B,
                    tag)
+    elif tag in ("run_longspec_snapkv_eot", "run_selfspec_stream_eot", "run_baseline_eot"):
+        # EOT-driven termination: the tokenizer's eos / unk ids are set to tokens these models actually emit (866 and
+        # 1410 sit in a loop of the first sequence), so batches end on an accepted EOT draft token, on an EOT bonus
+        # token, or -- baseline -- on an EOT step (tests/SnapKV/longspec_benchmark.py:212-226,262-264)
+        StubTokenizer.eos_token_id, StubTokenizer.unk_token_id = 866, 1410
+        if tag == "run_longspec_snapkv_eot":
+            run_script("tests/SnapKV/longspec_benchmark.py",
+                       ["--target", str(ck["tinytgt"]), "--model", str(ck["tinytgt"]), "--draft_budget", "129",
+                        "--draft_rank_group", "0"] + common,
+                       [("Engine.SnapKV.backend", "LMBackend", ["encode", "inference"]),
+                        ("Engine.SnapKV.backend_draft", "LMBackend_Draft", ["encode", "inference"])], vocab, S, 6 * B, tag)
+        elif tag == "run_selfspec_stream_eot":
+            run_script("tests/StreamingLLM/selfspec_benchmark.py",
+                       ["--model", str(ck["tinytgt"]), "--draft_budget", "129"] + common,
+                       [("Engine.StreamingLLM.backend", "LMBackend", ["encode", "draft_encode", "speculate", "verify"])],
+                       vocab, S, 6 * B, tag)
+        else:
+            run_script("tests/baseline_benchmark.py",
+                       ["--model", str(ck["tinytgt"]), "--B", str(B), "--prefix_len", str(S), "--max_len", str(ML),
+                        "--rank_group", "0"],
+                       [("Engine.SnapKV.backend", "LMBackend", ["encode", "inference"])], vocab, S, 6 * B, tag)
     elif tag == "run_longspec_snapkv_rej":    # different draft model (frequent rejections); gamma=1 because the
         # SnapKV draft table is never rolled back by the harness (it rebinds draft.paged_kv_last_page_len, the
         # compressed path uses draft_paged_kv_last_page_len) and would overflow its spare page at gamma=3
@@ -956,7 +977,8 @@ RUNS = ["run_longspec_snapkv", "run_longspec_snapkv_rej", "run_longspec_stream",
         "run_longspec_stream_70b", "run_selfspec_stream_tp2", "run_longspec_snapkv_tp4d2",
         "run_selfspec_stream_tp3", "run_baseline_68m_b1",
         "run_longspec_snapkv_fullkv", "run_longspec_snapkv_b1", "run_selfspec_stream_b1", "run_longspec_snapkv_b257",
-        "run_longspec_stream_noevict", "cli_longspec_snapkv",
+        "run_longspec_stream_noevict", "run_longspec_snapkv_eot", "run_selfspec_stream_eot",
+        "run_baseline_eot", "cli_longspec_snapkv",
         "cli_longspec_stream", "cli_selfspec_snapkv", "cli_selfspec_stream", "cli_baseline"]
 
 

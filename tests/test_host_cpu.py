@@ -959,3 +959,56 @@ def test_entry_points_print_the_reference_scripts_report(tag, cpu_ops_patched, c
     assert len(got) == len(j["stdout"]), (len(got), len(j["stdout"]), got[-3:], j["stdout"][-3:])
     for i, (a, b) in enumerate(zip(got, j["stdout"])):
         assert a == b, (i, a, b)
+
+
+@pytest.mark.parametrize("kind", ["longspec_snapkv_eot", "selfspec_stream_eot", "baseline_eot"])
+def test_eot_driven_termination_matches_reference_trace(kind, cpu_ops_patched, ckpt_dir):
+    """Termination by end-of-text tokens (tests/SnapKV/longspec_benchmark.py:212-226,262-264; baseline_benchmark.py:88):
+    the reference scripts were run with a tokenizer whose eos / unk ids (866, 1410) are tokens the tiny model emits, so
+    batches end on an accepted EOT draft token, an EOT bonus token or an EOT baseline step; the product's loops, given
+    the same ids, reproduce every Engine call and the final output."""
+    from magicdec_amd import harness
+    j = gc.load_json(f"run_{kind}.json")
+    e1, e2 = 866, 1410
+    log = []
+    if kind.startswith("longspec"):
+        from magicdec_amd.Engine.SnapKV.backend import LMBackend
+        from magicdec_amd.Engine.SnapKV.backend_draft import LMBackend_Draft
+        eng = LMBackend(dtype=torch.bfloat16, device="cpu", dec_len=gc.GAMMA + 1)
+        eng.load_model(ckpt_dir / "tinytgt" / "model.pth", use_tp=False)
+        eng.setup_caches(max_batch_size=gc.B, max_seq_length=gc.MAX_LEN)
+        drf = LMBackend_Draft(dtype=torch.bfloat16, device="cpu", draft_budget=gc.BUDGET)
+        drf.load_model(ckpt_dir / "tinytgt" / "model.pth", use_tp=False)
+        drf.setup_caches(max_batch_size=gc.B, max_seq_length=gc.MAX_LEN, draft_budget=gc.BUDGET)
+        cpu_ops.TOPK_REPLAY.update(table=j["snapkv_topk"], pos=0)
+        te = Tracer(eng, "SnapKV.LMBackend", log, ("encode", "inference"))
+        td = Tracer(drf, "SnapKV.LMBackend_Draft", log, ("encode", "inference"))
+        last = None
+        for ids in gc.synthetic_batches():
+            last, _ = harness.run_longspec_batch(te, td, ids, gc.GAMMA, gc.MAX_LEN, e1, e2)
+        final = dict(output=last.output.tolist(), num_nodes=last.num_nodes.tolist())
+    elif kind.startswith("selfspec"):
+        from magicdec_amd.Engine.StreamingLLM.backend import LMBackend
+        eng = LMBackend(dtype=torch.bfloat16, device="cpu", dec_len=gc.GAMMA + 1)
+        eng.load_model(ckpt_dir / "tinytgt" / "model.pth", use_tp=False)
+        eng.setup_caches(max_batch_size=gc.B, max_seq_length=gc.MAX_LEN, draft_budget=gc.BUDGET)
+        te = Tracer(eng, "StreamingLLM.LMBackend", log, ("encode", "draft_encode", "speculate", "verify"))
+        last = None
+        for ids in gc.synthetic_batches():
+            last, _ = harness.run_selfspec_batch(te, ids, gc.GAMMA, gc.MAX_LEN, e1, e2, True)
+        final = dict(output=last.output.tolist(), num_nodes=last.num_nodes.tolist())
+    else:
+        from magicdec_amd.Engine.SnapKV.backend import LMBackend
+        eng = LMBackend(dtype=torch.bfloat16, device="cpu")
+        eng.load_model(ckpt_dir / "tinytgt" / "model.pth", use_tp=False)
+        eng.setup_caches(max_batch_size=gc.B, max_seq_length=gc.MAX_LEN)
+        te = Tracer(eng, "SnapKV.LMBackend", log, ("encode", "inference"))
+        out = None
+        for ids in gc.synthetic_batches():
+            out, _, _ = harness.run_baseline_batch(te, ids, gc.MAX_LEN, e1, e2)
+        final = dict(output=out.tolist())
+    _compare(log, j["trace"])
+    for k, v in j["final"].items():
+        assert final[k] == v, k
+    # the EOT ids really ended batches early: fewer Engine calls than the same run with the default ids
+    assert len(j["trace"]) < len(gc.load_json(f"run_{kind[:-4]}.json")["trace"])
