@@ -1012,3 +1012,66 @@ def test_eot_driven_termination_matches_reference_trace(kind, cpu_ops_patched, c
         assert final[k] == v, k
     # the EOT ids really ended batches early: fewer Engine calls than the same run with the default ids
     assert len(j["trace"]) < len(gc.load_json(f"run_{kind[:-4]}.json")["trace"])
+
+
+TP_QWEN_WORKER = r'''
+import os, sys, json, torch
+sys.path.insert(0, os.environ["MD_ROOT"])
+import torch.distributed as dist
+from pathlib import Path
+from tests import cpu_ops, golden_cfg as gc
+from oracle import magicdec_ref as mr, harness_ref as hr
+cpu_ops.install()
+from magicdec_amd import harness
+from magicdec_amd.Engine import model_core
+from magicdec_amd.Engine.tp import init_dist
+from magicdec_amd.Engine.SnapKV.backend import LMBackend
+ck = Path(os.environ["MD_CKPT"])
+gc.register_tiny(model_core)
+rank, group = init_dist()
+world = dist.get_world_size()
+eng = LMBackend(dtype=torch.bfloat16, device="cpu", dec_len=gc.GAMMA + 1, draft_dec_len=1)
+eng.load_model(ck / "tinyqwen" / "model.pth", use_tp=True, rank_group=list(range(world)), group=group)
+eng.setup_caches(max_batch_size=gc.B, max_seq_length=gc.MAX_LEN, draft_budget=gc.BUDGET)
+bias = eng.model.layers[0].attention.wqkv.bias
+cfg, sd = gc.tiny("tinyqwen")
+ssd, lcfg = mr.shard_state_dict(sd, cfg, rank, world)
+ora = mr.RefEngine("snapkv_self", lcfg, ssd, gc.B, gc.MAX_LEN, gc.BUDGET, group=group, rank=rank, world=world)
+res = dict(rank=rank, bias_shape=list(bias.shape), bias_equal=bool(torch.equal(bias, ssd["layers.0.attention.wqkv.bias"])),
+           batches=[])
+for ids in gc.synthetic_batches()[:2]:
+    st, _ = harness.run_selfspec_batch(eng, ids, gc.GAMMA, gc.MAX_LEN, gc.EOT_1, gc.EOT_2, False)
+    ref = hr.selfspec_batch(ora, ids, gc.GAMMA, gc.MAX_LEN, gc.EOT_1, gc.EOT_2, False)
+    res["batches"].append(dict(output=st.output.tolist(), num_nodes=st.num_nodes.tolist(),
+                               oracle_output=ref["output"].tolist(), oracle_num_nodes=ref["num_nodes"].tolist()))
+json.dump(res, open(os.path.join(os.environ["MD_OUT"], f"rank{rank}.json"), "w"))
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+def test_tensor_parallel_qkv_bias_model_shards_the_bias(ckpt_dir):
+    """BASELINE configs[4] is a qkv-bias model (Qwen2.5-32B) at TP = 8 -- which the reference cannot run: Engine/tp.py
+    slices wqkv.weight (and int8 scales) by kv-head range but leaves wqkv.bias whole, so F.linear raises
+    ("The expanded size of the tensor (448) must match the existing size (896)": reproduced with the tiny Qwen-like
+    model at TP = 2).  The product slices the bias with the weight's head ranges; with no reference run to compare
+    with, the yardstick is the oracle sharded the same way over the same gloo all-reduce: identical tokens on both ranks."""
+    import json
+    out = tempfile.mkdtemp(prefix="md_tpq_")
+    script = os.path.join(out, "worker.py")
+    Path(script).write_text(TP_QWEN_WORKER)
+    port = 29100 + (os.getpid() % 500)
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, LOCAL_RANK=str(r), LOCAL_WORLD_SIZE="2", RANK=str(r), WORLD_SIZE="2",
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), MD_ROOT=str(ROOT), MD_CKPT=str(ckpt_dir), MD_OUT=out,
+                   OMP_NUM_THREADS="2")
+        procs.append(subprocess.Popen([sys.executable, script], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    logs = [p.communicate(timeout=1500)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(logs)
+    got = [json.load(open(os.path.join(out, f"rank{r}.json"))) for r in range(2)]
+    for g in got:
+        assert g["bias_shape"] == [(5 + 2) * 64] and g["bias_equal"]          # one kv head per rank: 5 q heads + k + v
+        for b in g["batches"]:
+            assert b["output"] == b["oracle_output"] and b["num_nodes"] == b["oracle_num_nodes"]
+    assert got[0]["batches"] == got[1]["batches"]
