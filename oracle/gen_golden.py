@@ -683,6 +683,20 @@ def scen_run(tag):
                        ["--model", str(ck["tinytgt"]), "--B", str(B), "--prefix_len", str(S), "--max_len", str(ML),
                         "--rank_group", "0"],
                        [("Engine.SnapKV.backend", "LMBackend", ["encode", "inference"])], vocab, S, 6 * B, tag)
+    elif tag == "run_baseline_int8":
+        # weight-only int8 end to end: the reference's own quantiser (Engine/quantize.py:50-70) makes model_int8.pth from
+        # the tiny checkpoint, the reference's loader (Engine/utils.py:201-205: "int8" in the path) swaps the linears,
+        # baseline_benchmark.py decodes with it
+        Q = ref_import.module("Engine.quantize")
+        M = ref_import.module("Engine.SnapKV.model")
+        inject_configs()
+        m = M.Transformer.from_name("tinytgt")
+        m.load_state_dict(torch.load(str(ck["tinytgt"]), weights_only=True), assign=True)
+        q8 = Path(tmp) / "tinytgt" / "model_int8.pth"
+        torch.save(Q.WeightOnlyInt8QuantHandler(m).create_quantized_state_dict(), q8)
+        run_script("tests/baseline_benchmark.py",
+                   ["--model", str(q8), "--B", str(B), "--prefix_len", str(S), "--max_len", str(ML), "--rank_group", "0"],
+                   [("Engine.SnapKV.backend", "LMBackend", ["encode", "inference"])], vocab, S, 6 * B, tag)
     elif tag == "run_longspec_snapkv_rej":    # different draft model (frequent rejections); gamma=1 because the
         # SnapKV draft table is never rolled back by the harness (it rebinds draft.paged_kv_last_page_len, the
         # compressed path uses draft_paged_kv_last_page_len) and would overflow its spare page at gamma=3
@@ -978,7 +992,7 @@ RUNS = ["run_longspec_snapkv", "run_longspec_snapkv_rej", "run_longspec_stream",
         "run_selfspec_stream_tp3", "run_baseline_68m_b1",
         "run_longspec_snapkv_fullkv", "run_longspec_snapkv_b1", "run_selfspec_stream_b1", "run_longspec_snapkv_b257",
         "run_longspec_stream_noevict", "run_longspec_snapkv_eot", "run_selfspec_stream_eot",
-        "run_baseline_eot", "cli_longspec_snapkv",
+        "run_baseline_eot", "run_baseline_int8", "cli_longspec_snapkv",
         "cli_longspec_stream", "cli_selfspec_snapkv", "cli_selfspec_stream", "cli_baseline"]
 
 

@@ -1075,3 +1075,33 @@ def test_tensor_parallel_qkv_bias_model_shards_the_bias(ckpt_dir):
         for b in g["batches"]:
             assert b["output"] == b["oracle_output"] and b["num_nodes"] == b["oracle_num_nodes"]
     assert got[0]["batches"] == got[1]["batches"]
+
+
+def test_int8_weight_only_end_to_end_matches_reference_trace(cpu_ops_patched, ckpt_dir):
+    """Weight-only int8 end to end: quantise the tiny checkpoint (Engine/quantize.py), load `model_int8.pth` through the
+    loader's "int8 in the path" switch (Engine/utils.py:201-205), decode with the baseline loop -- every Engine call's
+    tokens equal the REAL reference doing the same with its own quantiser and loader (run_baseline_int8)."""
+    from magicdec_amd import harness
+    from magicdec_amd.Engine import model_core, quantize as Q
+    from magicdec_amd.Engine.SnapKV.backend import LMBackend
+    j = gc.load_json("run_baseline_int8.json")
+    _, sd = gc.tiny("tinytgt")
+    m = model_core.Transformer.from_name("tinytgt")
+    m.load_state_dict(sd, assign=True)
+    d = Path(tempfile.mkdtemp(prefix="md_int8_")) / "tinytgt"
+    d.mkdir(parents=True)
+    torch.save(Q.WeightOnlyInt8QuantHandler(m).create_quantized_state_dict(), d / "model_int8.pth")
+    eng = LMBackend(dtype=torch.bfloat16, device="cpu")
+    eng.load_model(d / "model_int8.pth", use_tp=False)
+    assert isinstance(eng.model.layers[0].attention.wqkv, Q.WeightOnlyInt8Linear)
+    assert eng.model.layers[0].feed_forward.w2.weight.dtype == torch.int8
+    eng.setup_caches(max_batch_size=gc.B, max_seq_length=gc.MAX_LEN)
+    log = []
+    te = Tracer(eng, "SnapKV.LMBackend", log, ("encode", "inference"))
+    out = None
+    for ids in gc.synthetic_batches():
+        out, _, _ = harness.run_baseline_batch(te, ids, gc.MAX_LEN, gc.EOT_1, gc.EOT_2)
+    _compare(log, j["trace"])
+    assert out.tolist() == j["final"]["output"]
+    # and it is not the bf16 model's trace
+    assert [r["out"] for r in j["trace"]] != [r["out"] for r in gc.load_json("run_baseline.json")["trace"]]
