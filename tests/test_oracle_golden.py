@@ -154,14 +154,30 @@ def _engines(kind):
         cfg_d, sd_d = gc.tiny("tinydrf")
         return (mr.RefEngine("target", cfg_7, sd_7, gc.B, gc.MAX_LEN),
                 mr.RefEngine("stream_draft", cfg_d, sd_d, gc.B, 0, gc.BUDGET))
+    if kind == "longspec_snapkv_fullkv":       # --draft_budget -1: a different draft model decoding over its full KV
+        cfg_d, sd_d = gc.tiny("tinydrf")
+        return (mr.RefEngine("target", cfg_t, sd_t, gc.B, gc.MAX_LEN),
+                mr.RefEngine("snapkv_draft", cfg_d, sd_d, gc.B, gc.MAX_LEN, -1))
+    if kind == "longspec_snapkv_b257":         # the headline budget: 3 draft pages per request
+        return (mr.RefEngine("target", cfg_t, sd_t, gc.B, gc.MAX_LEN),
+                mr.RefEngine("snapkv_draft", cfg_t, sd_t, gc.B, gc.MAX_LEN, 257))
+    if kind == "longspec_stream_noevict":      # budget 513 > prompt + generated tokens: never evicts
+        return (mr.RefEngine("target", cfg_t, sd_t, gc.B, gc.MAX_LEN),
+                mr.RefEngine("stream_draft", cfg_t, sd_t, gc.B, 0, 513))
+    if kind == "longspec_snapkv_eot":
+        return (mr.RefEngine("target", cfg_t, sd_t, gc.B, gc.MAX_LEN),
+                mr.RefEngine("snapkv_draft", cfg_t, sd_t, gc.B, gc.MAX_LEN, gc.BUDGET))
     raise KeyError(kind)
 
 
 @pytest.mark.parametrize("kind,gamma", [("longspec_snapkv", 3), ("longspec_snapkv_rej", 1), ("longspec_stream", 3),
-                                        ("longspec_stream_70b", 3)])
+                                        ("longspec_stream_70b", 3), ("longspec_snapkv_fullkv", 3),
+                                        ("longspec_snapkv_b257", 3), ("longspec_stream_noevict", 3),
+                                        ("longspec_snapkv_eot", 3)])
 def test_longspec_matches_reference_script(kind, gamma):
     j = gc.load_json(f"run_{kind}.json")
     eng, drf = _engines(kind)
+    eot_1, eot_2 = (866, 1410) if kind.endswith("_eot") else (gc.EOT_1, gc.EOT_2)    # _eot: ids the model emits
     rename = {"SnapKV.LMBackend.encode": "T.encode", "SnapKV.LMBackend.inference": "T.inference",
               "SnapKV.LMBackend_Draft.encode": "D.encode", "SnapKV.LMBackend_Draft.inference": "D.inference",
               "StreamingLLM.LMBackend_Draft.encode": "D.encode", "StreamingLLM.LMBackend_Draft.inference": "D.inference"}
@@ -172,19 +188,21 @@ def test_longspec_matches_reference_script(kind, gamma):
     trace = []
     last = None
     for ids in gc.synthetic_batches():
-        last = hr.longspec_batch(eng, drf, ids, gamma, gc.MAX_LEN, gc.EOT_1, gc.EOT_2, trace)
+        last = hr.longspec_batch(eng, drf, ids, gamma, gc.MAX_LEN, eot_1, eot_2, trace)
     _check_trace(trace, j["trace"], rename)
     assert last["output"].tolist() == j["final"]["output"]
     assert last["num_nodes"].tolist() == j["final"]["num_nodes"]
 
 
-@pytest.mark.parametrize("kind", ["selfspec_snapkv", "selfspec_stream", "selfspec_snapkv_qwen", "selfspec_snapkv_70b"])
+@pytest.mark.parametrize("kind", ["selfspec_snapkv", "selfspec_stream", "selfspec_snapkv_qwen", "selfspec_snapkv_70b",
+                                  "selfspec_stream_eot"])
 def test_selfspec_matches_reference_script(kind):
     """_qwen / _70b: the reference run on a Qwen2.5-like (qkv bias, g=5, eps 1e-6) and a Llama-70B-like (g=8, D=128)
     tiny model -- pins the oracle's bias handling and the g != 4 SnapKV paths at the engine level."""
     j = gc.load_json(f"run_{kind}.json")
     cfg, sd = gc.tiny("tinyqwen" if kind.endswith("qwen") else "tiny70b" if kind.endswith("70b") else "tinytgt")
-    streaming = kind == "selfspec_stream"
+    streaming = kind.startswith("selfspec_stream")
+    eot_1, eot_2 = (866, 1410) if kind.endswith("_eot") else (gc.EOT_1, gc.EOT_2)
     eng = mr.RefEngine("stream_self" if streaming else "snapkv_self", cfg, sd, gc.B, gc.MAX_LEN, gc.BUDGET)
     mod = "StreamingLLM" if streaming else "SnapKV"
     rename = {f"{mod}.LMBackend.{f}": f"T.{f}" for f in ("encode", "draft_encode", "speculate", "verify")}
@@ -193,23 +211,66 @@ def test_selfspec_matches_reference_script(kind):
     trace = []
     last = None
     for ids in gc.synthetic_batches():
-        last = hr.selfspec_batch(eng, ids, gc.GAMMA, gc.MAX_LEN, gc.EOT_1, gc.EOT_2, streaming, trace)
+        last = hr.selfspec_batch(eng, ids, gc.GAMMA, gc.MAX_LEN, eot_1, eot_2, streaming, trace)
     _check_trace(trace, j["trace"], rename)
     assert last["output"].tolist() == j["final"]["output"]
     assert last["num_nodes"].tolist() == j["final"]["num_nodes"]
 
 
-def test_baseline_matches_reference_script():
-    j = gc.load_json("run_baseline.json")
-    cfg, sd = gc.tiny("tinytgt")
-    eng = mr.RefEngine("target", cfg, sd, gc.B, gc.MAX_LEN)
+@pytest.mark.parametrize("kind", ["baseline", "baseline_eot", "baseline_68m_b1"])
+def test_baseline_matches_reference_script(kind):
+    """baseline_68m_b1 = BASELINE.json configs[0]: the reference's "68m" entry (MHA), B = 1, prefix 129, max_len 256."""
+    j = gc.load_json(f"run_{kind}.json")
+    eot_1, eot_2 = (866, 1410) if kind.endswith("_eot") else (gc.EOT_1, gc.EOT_2)
+    if kind == "baseline_68m_b1":
+        from oracle.magicdec_ref import RefConfig, init_state_dict
+        cfg = RefConfig(n_layer=2, n_head=12, n_local_heads=12, dim=768, intermediate_size=3072, vocab_size=32000)
+        sd = init_state_dict(cfg, 68, wo_scale=0.1)
+        B, max_len = 1, 256
+        g = torch.Generator().manual_seed(123)
+        ids_all = torch.randint(4, 32000, (7, 129), generator=g)
+        ids_all[:, 0] = 1
+        batches = [ids_all[i:i + 1] for i in range(7)]
+    else:
+        cfg, sd = gc.tiny("tinytgt")
+        B, max_len, batches = gc.B, gc.MAX_LEN, gc.synthetic_batches()
+    eng = mr.RefEngine("target", cfg, sd, B, max_len)
     rename = {"SnapKV.LMBackend.encode": "T.encode", "SnapKV.LMBackend.inference": "T.inference"}
     trace = []
     last = None
-    for ids in gc.synthetic_batches():
-        last = hr.baseline_batch(eng, ids, gc.MAX_LEN, gc.EOT_1, gc.EOT_2, trace)
+    for ids in batches:
+        last = hr.baseline_batch(eng, ids, max_len, eot_1, eot_2, trace)
     _check_trace(trace, j["trace"], rename)
     assert last["output"].tolist() == j["final"]["output"]
+
+
+@pytest.mark.parametrize("kind", ["longspec_snapkv_b1", "selfspec_stream_b1"])
+def test_batch_size_one_matches_reference_script(kind):
+    """B = 1 (the scripts' default): the oracle's loops against the reference's traces."""
+    j = gc.load_json(f"run_{kind}.json")
+    gamma = int(j["argv"][j["argv"].index("--gamma") + 1])
+    cfg, sd = gc.tiny("tinytgt")
+    g = torch.Generator().manual_seed(123)
+    ids_all = torch.randint(4, 2048, (8, gc.S), generator=g)
+    ids_all[:, 0] = 1
+    trace = []
+    last = None
+    if kind.startswith("longspec"):
+        eng = mr.RefEngine("target", cfg, sd, 1, gc.MAX_LEN)
+        drf = mr.RefEngine("snapkv_draft", cfg, sd, 1, gc.MAX_LEN, gc.BUDGET)
+        drf.topk_replay = j["snapkv_topk"]
+        rename = {"SnapKV.LMBackend.encode": "T.encode", "SnapKV.LMBackend.inference": "T.inference",
+                  "SnapKV.LMBackend_Draft.encode": "D.encode", "SnapKV.LMBackend_Draft.inference": "D.inference"}
+        for b in range(8):
+            last = hr.longspec_batch(eng, drf, ids_all[b:b + 1], gamma, gc.MAX_LEN, gc.EOT_1, gc.EOT_2, trace)
+    else:
+        eng = mr.RefEngine("stream_self", cfg, sd, 1, gc.MAX_LEN, gc.BUDGET)
+        rename = {f"StreamingLLM.LMBackend.{f}": f"T.{f}" for f in ("encode", "draft_encode", "speculate", "verify")}
+        for b in range(8):
+            last = hr.selfspec_batch(eng, ids_all[b:b + 1], gamma, gc.MAX_LEN, gc.EOT_1, gc.EOT_2, True, trace)
+    _check_trace(trace, j["trace"], rename)
+    assert last["output"].tolist() == j["final"]["output"]
+    assert last["num_nodes"].tolist() == j["final"]["num_nodes"]
 
 
 def test_streaming_prefill_cache_bytes_budget_513():
