@@ -584,3 +584,45 @@ def test_bench_tp_code_path_with_rccl_graphs_one_rank():
     line = json.loads(last)
     assert line["config"]["hip_graphs"] is True and line["config"]["allreduce"] == "rccl"
     assert line["config"]["emulated_tp_rank0_of"] == 2 and line["value"] > 0 and line["roofline"]["traffic"] is None
+
+
+def test_longspec_full_kv_draft_lockstep_with_oracle(ckpt_dir):
+    """--draft_budget -1 (the reference script's default): a different, smaller draft model decoding over its FULL KV
+    cache (no SnapKV select, frequent rejections -> the rollback and two-token paths), replayed in lock-step against
+    the oracle (which is pinned to the real reference's run of this layout: run_longspec_snapkv_fullkv)."""
+    from pathlib import Path
+    from magicdec_amd.Engine.SnapKV.backend_draft import LMBackend_Draft
+    cfg_t, sd_t = gc.tiny("tinytgt")
+    cfg_d, sd_d = gc.tiny("tinydrf")
+    log = []
+    tgt = Recorder(mr.RefEngine("target", cfg_t, sd_t, gc.B, gc.MAX_LEN), "T", log)
+    drf = Recorder(mr.RefEngine("snapkv_draft", cfg_d, sd_d, gc.B, gc.MAX_LEN, -1), "D", log)
+    for ids in gc.synthetic_batches()[:1]:
+        hr.longspec_batch(tgt, drf, ids, gc.GAMMA, gc.MAX_LEN, gc.EOT_1, gc.EOT_2)
+    e_d = LMBackend_Draft(dtype=torch.bfloat16, device=DEV, draft_budget=-1)
+    e_d.load_model(Path(ckpt_dir) / "tinydrf" / "model.pth", use_tp=False)
+    e_d.setup_caches(max_batch_size=gc.B, max_seq_length=gc.MAX_LEN, draft_budget=-1)
+    alt = {"T": _alt("target", cfg_t, sd_t, gc.B, gc.MAX_LEN), "D": _alt("snapkv_draft", cfg_d, sd_d, gc.B, gc.MAX_LEN, -1)}
+    st = replay(log, {"T": _hip("target", ckpt_dir), "D": e_d}, alt)
+    n_cu = sum(1 for r in log if r["cu"] is not None)
+    parity_report(st.line("longspec, full-KV draft (budget -1)") + f"  two-token draft steps={n_cu}")
+
+
+def test_batch_size_one_selfspec_stream_lockstep_with_oracle(ckpt_dir):
+    """B = 1 (the reference scripts' default batch size): StreamingLLM self-speculation with one request -- one-block
+    grids in every kernel -- in lock-step against the oracle (pinned to the reference's B = 1 run:
+    run_selfspec_stream_b1)."""
+    from pathlib import Path
+    from magicdec_amd.Engine.StreamingLLM.backend import LMBackend
+    cfg, sd = gc.tiny("tinytgt")
+    log = []
+    eng = Recorder(mr.RefEngine("stream_self", cfg, sd, 1, gc.MAX_LEN, gc.BUDGET), "T", log)
+    g = torch.Generator().manual_seed(123)
+    ids = torch.randint(4, cfg.vocab_size, (1, gc.S), generator=g)
+    ids[:, 0] = 1
+    hr.selfspec_batch(eng, ids, gc.GAMMA, gc.MAX_LEN, gc.EOT_1, gc.EOT_2, True)
+    e = LMBackend(dtype=torch.bfloat16, device=DEV, dec_len=gc.GAMMA + 1)
+    e.load_model(Path(ckpt_dir) / "tinytgt" / "model.pth", use_tp=False)
+    e.setup_caches(max_batch_size=1, max_seq_length=gc.MAX_LEN, draft_budget=gc.BUDGET)
+    st = replay(log, {"T": e}, {"T": _alt("stream_self", cfg, sd, 1, gc.MAX_LEN, gc.BUDGET)})
+    parity_report(st.line("selfspec/stream_self, B = 1"))
