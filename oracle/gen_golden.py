@@ -697,6 +697,15 @@ def scen_run(tag):
         run_script("tests/baseline_benchmark.py",
                    ["--model", str(q8), "--B", str(B), "--prefix_len", str(S), "--max_len", str(ML), "--rank_group", "0"],
                    [("Engine.SnapKV.backend", "LMBackend", ["encode", "inference"])], vocab, S, 6 * B, tag)
+    elif tag in ("run_selfspec_stream_b257", "run_selfspec_snapkv_b257", "run_selfspec_stream_g5", "run_selfspec_snapkv_g5"):
+        # self-speculation at the BASELINE budgets (configs[1] / configs[4]: 257 rows = 3 draft pages) and at the
+        # scripts' default speculation length gamma = 5
+        kind = "StreamingLLM" if "stream" in tag else "SnapKV"
+        budget = "257" if tag.endswith("b257") else "129"
+        cm = [c if c != str(G) else "5" for c in common] if tag.endswith("g5") else common
+        fns = ["encode", "draft_encode", "speculate", "verify"] if kind == "StreamingLLM" else ["encode", "speculate", "verify"]
+        run_script(f"tests/{kind}/selfspec_benchmark.py", ["--model", str(ck["tinytgt"]), "--draft_budget", budget] + cm,
+                   [(f"Engine.{kind}.backend", "LMBackend", fns)], vocab, S, 6 * B, tag)
     elif tag == "run_longspec_snapkv_rej":    # different draft model (frequent rejections); gamma=1 because the
         # SnapKV draft table is never rolled back by the harness (it rebinds draft.paged_kv_last_page_len, the
         # compressed path uses draft_paged_kv_last_page_len) and would overflow its spare page at gamma=3
@@ -992,7 +1001,8 @@ RUNS = ["run_longspec_snapkv", "run_longspec_snapkv_rej", "run_longspec_stream",
         "run_selfspec_stream_tp3", "run_baseline_68m_b1",
         "run_longspec_snapkv_fullkv", "run_longspec_snapkv_b1", "run_selfspec_stream_b1", "run_longspec_snapkv_b257",
         "run_longspec_stream_noevict", "run_longspec_snapkv_eot", "run_selfspec_stream_eot",
-        "run_baseline_eot", "run_baseline_int8", "cli_longspec_snapkv",
+        "run_baseline_eot", "run_baseline_int8", "run_selfspec_stream_b257",
+        "run_selfspec_snapkv_b257", "run_selfspec_stream_g5", "run_selfspec_snapkv_g5", "cli_longspec_snapkv",
         "cli_longspec_stream", "cli_selfspec_snapkv", "cli_selfspec_stream", "cli_baseline"]
 
 

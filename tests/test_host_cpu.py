@@ -210,28 +210,33 @@ def test_product_longspec_host_logic_matches_reference_trace(kind, gamma, cpu_op
     assert last.num_nodes.tolist() == j["final"]["num_nodes"]
 
 
-@pytest.mark.parametrize("kind", ["selfspec_snapkv", "selfspec_stream", "selfspec_snapkv_qwen", "selfspec_snapkv_70b"])
+@pytest.mark.parametrize("kind", ["selfspec_snapkv", "selfspec_stream", "selfspec_snapkv_qwen", "selfspec_snapkv_70b",
+                                  "selfspec_stream_b257", "selfspec_snapkv_b257", "selfspec_stream_g5", "selfspec_snapkv_g5"])
 def test_product_selfspec_host_logic_matches_reference_trace(kind, cpu_ops_patched, ckpt_dir):
+    """_b257: the BASELINE configs[1] / configs[4] draft budget (3 draft pages per request); _g5: the scripts' default
+    speculation length gamma = 5."""
     from magicdec_amd import harness
     j = gc.load_json(f"run_{kind}.json")
     model = "tinyqwen" if kind.endswith("qwen") else "tiny70b" if kind.endswith("70b") else "tinytgt"
-    streaming = kind.endswith("stream")
+    streaming = "selfspec_stream" in kind
+    gamma = int(j["argv"][j["argv"].index("--gamma") + 1])
+    budget = int(j["argv"][j["argv"].index("--draft_budget") + 1])
     if streaming:
         from magicdec_amd.Engine.StreamingLLM.backend import LMBackend
-        eng = LMBackend(dtype=torch.bfloat16, device="cpu", dec_len=gc.GAMMA + 1)
+        eng = LMBackend(dtype=torch.bfloat16, device="cpu", dec_len=gamma + 1)
         cls = "StreamingLLM.LMBackend"
     else:
         from magicdec_amd.Engine.SnapKV.backend import LMBackend
-        eng = LMBackend(dtype=torch.bfloat16, device="cpu", dec_len=gc.GAMMA + 1, draft_dec_len=1)
+        eng = LMBackend(dtype=torch.bfloat16, device="cpu", dec_len=gamma + 1, draft_dec_len=1)
         cls = "SnapKV.LMBackend"
         cpu_ops.TOPK_REPLAY.update(table=j["snapkv_topk"], pos=0)
     eng.load_model(ckpt_dir / model / "model.pth", use_tp=False)
-    eng.setup_caches(max_batch_size=gc.B, max_seq_length=gc.MAX_LEN, draft_budget=gc.BUDGET)
+    eng.setup_caches(max_batch_size=gc.B, max_seq_length=gc.MAX_LEN, draft_budget=budget)
     log = []
     te = Tracer(eng, cls, log, ("encode", "draft_encode", "speculate", "verify"))
     last = None
     for ids in gc.synthetic_batches():
-        last, _ = harness.run_selfspec_batch(te, ids, gc.GAMMA, gc.MAX_LEN, gc.EOT_1, gc.EOT_2, streaming)
+        last, _ = harness.run_selfspec_batch(te, ids, gamma, gc.MAX_LEN, gc.EOT_1, gc.EOT_2, streaming)
     _compare(log, j["trace"])
     assert last.output.tolist() == j["final"]["output"]
     assert last.num_nodes.tolist() == j["final"]["num_nodes"]

@@ -195,7 +195,8 @@ def test_longspec_matches_reference_script(kind, gamma):
 
 
 @pytest.mark.parametrize("kind", ["selfspec_snapkv", "selfspec_stream", "selfspec_snapkv_qwen", "selfspec_snapkv_70b",
-                                  "selfspec_stream_eot"])
+                                  "selfspec_stream_eot", "selfspec_stream_b257", "selfspec_snapkv_b257",
+                                  "selfspec_stream_g5", "selfspec_snapkv_g5"])
 def test_selfspec_matches_reference_script(kind):
     """_qwen / _70b: the reference run on a Qwen2.5-like (qkv bias, g=5, eps 1e-6) and a Llama-70B-like (g=8, D=128)
     tiny model -- pins the oracle's bias handling and the g != 4 SnapKV paths at the engine level."""
@@ -203,7 +204,9 @@ def test_selfspec_matches_reference_script(kind):
     cfg, sd = gc.tiny("tinyqwen" if kind.endswith("qwen") else "tiny70b" if kind.endswith("70b") else "tinytgt")
     streaming = kind.startswith("selfspec_stream")
     eot_1, eot_2 = (866, 1410) if kind.endswith("_eot") else (gc.EOT_1, gc.EOT_2)
-    eng = mr.RefEngine("stream_self" if streaming else "snapkv_self", cfg, sd, gc.B, gc.MAX_LEN, gc.BUDGET)
+    gamma = int(j["argv"][j["argv"].index("--gamma") + 1])            # 3, or the scripts' default 5 (_g5)
+    budget = int(j["argv"][j["argv"].index("--draft_budget") + 1])    # 129, or the BASELINE budget 257 (_b257)
+    eng = mr.RefEngine("stream_self" if streaming else "snapkv_self", cfg, sd, gc.B, gc.MAX_LEN, budget)
     mod = "StreamingLLM" if streaming else "SnapKV"
     rename = {f"{mod}.LMBackend.{f}": f"T.{f}" for f in ("encode", "draft_encode", "speculate", "verify")}
     if not streaming:
@@ -211,7 +214,7 @@ def test_selfspec_matches_reference_script(kind):
     trace = []
     last = None
     for ids in gc.synthetic_batches():
-        last = hr.selfspec_batch(eng, ids, gc.GAMMA, gc.MAX_LEN, eot_1, eot_2, streaming, trace)
+        last = hr.selfspec_batch(eng, ids, gamma, gc.MAX_LEN, eot_1, eot_2, streaming, trace)
     _check_trace(trace, j["trace"], rename)
     assert last["output"].tolist() == j["final"]["output"]
     assert last["num_nodes"].tolist() == j["final"]["num_nodes"]
