@@ -28,6 +28,16 @@ from tests.conftest import parity_report
 from tests.parity_util import capped_threads
 
 pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def _capped_cpu_threads():
+    """The oracle runs of these tests are yardsticks behind tolerance gates (tokens within the measured logit gate,
+    integer state teacher-forced), never bit-compared with the GPU: cap torch's intra-op pool, which on the GPU boxes'
+    256-core hosts makes the small CPU matmuls of the oracle tens of times slower (tests/parity_util.capped_threads)."""
+    from tests.parity_util import capped_threads
+    with capped_threads():
+        yield
 DEV = "cuda:0"
 # err_hip <= GATE_FACTOR * err_alt + GATE_ULPS * ulp_bf16(max |logit|).  Two ulps: one for the final bf16 rounding of
 # the logits, one for what the float64-linear oracle does NOT model -- the attention kernel multiplies P in bf16

@@ -18,6 +18,16 @@ from tests.test_gpu_fp8 import quantize_cache
 
 pytestmark = pytest.mark.gpu
 
+
+@pytest.fixture(autouse=True)
+def _capped_cpu_threads():
+    """The oracle runs of these tests are yardsticks behind tolerance gates (tokens within the measured logit gate,
+    integer state teacher-forced), never bit-compared with the GPU: cap torch's intra-op pool, which on the GPU boxes'
+    256-core hosts makes the small CPU matmuls of the oracle tens of times slower (tests/parity_util.capped_threads)."""
+    from tests.parity_util import capped_threads
+    with capped_threads():
+        yield
+
 DEV = "cuda"
 BF = torch.bfloat16
 F8 = torch.float8_e4m3fn
