@@ -764,6 +764,11 @@ def scen_run(tag):
                    ["--model", str(ck["tinykh4"]), "--draft_budget", "129"] + common[:-2] + ["--rank_group", "0", "1", "2"],
                    [("Engine.StreamingLLM.backend", "LMBackend", ["encode", "draft_encode", "speculate", "verify"])],
                    vocab, S, 6 * B, tag)
+    elif tag == "run_selfspec_snapkv_tp4":    # configs[4]'s per-rank layout exactly: ONE kv head per rank (four-kv-head model
+        # over 4 ranks), every rank runs the SnapKV select / gather of its own head
+        run_script("tests/SnapKV/selfspec_benchmark.py",
+                   ["--model", str(ck["tinykh4"]), "--draft_budget", "129"] + common[:-2] + ["--rank_group", "0", "1", "2", "3"],
+                   [("Engine.SnapKV.backend", "LMBackend", ["encode", "speculate", "verify"])], vocab, S, 6 * B, tag)
     elif tag == "run_selfspec_snapkv_tp2":    # BASELINE configs[4]'s layout in miniature: TP self-speculation, SnapKV cache
         run_script("tests/SnapKV/selfspec_benchmark.py",
                    ["--model", str(ck["tinytgt"]), "--draft_budget", "129"] + common[:-2] + ["--rank_group", "0", "1"],
@@ -998,7 +1003,7 @@ RUNS = ["run_longspec_snapkv", "run_longspec_snapkv_rej", "run_longspec_stream",
         "run_selfspec_stream", "run_baseline", "run_longspec_stream_tp2", "run_longspec_snapkv_tp2",
         "run_selfspec_snapkv_tp2", "run_selfspec_snapkv_qwen", "run_selfspec_snapkv_70b",
         "run_longspec_stream_70b", "run_selfspec_stream_tp2", "run_longspec_snapkv_tp4d2",
-        "run_selfspec_stream_tp3", "run_baseline_68m_b1",
+        "run_selfspec_stream_tp3", "run_selfspec_snapkv_tp4", "run_baseline_68m_b1",
         "run_longspec_snapkv_fullkv", "run_longspec_snapkv_b1", "run_selfspec_stream_b1", "run_longspec_snapkv_b257",
         "run_longspec_stream_noevict", "run_longspec_snapkv_eot", "run_selfspec_stream_eot",
         "run_baseline_eot", "run_baseline_int8", "run_selfspec_stream_b257",

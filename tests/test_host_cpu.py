@@ -496,6 +496,33 @@ def test_tensor_parallel_uneven_kv_head_shards_match_reference_tp3_trace(ckpt_di
         assert g["final"] == j["final"]
 
 
+def test_tensor_parallel_selfspec_snapkv_one_kv_head_per_rank_matches_reference_tp4_trace(ckpt_dir):
+    """BASELINE configs[4]'s per-rank layout exactly -- ONE kv head per rank (four-kv-head model over 4 ranks), every
+    rank running the SnapKV select / gather of its own head -- over gloo, world_size 4: all four product ranks reproduce
+    the REAL reference's TP=4 trace (oracle/gen_golden.py run_selfspec_snapkv_tp4; each rank replays the reference's
+    torch.topk tie resolution for its head)."""
+    import json
+    kind = "run_selfspec_snapkv_tp4"
+    out = tempfile.mkdtemp(prefix="md_tp4s_")
+    script = os.path.join(out, "worker.py")
+    Path(script).write_text(TP_SNAPKV_WORKER)
+    port = 29050 + (os.getpid() % 40)
+    procs = []
+    for r in range(4):
+        env = dict(os.environ, LOCAL_RANK=str(r), LOCAL_WORLD_SIZE="4", RANK=str(r), WORLD_SIZE="4",
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), MD_ROOT=str(ROOT), MD_CKPT=str(ckpt_dir), MD_OUT=out,
+                   MD_KIND=kind, MD_DRAFT_RANKS="0,1,2,3", MD_MODEL="tinykh4", OMP_NUM_THREADS="2")
+        procs.append(subprocess.Popen([sys.executable, script], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    logs = [p.communicate(timeout=1500)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(logs)
+    j = gc.load_json(f"{kind}.json")
+    for r in range(4):
+        got = json.load(open(os.path.join(out, f"rank{r}.json")))
+        assert got["local_heads"] == [4, 1]
+        _compare(got["trace"], j["trace"])
+        assert got["final"] == j["final"]
+
+
 def test_tensor_parallel_tp4_target_with_tp2_draft_subgroup_matches_reference_trace(ckpt_dir):
     """The reference README's topology (README.md:69: target on all ranks, draft on a sub-group) in miniature: target
     TP4 + SnapKV draft TP2 on ranks {0, 1} over gloo, world_size 4, four-kv-head model.  Ranks 2 and 3 hold no draft
