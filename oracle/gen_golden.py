@@ -112,16 +112,21 @@ def inject_configs():
 
 
 # ------------------------------------------------------------------------------------ snapkv_select
-def scen_snapkv_select():
+SNAPKV_CASES = {"g4": (4, 2, 64, 416, 129, 2, 0), "g5": (5, 2, 64, 288, 129, 2, 1), "g8": (8, 1, 128, 416, 257, 2, 2),
+                "g4d128": (4, 1, 128, 544, 257, 1, 3)}
+# a context of several 1024-column score chunks (the GPU kernel's softmax statistics are computed per chunk and
+# combined): 3104 = 3072 + 32 columns, the headline budget 257
+SNAPKV_LONG_CASES = {"g4s3104": (4, 1, 64, 3104, 257, 1, 7)}
+
+
+def scen_snapkv_select(cases=None, fname="snapkv_select.npz"):
     M = ref_import.module("Engine.SnapKV.model")
     out = {}
-    for tag, (g, KH, D, S, budget, B, seed) in {"g4": (4, 2, 64, 416, 129, 2, 0), "g5": (5, 2, 64, 288, 129, 2, 1),
-                                                "g8": (8, 1, 128, 416, 257, 2, 2),
-                                                "g4d128": (4, 1, 128, 544, 257, 1, 3)}.items():
+    for tag, (g, KH, D, S, budget, B, seed) in (cases or SNAPKV_CASES).items():
         W = 32
         H = g * KH
         torch.manual_seed(seed)
-        cfg = M.ModelArgs(block_size=2048, n_layer=1, n_head=H, n_local_heads=KH, dim=H * D, intermediate_size=256,
+        cfg = M.ModelArgs(block_size=max(2048, S), n_layer=1, n_head=H, n_local_heads=KH, dim=H * D, intermediate_size=256,
                           vocab_size=128)
         att = M.Attention(cfg)
         att.is_spec, att.draft_budget, att.window_size, att.pooling, att.kernel_size = True, budget, W, "avgpool", 5
@@ -158,7 +163,11 @@ def scen_snapkv_select():
         out.update({f"{tag}_meta": np.array([g, KH, D, S, budget, B, W]), f"{tag}_q": bits(q), f"{tag}_k": bits(kfull),
                     f"{tag}_v": bits(vfull), f"{tag}_scores": bits(cap["scores"]), f"{tag}_idx": cap["idx"].numpy(),
                     f"{tag}_newk": bits(cap["k"]), f"{tag}_newv": bits(cap["v"])})
-    np.savez_compressed(GOLD / "snapkv_select.npz", **out)
+    np.savez_compressed(GOLD / fname, **out)
+
+
+def scen_snapkv_select_long():
+    scen_snapkv_select(SNAPKV_LONG_CASES, "snapkv_select_long.npz")
 
 
 # ------------------------------------------------------------------------------------ stream_prefill
@@ -996,7 +1005,7 @@ def scen_benchflag(tag):
     print(tag, len(trace), "calls", len(topk_calls), "top-k calls")
 
 
-SCENARIOS = {"int8_quant": scen_int8_quant, "pg19": scen_pg19, "convert_hf": scen_convert_hf, "mylib_schemas": scen_mylib_schemas, "snapkv_select": scen_snapkv_select, "stream_prefill": scen_stream_prefill, "stream_prefill_b513": scen_stream_prefill_b513,
+SCENARIOS = {"int8_quant": scen_int8_quant, "pg19": scen_pg19, "convert_hf": scen_convert_hf, "mylib_schemas": scen_mylib_schemas, "snapkv_select": scen_snapkv_select, "snapkv_select_long": scen_snapkv_select_long, "stream_prefill": scen_stream_prefill, "stream_prefill_b513": scen_stream_prefill_b513,
              "accept_loop": scen_accept_loop, "tp_shapes": scen_tp_shapes, "tp_shapes_kh4": scen_tp_shapes_kh4,
              "model_configs": scen_model_configs}
 RUNS = ["run_longspec_snapkv", "run_longspec_snapkv_rej", "run_longspec_stream", "run_selfspec_snapkv",

@@ -85,7 +85,7 @@ def snapkv_select(q_win, cache, indices, indptr, ctx_len, window, budget, pool_k
     g = H // KH
     n = q_win.shape[0] // B
     last = torch.full((B,), 1, dtype=torch.int32)
-    idxs, nk, nv = [], [], []
+    idxs, nk, nv, scs = [], [], [], []
     for b in range(B):
         npg = int(indptr[b + 1]) - int(indptr[b])
         pages = indices[int(indptr[b]):int(indptr[b + 1])].long()
@@ -94,8 +94,9 @@ def snapkv_select(q_win, cache, indices, indptr, ctx_len, window, budget, pool_k
         ov = None
         if TOPK_REPLAY["table"] is not None:
             ov = torch.as_tensor(TOPK_REPLAY["table"][TOPK_REPLAY["pos"]])[b]
-        idx, k2, v2, _ = mr.snapkv_select(q_win[b * n:(b + 1) * n], kk, vv, g, window, budget, idx=ov)
+        idx, k2, v2, sc = mr.snapkv_select(q_win[b * n:(b + 1) * n], kk, vv, g, window, budget, idx=ov)
         idxs.append(idx)
+        scs.append(sc)
         nk.append(k2)
         nv.append(v2)
     if TOPK_REPLAY["table"] is not None:
@@ -103,6 +104,8 @@ def snapkv_select(q_win, cache, indices, indptr, ctx_len, window, budget, pool_k
     ip = (torch.arange(B + 1) * budget).to(torch.int32)
     fr.append_paged_kv_cache(torch.cat(nk).to(draft_cache.dtype), torch.cat(nv).to(draft_cache.dtype), ip, draft_cache,
                              dindices, dindptr, dlast)
+    if return_scores:
+        return torch.stack(idxs).to(torch.int32), torch.stack(scs)
     return torch.stack(idxs).to(torch.int32)
 
 
