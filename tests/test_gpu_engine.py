@@ -636,3 +636,24 @@ def test_batch_size_one_selfspec_stream_lockstep_with_oracle(ckpt_dir):
     e.setup_caches(max_batch_size=1, max_seq_length=gc.MAX_LEN, draft_budget=gc.BUDGET)
     st = replay(log, {"T": e}, {"T": _alt("stream_self", cfg, sd, 1, gc.MAX_LEN, gc.BUDGET)})
     parity_report(st.line("selfspec/stream_self, B = 1"))
+
+
+def test_selfspec_snapkv_lockstep_with_a_prefix_of_several_score_chunks(ckpt_dir):
+    """The same lock-step with a 1184-token prompt (10 prefill chunks; 1152 candidate columns = two of the SnapKV
+    kernel's 1024-column score chunks inside the engine flow; verify over 10 pages) instead of the 416 of the other
+    engine tests."""
+    from pathlib import Path
+    from magicdec_amd.Engine.SnapKV.backend import LMBackend
+    S, ML = 1184, 1280
+    cfg, sd = gc.tiny("tinytgt")
+    log = []
+    eng = Recorder(mr.RefEngine("snapkv_self", cfg, sd, gc.B, ML, gc.BUDGET), "T", log)
+    g = torch.Generator().manual_seed(77)
+    ids = torch.randint(4, cfg.vocab_size, (gc.B, S), generator=g)
+    ids[:, 0] = 1
+    hr.selfspec_batch(eng, ids, gc.GAMMA, ML, gc.EOT_1, gc.EOT_2, False)
+    e = LMBackend(dtype=torch.bfloat16, device=DEV, dec_len=gc.GAMMA + 1, draft_dec_len=1)
+    e.load_model(Path(ckpt_dir) / "tinytgt" / "model.pth", use_tp=False)
+    e.setup_caches(max_batch_size=gc.B, max_seq_length=ML, draft_budget=gc.BUDGET)
+    st = replay(log, {"T": e}, {"T": _alt("snapkv_self", cfg, sd, gc.B, ML, gc.BUDGET)})
+    parity_report(st.line("selfspec/snapkv_self, prefix 1184"))
