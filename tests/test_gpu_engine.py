@@ -657,3 +657,23 @@ def test_selfspec_snapkv_lockstep_with_a_prefix_of_several_score_chunks(ckpt_dir
     e.setup_caches(max_batch_size=gc.B, max_seq_length=ML, draft_budget=gc.BUDGET)
     st = replay(log, {"T": e}, {"T": _alt("snapkv_self", cfg, sd, gc.B, ML, gc.BUDGET)})
     parity_report(st.line("selfspec/snapkv_self, prefix 1184"))
+
+
+def test_selfspec_stream_lockstep_at_the_baseline_budget_257(ckpt_dir):
+    """BASELINE configs[1]'s draft geometry: StreamingLLM self-speculation with budget 257 (3 draft pages per request:
+    the eviction shifts rows across page boundaries at every prefill chunk) and a 1184-token prompt."""
+    from pathlib import Path
+    from magicdec_amd.Engine.StreamingLLM.backend import LMBackend
+    S, ML, budget = 1184, 1280, 257
+    cfg, sd = gc.tiny("tinytgt")
+    log = []
+    eng = Recorder(mr.RefEngine("stream_self", cfg, sd, gc.B, ML, budget), "T", log)
+    g = torch.Generator().manual_seed(78)
+    ids = torch.randint(4, cfg.vocab_size, (gc.B, S), generator=g)
+    ids[:, 0] = 1
+    hr.selfspec_batch(eng, ids, gc.GAMMA, ML, gc.EOT_1, gc.EOT_2, True)
+    e = LMBackend(dtype=torch.bfloat16, device=DEV, dec_len=gc.GAMMA + 1)
+    e.load_model(Path(ckpt_dir) / "tinytgt" / "model.pth", use_tp=False)
+    e.setup_caches(max_batch_size=gc.B, max_seq_length=ML, draft_budget=budget)
+    st = replay(log, {"T": e}, {"T": _alt("stream_self", cfg, sd, gc.B, ML, budget)})
+    parity_report(st.line("selfspec/stream_self, budget 257, prefix 1184"))
