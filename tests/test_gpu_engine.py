@@ -24,7 +24,7 @@ import torch
 from oracle import harness_ref as hr
 from oracle import magicdec_ref as mr
 from tests import golden_cfg as gc
-from tests.conftest import parity_report
+from tests.conftest import first_gpu_run, parity_report
 from tests.parity_util import capped_threads
 
 pytestmark = pytest.mark.gpu
@@ -596,6 +596,7 @@ def test_bench_tp_code_path_with_rccl_graphs_one_rank():
     assert line["config"]["emulated_tp_rank0_of"] == 2 and line["value"] > 0 and line["roofline"]["traffic"] is None
 
 
+@first_gpu_run
 def test_longspec_full_kv_draft_lockstep_with_oracle(ckpt_dir):
     """--draft_budget -1 (the reference script's default): a different, smaller draft model decoding over its FULL KV
     cache (no SnapKV select, frequent rejections -> the rollback and two-token paths), replayed in lock-step against
@@ -618,6 +619,7 @@ def test_longspec_full_kv_draft_lockstep_with_oracle(ckpt_dir):
     parity_report(st.line("longspec, full-KV draft (budget -1)") + f"  two-token draft steps={n_cu}")
 
 
+@first_gpu_run
 def test_batch_size_one_selfspec_stream_lockstep_with_oracle(ckpt_dir):
     """B = 1 (the reference scripts' default batch size): StreamingLLM self-speculation with one request -- one-block
     grids in every kernel -- in lock-step against the oracle (pinned to the reference's B = 1 run:
@@ -638,6 +640,7 @@ def test_batch_size_one_selfspec_stream_lockstep_with_oracle(ckpt_dir):
     parity_report(st.line("selfspec/stream_self, B = 1"))
 
 
+@first_gpu_run
 def test_selfspec_snapkv_lockstep_with_a_prefix_of_several_score_chunks(ckpt_dir):
     """The same lock-step with a 1184-token prompt (10 prefill chunks; 1152 candidate columns = two of the SnapKV
     kernel's 1024-column score chunks inside the engine flow; verify over 10 pages) instead of the 416 of the other
@@ -659,6 +662,7 @@ def test_selfspec_snapkv_lockstep_with_a_prefix_of_several_score_chunks(ckpt_dir
     parity_report(st.line("selfspec/snapkv_self, prefix 1184"))
 
 
+@first_gpu_run
 def test_selfspec_stream_lockstep_at_the_baseline_budget_257(ckpt_dir):
     """BASELINE configs[1]'s draft geometry: StreamingLLM self-speculation with budget 257 (3 draft pages per request:
     the eviction shifts rows across page boundaries at every prefill chunk) and a 1184-token prompt."""
