@@ -270,7 +270,7 @@ def _loop_body_source(script, first_marker, last_marker):
     return "\n".join(l[ind:] for l in body)
 
 
-def scen_accept_loop():
+def scen_accept_loop(fuzz=False):
     """Executes the reference's own loop-body statements on crafted integer inputs (EOT in draft / bonus,
     all-accept rows, mixed rows, length termination) and records inputs and resulting state."""
     variants = {
@@ -282,7 +282,7 @@ def scen_accept_loop():
                             "draft_tokens = tokens_buffer[:, 1:args.gamma+1]", "if not terminal:\n"),
     }
     out = {}
-    rng = np.random.default_rng(7)
+    rng = np.random.default_rng(11 if fuzz else 7)
     for vname, (script, m0, _) in variants.items():
         lines = (Path(ref_import.REFERENCE_ROOT) / script).read_text().splitlines()
         i0 = next(i for i, l in enumerate(lines) if m0 in l)
@@ -300,17 +300,28 @@ def scen_accept_loop():
         tail_src = "\n".join(l[tind:] for l in tail)
         code, tail_code = compile(src, script, "exec"), compile(tail_src, script, "exec")
         cases = []
-        for case in range(24):
-            gamma = int(rng.choice([1, 3, 4]))
-            B = int(rng.choice([1, 3, 8]))
+        for case in range(20 if fuzz else 24):
+            gamma = int(rng.choice([1, 2, 3, 5, 6] if fuzz else [1, 3, 4]))
+            B = int(rng.choice([2, 16, 64, 130] if fuzz else [1, 3, 8]))      # 130: more than one wavefront of rows
             prefix = 300
             out_cols = prefix + 128 + 1
             eot_1, eot_2 = 7, 9
             tb = torch.from_numpy(rng.integers(10, 30, size=(B, gamma + 1))).long()
             tt = tb.roll(-1, dims=1).clone()
             tt[:, -1] = torch.from_numpy(rng.integers(10, 30, size=(B,)))
-            mode = case % 6
-            if mode == 0:       # all accepted somewhere
+            mode = -1 if fuzz else case % 6
+            if fuzz:            # unstructured: per-element rejections (p in {0.05, 0.3}), EOT ids sprinkled over drafts and
+                # targets (p = 0.01: accepted EOT drafts, EOT bonus tokens, EOT after a rejection), random lengths
+                p_rej = float(rng.choice([0.05, 0.3]))
+                rej = torch.from_numpy(rng.random((B, gamma + 1)) < p_rej)
+                tt = torch.where(rej, tt + 100, tt)
+                e = torch.from_numpy(rng.random((B, gamma + 1)) < 0.01)
+                which = torch.from_numpy(rng.integers(0, 2, size=(B, gamma + 1))).bool()
+                eot = torch.where(which, torch.tensor(eot_1), torch.tensor(eot_2))
+                tb = torch.where(e, eot, tb)
+                tt[:, :-1] = torch.where(e[:, 1:] & ~rej[:, :-1], eot[:, 1:], tt[:, :-1])   # an EOT draft the target agrees on
+                tt[:, -1] = torch.where(torch.from_numpy(rng.random(B) < 0.01), torch.tensor(eot_2), tt[:, -1])
+            elif mode == 0:     # all accepted somewhere
                 pass
             elif mode == 1:     # random rejections
                 rej = torch.from_numpy(rng.integers(0, 2, size=(B, gamma + 1))).bool()
@@ -323,7 +334,7 @@ def scen_accept_loop():
                 tt[B - 1, 0] = eot_2
             elif mode == 4:     # mixed full / partial
                 tt[::2] = tt[::2] + 100
-            base = torch.from_numpy(rng.integers(prefix, prefix + 40, size=(B,))).int()
+            base = torch.from_numpy(rng.integers(prefix, prefix + (79 if fuzz and case % 4 == 0 else 40), size=(B,))).int()
             if mode == 5:       # length termination
                 base[:] = prefix + 78
             ns = types.SimpleNamespace
@@ -362,7 +373,11 @@ def scen_accept_loop():
                        cachelens_update=env["cachelens_update"].tolist() if env.get("next_double") else None)
             cases.append(dict(inp=rec, out=res))
         out[vname] = cases
-    (GOLD / "accept_loop.json").write_text(json.dumps(out))
+    (GOLD / ("accept_loop_fuzz.json" if fuzz else "accept_loop.json")).write_text(json.dumps(out))
+
+
+def scen_accept_loop_fuzz():
+    scen_accept_loop(fuzz=True)
 
 
 # ------------------------------------------------------------------------------------ tp_shapes
@@ -1006,7 +1021,7 @@ def scen_benchflag(tag):
 
 
 SCENARIOS = {"int8_quant": scen_int8_quant, "pg19": scen_pg19, "convert_hf": scen_convert_hf, "mylib_schemas": scen_mylib_schemas, "snapkv_select": scen_snapkv_select, "snapkv_select_long": scen_snapkv_select_long, "stream_prefill": scen_stream_prefill, "stream_prefill_b513": scen_stream_prefill_b513,
-             "accept_loop": scen_accept_loop, "tp_shapes": scen_tp_shapes, "tp_shapes_kh4": scen_tp_shapes_kh4,
+             "accept_loop": scen_accept_loop, "accept_loop_fuzz": scen_accept_loop_fuzz, "tp_shapes": scen_tp_shapes, "tp_shapes_kh4": scen_tp_shapes_kh4,
              "model_configs": scen_model_configs}
 RUNS = ["run_longspec_snapkv", "run_longspec_snapkv_rej", "run_longspec_stream", "run_selfspec_snapkv",
         "run_selfspec_stream", "run_baseline", "run_longspec_stream_tp2", "run_longspec_snapkv_tp2",

@@ -351,11 +351,13 @@ VARIANTS = {"longspec": (lambda g: g, lambda g: g, True, "draft_"),
             "selfspec_stream": (lambda g: g, lambda g: g, True, "engine_draft_")}
 
 
+@pytest.mark.parametrize("fixture", ["accept_loop.json", pytest.param("accept_loop_fuzz.json", marks=first_gpu_run)])
 @pytest.mark.parametrize("variant", list(VARIANTS))
-def test_accept_rollback_kernel_matches_reference_loop_body(ops, variant):
-    """Bit-exact against vectors produced by exec'ing the reference's own loop body (gen_golden.py:accept_loop)."""
+def test_accept_rollback_kernel_matches_reference_loop_body(ops, variant, fixture):
+    """Bit-exact against vectors produced by exec'ing the reference's own loop body (gen_golden.py:accept_loop;
+    accept_loop_fuzz: unstructured cases, gamma up to 6, up to 130 rows = more than one wavefront of requests)."""
     dr, cap, dbl, pre = VARIANTS[variant]
-    for c in gc.load_json("accept_loop.json")[variant]:
+    for c in gc.load_json(fixture)[variant]:
         i, o = c["inp"], c["out"]
         G, B = i["gamma"], i["B"]
         d = lambda x, dt: torch.tensor(x, dtype=dt, device=DEV)

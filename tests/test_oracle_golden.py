@@ -74,9 +74,12 @@ VARIANTS = {"longspec": dict(dr=lambda g: g, cap=lambda g: g, dbl=True, draft="d
             "selfspec_stream": dict(dr=lambda g: g, cap=lambda g: g, dbl=True, draft="engine")}
 
 
+@pytest.mark.parametrize("fixture", ["accept_loop.json", "accept_loop_fuzz.json"])
 @pytest.mark.parametrize("variant", list(VARIANTS))
-def test_accept_loop_bit_exact(variant):
-    cases = gc.load_json("accept_loop.json")[variant]
+def test_accept_loop_bit_exact(variant, fixture):
+    """accept_loop_fuzz: unstructured cases (per-element rejections, EOT ids sprinkled over drafts and targets, gamma up to
+    6, up to 130 rows) from the same exec of the reference's loop bodies."""
+    cases = gc.load_json(fixture)[variant]
     V = VARIANTS[variant]
     assert len(cases) >= 20
     seen_term = seen_double = 0
