@@ -17,15 +17,28 @@ from .data import convert_pg19_dataset, load_tokenizer
 from .Engine.utils import setup_seed
 
 
-def _common(parser, spec=True):
-    parser.add_argument('--model', type=Path, default=Path("checkpoints/meta-llama/Llama-3.2-1B/model.pth"), help='model')
+# Per-script defaults of the reference's five entry points (their argparse blocks differ: e.g. the self-speculation scripts
+# default to B = 45, prefix 100000, gamma 7, budget 4097; tests/SnapKV/selfspec_benchmark.py:17-36).  Checkpoint paths are
+# the one deliberate difference: "checkpoints/..." relative to the working directory instead of "/scratch/models/...".
+_CKPT_8B = Path("checkpoints/meta-llama/Meta-Llama-3.1-8B/model.pth")
+_CKPT_1B = Path("checkpoints/meta-llama/Llama-3.2-1B/model.pth")
+_DEFAULTS = {
+    "longspec": dict(model=_CKPT_1B, B=1, prefix_len=4000, max_len=64, gamma=5),
+    "selfspec": dict(model=_CKPT_8B, B=45, prefix_len=100000, max_len=100096, gamma=7, draft_budget=4097),
+    "baseline": dict(model=_CKPT_8B, B=16, prefix_len=8065, max_len=8192),
+}
+
+
+def _common(parser, script, kind=None):
+    d = _DEFAULTS[script]
+    parser.add_argument('--model', type=Path, default=d["model"], help='model')
     parser.add_argument('--model_name', type=str, default="meta-llama/Meta-Llama-3.1-8B", help='model name')
     parser.add_argument('--dataset', type=str, default="pg19", help='Dataset name.')
     parser.add_argument('--rank_group', nargs='+', type=int, help='Target group of ranks')
     parser.add_argument('--compile', action='store_true', help='Capture the decode steps into hipGraphs.')
-    parser.add_argument('--B', type=int, default=1, help='Batch size.')
-    parser.add_argument('--prefix_len', type=int, default=4000, help='Prefix length')
-    parser.add_argument('--max_len', type=int, default=64, help='Generate length')
+    parser.add_argument('--B', type=int, default=d["B"], help='Batch size.')
+    parser.add_argument('--prefix_len', type=int, default=d["prefix_len"], help='Prefix length')
+    parser.add_argument('--max_len', type=int, default=d["max_len"], help='Generate length')
     parser.add_argument('--seed', type=int, default=123, help='Random seed.')
     parser.add_argument('--printoutput', action='store_true', help='Whether to print the generated text.')
     parser.add_argument('--benchmark', action='store_true', help='Per-phase timing (adds synchronisations).')
@@ -34,10 +47,35 @@ def _common(parser, spec=True):
     parser.add_argument('--kv_layout', type=str, default="NHD", choices=["NHD", "HND"],
                         help='Page layout of the full-context KV cache (the reference plans flashinfer "NHD"; '
                              'HND keeps the rows of one kv head contiguous).')
-    if spec:
-        parser.add_argument('--draft_budget', type=int, default=-1, help='Draft KV budget.')
-        parser.add_argument('--gamma', type=int, default=5, help='speculation length')
-        parser.add_argument('--window_size', type=int, default=32, help='SnapKV observation window')
+    if script != "baseline":
+        budget = d.get("draft_budget", -1 if kind == "SnapKV" else 1025)     # longspec: SnapKV -1, StreamingLLM 1025
+        parser.add_argument('--draft_budget', type=int, default=budget, help='Draft KV budget.')
+        parser.add_argument('--gamma', type=int, default=d["gamma"], help='speculation length')
+        if kind == "SnapKV":
+            parser.add_argument('--window_size', type=int, default=32, help='SnapKV observation window')
+
+
+def longspec_parser(kind="SnapKV"):
+    """The flags and defaults of tests/<kind>/longspec_benchmark.py (+ --kv_dtype / --kv_layout)."""
+    parser = argparse.ArgumentParser(description='Process model configuration and partitions.')
+    _common(parser, "longspec", kind)
+    parser.add_argument('--target', type=Path, default=_CKPT_8B, help='target model')
+    parser.add_argument('--draft_rank_group', nargs='+', type=int, help='Draft group of ranks')
+    return parser
+
+
+def selfspec_parser(kind="SnapKV"):
+    """The flags and defaults of tests/<kind>/selfspec_benchmark.py (+ --kv_dtype / --kv_layout)."""
+    parser = argparse.ArgumentParser(description='Process model configuration and partitions.')
+    _common(parser, "selfspec", kind)
+    return parser
+
+
+def baseline_parser():
+    """The flags and defaults of tests/baseline_benchmark.py (+ --dataset / --benchmark / --kv_dtype / --kv_layout)."""
+    parser = argparse.ArgumentParser(description='Process model configuration and partitions.')
+    _common(parser, "baseline")
+    return parser
 
 
 def _eot(tokenizer):
@@ -66,11 +104,7 @@ def _dataset(args, tokenizer, vocab):
 
 def longspec_main(kind: str, argv=None):
     """kind: 'SnapKV' | 'StreamingLLM' -- tests/<kind>/longspec_benchmark.py."""
-    parser = argparse.ArgumentParser(description='Process model configuration and partitions.')
-    _common(parser)
-    parser.add_argument('--target', type=Path, default=Path("checkpoints/meta-llama/Meta-Llama-3.1-8B/model.pth"), help='target model')
-    parser.add_argument('--draft_rank_group', nargs='+', type=int, help='Draft group of ranks')
-    args = parser.parse_args(argv)
+    args = longspec_parser(kind).parse_args(argv)
     assert args.prefix_len < args.max_len
     assert (args.max_len + 127) // 128 == args.prefix_len // 128 + 1
     if kind == "SnapKV":
@@ -171,9 +205,7 @@ def longspec_main(kind: str, argv=None):
 
 def selfspec_main(kind: str, argv=None):
     """kind: 'SnapKV' | 'StreamingLLM' -- tests/<kind>/selfspec_benchmark.py."""
-    parser = argparse.ArgumentParser(description='Process model configuration and partitions.')
-    _common(parser)
-    args = parser.parse_args(argv)
+    args = selfspec_parser(kind).parse_args(argv)
     assert args.prefix_len < args.max_len
     assert (args.max_len + 127) // 128 == args.prefix_len // 128 + 1
     assert (args.draft_budget - 1) % 128 == 0
@@ -248,9 +280,7 @@ def selfspec_main(kind: str, argv=None):
 
 def baseline_main(argv=None):
     """tests/baseline_benchmark.py: the autoregressive denominator of every speedup figure."""
-    parser = argparse.ArgumentParser(description='Process model configuration and partitions.')
-    _common(parser, spec=False)
-    args = parser.parse_args(argv)
+    args = baseline_parser().parse_args(argv)
     assert args.prefix_len < args.max_len          # tests/baseline_benchmark.py:30-31
     assert args.max_len % 128 == 0
     DEVICE = _device()

@@ -452,6 +452,26 @@ def scen_model_configs():
           sum(1 for v in res["lookup"].values() if "error" in v), "errors")
 
 
+def scen_cli_args():
+    """The command-line contract of the five entry points: every parser.add_argument(...) of the reference scripts, read
+    from their source with ast (flags, type, default, nargs, action)."""
+    import ast
+    scripts = ["tests/SnapKV/longspec_benchmark.py", "tests/StreamingLLM/longspec_benchmark.py",
+               "tests/SnapKV/selfspec_benchmark.py", "tests/StreamingLLM/selfspec_benchmark.py",
+               "tests/baseline_benchmark.py"]
+    res = {}
+    for sc in scripts:
+        tree = ast.parse((Path(ref_import.REFERENCE_ROOT) / sc).read_text())
+        args = []
+        for node in ast.walk(tree):
+            if isinstance(node, ast.Call) and getattr(node.func, "attr", "") == "add_argument":
+                kw = {k.arg: ast.unparse(k.value) for k in node.keywords if k.arg != "help"}
+                args.append(dict(flags=[ast.literal_eval(a) for a in node.args], **kw))
+        res[sc] = args
+    (GOLD / "cli_args.json").write_text(json.dumps(res))
+    print("cli_args", {k: len(v) for k, v in res.items()})
+
+
 def scen_tp_shapes_kh4():
     """apply_tp (Engine/tp.py:184-207) of the four-kv-head model over 2, 3 (uneven: 2 | 1 | 1 kv heads; torch.chunk of
     1024 ffn rows -> 342 | 342 | 340, of 2048 vocab rows -> 683 | 683 | 682) and 4 ranks: per-rank tensor shapes and sums."""
@@ -1022,7 +1042,7 @@ def scen_benchflag(tag):
 
 SCENARIOS = {"int8_quant": scen_int8_quant, "pg19": scen_pg19, "convert_hf": scen_convert_hf, "mylib_schemas": scen_mylib_schemas, "snapkv_select": scen_snapkv_select, "snapkv_select_long": scen_snapkv_select_long, "stream_prefill": scen_stream_prefill, "stream_prefill_b513": scen_stream_prefill_b513,
              "accept_loop": scen_accept_loop, "accept_loop_fuzz": scen_accept_loop_fuzz, "tp_shapes": scen_tp_shapes, "tp_shapes_kh4": scen_tp_shapes_kh4,
-             "model_configs": scen_model_configs}
+             "model_configs": scen_model_configs, "cli_args": scen_cli_args}
 RUNS = ["run_longspec_snapkv", "run_longspec_snapkv_rej", "run_longspec_stream", "run_selfspec_snapkv",
         "run_selfspec_stream", "run_baseline", "run_longspec_stream_tp2", "run_longspec_snapkv_tp2",
         "run_selfspec_snapkv_tp2", "run_selfspec_snapkv_qwen", "run_selfspec_snapkv_70b",

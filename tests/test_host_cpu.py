@@ -1137,3 +1137,39 @@ def test_int8_weight_only_end_to_end_matches_reference_trace(cpu_ops_patched, ck
     assert out.tolist() == j["final"]["output"]
     # and it is not the bf16 model's trace
     assert [r["out"] for r in j["trace"]] != [r["out"] for r in gc.load_json("run_baseline.json")["trace"]]
+
+
+def test_command_line_flags_and_defaults_equal_the_reference_scripts():
+    """Every parser.add_argument(...) of the reference's five scripts (tests/golden/cli_args.json: read from their source
+    with ast) exists in the product's parser for that script with the same type, nargs, action and DEFAULT -- the
+    scripts differ (self-speculation defaults to B = 45, prefix 100000, gamma 7, budget 4097; StreamingLLM longspec to
+    budget 1025; the baseline to B = 16, prefix 8065).  Deliberate differences: checkpoint paths are relative
+    ("checkpoints/...", not "/scratch/models/..."), and the product adds --kv_dtype / --kv_layout (and, for the
+    baseline, --dataset / --benchmark)."""
+    from magicdec_amd import cli
+    j = gc.load_json("cli_args.json")
+    parsers = {"tests/SnapKV/longspec_benchmark.py": cli.longspec_parser("SnapKV"),
+               "tests/StreamingLLM/longspec_benchmark.py": cli.longspec_parser("StreamingLLM"),
+               "tests/SnapKV/selfspec_benchmark.py": cli.selfspec_parser("SnapKV"),
+               "tests/StreamingLLM/selfspec_benchmark.py": cli.selfspec_parser("StreamingLLM"),
+               "tests/baseline_benchmark.py": cli.baseline_parser()}
+    extras = {"--kv_dtype", "--kv_layout", "-h", "--help"}
+    for script, ref_args in j.items():
+        acts = {a.option_strings[0]: a for a in parsers[script]._actions if a.option_strings}
+        for ra in ref_args:
+            flag = ra["flags"][0]
+            assert flag in acts, (script, flag)
+            a = acts[flag]
+            if ra.get("action") == "'store_true'":
+                assert a.const is True and a.default is False and a.nargs == 0, (script, flag)
+                continue
+            assert a.type.__name__ == ra["type"], (script, flag, a.type, ra["type"])
+            assert repr(a.nargs) == ra.get("nargs", "None"), (script, flag, a.nargs)
+            if ra["type"] == "Path":
+                assert a.default.name == "model.pth" and a.default.parent.name in ra["default"], (script, flag, a.default)
+            elif "default" in ra:
+                assert repr(a.default) == ra["default"], (script, flag, a.default, ra["default"])
+            else:
+                assert a.default is None, (script, flag, a.default)
+        allowed = extras | ({"--dataset", "--benchmark"} if "baseline" in script else set())
+        assert set(acts) - {r["flags"][0] for r in ref_args} <= allowed, (script, set(acts) - {r["flags"][0] for r in ref_args})
