@@ -116,14 +116,17 @@ SNAPKV_CASES = {"g4": (4, 2, 64, 416, 129, 2, 0), "g5": (5, 2, 64, 288, 129, 2, 
                 "g4d128": (4, 1, 128, 544, 257, 1, 3)}
 # a context of several 1024-column score chunks (the GPU kernel's softmax statistics are computed per chunk and
 # combined): 3104 = 3072 + 32 columns, the headline budget 257
-SNAPKV_LONG_CASES = {"g4s3104": (4, 1, 64, 3104, 257, 1, 7)}
+SNAPKV_LONG_CASES = {"g4s3104": (4, 1, 64, 3104, 257, 1, 7),
+                     # --window_size 16 (the flag of the SnapKV scripts; every other fixture uses the default 32)
+                     "g4w16": (4, 2, 64, 400, 129, 2, 5, 16)}
 
 
 def scen_snapkv_select(cases=None, fname="snapkv_select.npz"):
     M = ref_import.module("Engine.SnapKV.model")
     out = {}
-    for tag, (g, KH, D, S, budget, B, seed) in (cases or SNAPKV_CASES).items():
-        W = 32
+    for tag, case in (cases or SNAPKV_CASES).items():
+        g, KH, D, S, budget, B, seed = case[:7]
+        W = case[7] if len(case) > 7 else 32
         H = g * KH
         torch.manual_seed(seed)
         cfg = M.ModelArgs(block_size=max(2048, S), n_layer=1, n_head=H, n_local_heads=KH, dim=H * D, intermediate_size=256,

@@ -468,7 +468,8 @@ def _snapkv_alt_oracle(q, k, v, g, W, budget):
     return torch.stack(sc), torch.stack(idx)
 
 
-@pytest.mark.parametrize("tag", ["g4", "g5", "g8", "g4d128", pytest.param("g4s3104", marks=first_gpu_run)])
+@pytest.mark.parametrize("tag", ["g4", "g5", "g8", "g4d128", pytest.param("g4s3104", marks=first_gpu_run),
+                                 pytest.param("g4w16", marks=first_gpu_run)])
 def test_snapkv_select_vs_reference_fixture(ops, tag, golden_dir):
     """Against the reference's own gen_draft_kv output (fixture).  The index work is exact GIVEN the scores (stable
     descending top-k, lowest index among equals; gathered rows bit-equal).  The bf16 scores themselves depend on the
@@ -480,8 +481,9 @@ def test_snapkv_select_vs_reference_fixture(ops, tag, golden_dir):
       * selected-index set per (request, kv head): |hip ^ ref| <= 2 * max|alt ^ ref| + 2, and every differing
         position's reference score lies within 2 ulp of the reference's selection threshold.
     All counts go to the parity report."""
-    # g4s3104: a context of three 1024-column score chunks (per-chunk softmax statistics, combined), budget 257
-    z = np.load(f"{golden_dir}/snapkv_select_long.npz" if tag == "g4s3104" else f"{golden_dir}/snapkv_select.npz")
+    # g4s3104: a context of three 1024-column score chunks (per-chunk softmax statistics, combined), budget 257;
+    # g4w16: --window_size 16 instead of the default 32
+    z = np.load(f"{golden_dir}/snapkv_select_long.npz" if tag in ("g4s3104", "g4w16") else f"{golden_dir}/snapkv_select.npz")
     g, KH, D, S, budget, B, W = [int(x) for x in z[f"{tag}_meta"]]
     H = g * KH
     q = gc.from_bits(z[f"{tag}_q"])

@@ -14,10 +14,11 @@ from tests import golden_cfg as gc
 
 
 # ------------------------------------------------------------------ SnapKV select
-@pytest.mark.parametrize("tag", ["g4", "g5", "g8", "g4d128", "g4s3104"])
+@pytest.mark.parametrize("tag", ["g4", "g5", "g8", "g4d128", "g4s3104", "g4w16"])
 def test_snapkv_scores_and_indices(tag, golden_dir):
-    # g4s3104: a context of three 1024-column score chunks (per-chunk softmax statistics, combined), budget 257
-    z = np.load(f"{golden_dir}/snapkv_select_long.npz" if tag == "g4s3104" else f"{golden_dir}/snapkv_select.npz")
+    # g4s3104: a context of three 1024-column score chunks (per-chunk softmax statistics, combined), budget 257;
+    # g4w16: --window_size 16 instead of the default 32
+    z = np.load(f"{golden_dir}/snapkv_select_long.npz" if tag in ("g4s3104", "g4w16") else f"{golden_dir}/snapkv_select.npz")
     g, KH, D, S, budget, B, W = [int(x) for x in z[f"{tag}_meta"]]
     q = gc.from_bits(z[f"{tag}_q"]).view(B, W, g * KH, D)
     k = gc.from_bits(z[f"{tag}_k"])
