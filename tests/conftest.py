@@ -17,14 +17,6 @@ def parity_report(line: str):
     print(line)
 
 
-# GPU tests written after round 2's GPU minutes were spent: their logic was dry-run against the CPU stand-ins (same test
-# body, tests/cpu_ops.py instead of the HIP library), the kernels underneath have not seen these shapes yet.  Non-strict
-# xfail = they RUN on hardware and report XPASS / XFAIL without deciding the suite's colour; the marker comes off after
-# their first run.
-first_gpu_run = pytest.mark.xfail(reason="first hardware run pending (written without GPU access, dry-run on the CPU "
-                                         "stand-ins)", strict=False)
-
-
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

@@ -73,3 +73,34 @@ def benchflag_inputs(ncols, call_index, vocab=2048, batch=B):
     if ncols > 8:
         ids[:, 0] = 1
     return ids
+
+
+def peaked_pair(emb_gain=16.0, peak=12.0, draft_miss_every=4, seed=77):
+    """A target / draft pair whose next-token distributions are PEAKED, as a trained model's are (random-init heads
+    give ~2048 nearly tied Gaussian logits, where any rounding difference legitimately flips an argmax): the head is
+    tied to the embedding through a fixed permutation pi of the non-special token ids, `output[j] = c * emb[pi(j)]`,
+    and the embedding dominates the residual stream (gain `emb_gain` over the layers' contributions), so that the logit
+    of the one token j with pi(j) == current token stands at ~`peak` while the other 2047 stay within ~+-2 -- a top-2
+    gap of hundreds of bf16 ulps, with the attention / MLP branches (all kernels still run at full strength) as the
+    perturbation.  The draft shares embedding and layers' shapes but mispredicts every `draft_miss_every`-th token id
+    (its permutation differs there), so rejections and rollbacks occur at a known rate.
+    Returns ((cfg_t, sd_t), (cfg_d, sd_d))."""
+    cfg_t, sd_t = tiny("tinytgt")
+    cfg_d, sd_d = tiny("tinydrf")
+    g = torch.Generator().manual_seed(seed)
+    V, dim = cfg_t.vocab_size, cfg_t.dim
+    assert (cfg_d.vocab_size, cfg_d.dim) == (V, dim)
+    emb = (torch.randn(V, dim, generator=g) * 0.02 * emb_gain)
+    perm = torch.arange(V)
+    perm[4:] = 4 + torch.randperm(V - 4, generator=g)           # ids 0..3 (BOS / EOT ids of the tests) stay fixed
+    c = peak / (dim * 0.02 * emb_gain)                          # logit of the tied row: |e|^2 / rms(e) * c = peak
+    head_t = emb[perm] * c
+    perm_d = perm.clone()
+    miss = torch.arange(4, V, draft_miss_every)
+    perm_d[miss] = perm[torch.roll(miss, 1)]                    # the draft's tied row is another token's there
+    head_d = emb[perm_d] * c
+    sd_t, sd_d = dict(sd_t), dict(sd_d)
+    for sd, head in ((sd_t, head_t), (sd_d, head_d)):
+        sd["tok_embeddings.weight"] = emb.to(torch.bfloat16)
+        sd["output.weight"] = head.to(torch.bfloat16)
+    return (cfg_t, sd_t), (cfg_d, sd_d)

@@ -210,6 +210,34 @@ def test_hnd_selfspec_snapkv_engine_lockstep_with_oracle(ckpt_dir):
         assert torch.equal(bits(to_hnd(a)), bits(b))
 
 
+def test_hnd_selfspec_streaming_engine_lockstep_with_oracle(ckpt_dir):
+    """BASELINE.json configs[1]'s engine (StreamingLLM self-speculation: one model, the full-context cache verified
+    against + the sink/window ring it drafts from) with the full-context cache stored HND (the ring stays NHD): the
+    oracle's selfspec run replayed in lock-step, same measured gates; the HND cache it ends with is the NHD engine's
+    cache permuted, bit for bit, and the rings are equal."""
+    from pathlib import Path
+    from magicdec_amd.Engine.StreamingLLM.backend import LMBackend
+    cfg, sd = gc.tiny("tinytgt")
+    log = []
+    eng = Recorder(mr.RefEngine("stream_self", cfg, sd, gc.B, gc.MAX_LEN, gc.BUDGET), "T", log)
+    for ids in gc.synthetic_batches()[:1]:
+        hr.selfspec_batch(eng, ids, gc.GAMMA, gc.MAX_LEN, gc.EOT_1, gc.EOT_2, True)
+    caches, rings = {}, {}
+    for layout in ("NHD", "HND"):
+        e = LMBackend(dtype=torch.bfloat16, device=DEV, dec_len=gc.GAMMA + 1)
+        e.load_model(Path(ckpt_dir) / "tinytgt" / "model.pth", use_tp=False)
+        e.setup_caches(max_batch_size=gc.B, max_seq_length=gc.MAX_LEN, draft_budget=gc.BUDGET, kv_layout=layout)
+        st = replay(log, {"T": e}, {"T": _alt("stream_self", cfg, sd, gc.B, gc.MAX_LEN, gc.BUDGET)})
+        parity_report(st.line(f"selfspec/stream_self kv_layout={layout}"))
+        caches[layout] = [b.attention.kv_cache.kv_cache.cpu() for b in e.model.layers]
+        rings[layout] = [b.attention.kv_cache.draft_cache.cpu() for b in e.model.layers]
+        assert caches[layout][0].shape[2] == (cfg.n_local_heads if layout == "HND" else 128)
+    for a, b in zip(caches["NHD"], caches["HND"]):
+        assert torch.equal(bits(to_hnd(a)), bits(b))
+    for a, b in zip(rings["NHD"], rings["HND"]):
+        assert torch.equal(bits(a), bits(b))
+
+
 def test_hnd_cfg5_layout_fp8_engine_lockstep_with_oracle():
     """BASELINE.json configs[4] in miniature with the fp8 cache stored HND (what the layout exists for): same replay
     against mr.RefEngine(kv_fp8=True) as test_gpu_engine.py's cfg5 test."""

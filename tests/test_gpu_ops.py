@@ -13,7 +13,7 @@ import torch
 from oracle import flashinfer_ref as fr
 from oracle import magicdec_ref as mr
 from tests import golden_cfg as gc
-from tests.conftest import first_gpu_run, parity_report
+from tests.conftest import parity_report
 from tests.parity_util import check_attention, dense_attention_f64
 
 pytestmark = pytest.mark.gpu
@@ -351,7 +351,7 @@ VARIANTS = {"longspec": (lambda g: g, lambda g: g, True, "draft_"),
             "selfspec_stream": (lambda g: g, lambda g: g, True, "engine_draft_")}
 
 
-@pytest.mark.parametrize("fixture", ["accept_loop.json", pytest.param("accept_loop_fuzz.json", marks=first_gpu_run)])
+@pytest.mark.parametrize("fixture", ["accept_loop.json", "accept_loop_fuzz.json"])
 @pytest.mark.parametrize("variant", list(VARIANTS))
 def test_accept_rollback_kernel_matches_reference_loop_body(ops, variant, fixture):
     """Bit-exact against vectors produced by exec'ing the reference's own loop body (gen_golden.py:accept_loop;
@@ -415,7 +415,6 @@ def test_streaming_shift_and_rotate_match_reference_cache_bytes(ops, golden_dir)
         assert torch.equal(bits(dst.cpu()), bits(gc.from_bits(z[f"rot{step}"]))), f"rot step {step}"
 
 
-@first_gpu_run
 def test_streaming_shift_and_rotate_at_budget_513_match_reference_digests(ops):
     """The same at BASELINE configs[3]'s draft budget (513 rows = 5 pages per request, two kv heads): the eviction moves
     rows across page boundaries.  Expected values: SHA-256 digests of the REAL reference's cache / rotated cache after
@@ -468,8 +467,8 @@ def _snapkv_alt_oracle(q, k, v, g, W, budget):
     return torch.stack(sc), torch.stack(idx)
 
 
-@pytest.mark.parametrize("tag", ["g4", "g5", "g8", "g4d128", pytest.param("g4s3104", marks=first_gpu_run),
-                                 pytest.param("g4w16", marks=first_gpu_run)])
+@pytest.mark.parametrize("tag", ["g4", "g5", "g8", "g4d128", "g4s3104",
+                                 "g4w16"])
 def test_snapkv_select_vs_reference_fixture(ops, tag, golden_dir):
     """Against the reference's own gen_draft_kv output (fixture).  The index work is exact GIVEN the scores (stable
     descending top-k, lowest index among equals; gathered rows bit-equal).  The bf16 scores themselves depend on the
