@@ -44,6 +44,9 @@ WORKLOADS = {
     "cfg3": ("Meta-Llama-3.1-8B", "Llama-3.2-1B", 64, 16032, 16128, 257, 3),
     "cfg3-small": ("Meta-Llama-3.1-8B", "Llama-3.2-1B", 8, 2080, 2176, 257, 3),
     "tiny": ("llama-68m-gqa", "llama-68m-gqa", 4, 416, 512, 129, 3),
+    # eight kv heads: shards down to ONE kv head per rank at TP8 with a TP4 draft sub-group -- the reference README's
+    # 8-GPU topology in miniature (tests/test_bench_cpu.py runs it over gloo with 4 and 8 ranks)
+    "tiny-kh8": ("llama-68m-kh8", "llama-68m-kh8", 4, 416, 512, 129, 3),
     # configs[1] of BASELINE.json: self-speculation, StreamingLLM draft cache (one model, two caches)
     "cfg2": ("Meta-Llama-3.1-8B", None, 32, 8065, 8192, 257, 3),
     # configs[3] / configs[4]: TP8 configurations -- on one GPU only as `--emulate-tp 8` (one rank's compute)
@@ -175,6 +178,10 @@ def run(args, dev):
     model_core.transformer_configs.setdefault(
         "llama-68m-gqa", dict(block_size=2048, n_layer=2, n_head=16, n_local_heads=4, dim=1024, intermediate_size=2048,
                               vocab_size=32000))
+
+    model_core.transformer_configs.setdefault(
+        "llama-68m-kh8", dict(block_size=2048, n_layer=2, n_head=32, n_local_heads=8, dim=2048, intermediate_size=1024,
+                              vocab_size=4096))      # g = 4: the reference's SnapKV select needs 8g >= 32 rows per chunk
 
     wl = WORKLOADS[args.workload]
     tgt_name, drf_name, B, S, ML, BUDGET, G = wl[:7]

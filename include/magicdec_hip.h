@@ -298,7 +298,9 @@ int md_accept_rollback(int64_t* tokens_buffer, const int64_t* target_tokens, int
  * asynchronous on `stream`, graph-capturable (call counters live in device memory), and must be issued in the same
  * order with the same sizes on every rank.  Spins are bounded (~2 s): on a time-out the kernel sets the status word
  * (md_ar_status: 0 = ok, 1 = timed out) and writes NaN into the rows it could not complete -- a missing peer is
- * never papered over; the host checks md_ar_status per batch and raises.
+ * never papered over (two-shot: the rows the timed-out rank owns are NaN in every rank's output); the host reads the
+ * status word with every iteration's flag read (md_ar_status_async: a 4-byte copy into pinned host memory queued on
+ * `stream`, valid after the stream is synchronised) and raises.
  * ---------------------------------------------------------------------- */
 #define MD_AR_HANDLE_BYTES 64
 #define MD_AR_MAX_RANKS 8
@@ -314,6 +316,7 @@ int md_allreduce_oneshot(md_ar_comm* comm, const void* in, void* out, size_t cou
 int md_allreduce_add_rmsnorm(md_ar_comm* comm, const void* partial, const void* resid, const void* weight,
                              void* out_h, void* out_y, int rows, int dim, float eps, int algo, md_stream_t stream);
 int md_ar_status(md_ar_comm* comm, int* status_host);
+int md_ar_status_async(md_ar_comm* comm, int* status_host_pinned, md_stream_t stream);
 int md_ar_destroy(md_ar_comm* comm);
 
 #ifdef __cplusplus

@@ -61,6 +61,19 @@ def _bind_state(backend, ent: _Captured):
         torch._foreach_copy_(dst, src)
 
 
+def _all_ranks_ok(backend, ok: bool) -> bool:
+    """True iff the capture succeeded on every rank of the back-end's tensor-parallel group (trivially `ok` without
+    one).  Collective over that group: every rank reaches it once per newly captured step."""
+    group = getattr(getattr(backend, "model", None), "process_group", None)
+    if group is None:
+        return ok
+    import torch.distributed as dist
+    dev = "cuda" if dist.get_backend(group) == "nccl" else "cpu"
+    t = torch.tensor([0 if ok else 1], dtype=torch.int32, device=dev)
+    dist.all_reduce(t, group=group)
+    return int(t.item()) == 0
+
+
 def run_captured(backend, key, fn, input_ids):
     kind = key[0]
     full_key = (key, tuple(input_ids.shape), tuple(getattr(backend, "paged_kv_indices").shape),
@@ -91,6 +104,7 @@ def run_captured(backend, key, fn, input_ids):
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
+        err = None
         try:
             # thread_local: the RCCL watchdog thread of torch.distributed polls hipEventQuery concurrently; in the
             # default "global" capture mode such a call from ANY thread invalidates the capture and kills the process
@@ -98,14 +112,21 @@ def run_captured(backend, key, fn, input_ids):
             with torch.cuda.graph(g, capture_error_mode="thread_local"):
                 ent.static_out = fn(ent.static_in)
         except Exception as e:  # noqa: BLE001 -- e.g. a collective this RCCL build cannot capture
-            # Capture executes nothing and the warm-up runs above are idempotent, so the step can still be run
-            # eagerly.  The failure is deterministic (same code on every rank), so all ranks of a TP group take
-            # this branch together.  Loud, once: silently running eager would misreport what was measured.
+            err = e
             torch.cuda.synchronize()
-            warnings.warn(f"[magicdec_amd] hipGraph capture of step {key} failed ({type(e).__name__}: {e}); "
-                          "this back-end continues WITHOUT graphs", RuntimeWarning, stacklevel=2)
+        # Under tensor parallelism every rank captures the same step at the same point of the same program, but a
+        # capture can fail on ONE rank only (an allocation, a watchdog race): a rank replaying a graph while another
+        # launches eagerly still issues the same collectives in the same order, yet the choice must not depend on
+        # luck -- the ranks agree on the outcome (one tiny all-reduce, outside any capture) and fall back together.
+        if not _all_ranks_ok(backend, err is None):
+            # Capture executes nothing and the warm-up runs above are idempotent, so the step can still be run
+            # eagerly.  Loud, once: silently running eager would misreport what was measured.
+            why = f"{type(err).__name__}: {err}" if err is not None else "it failed on another rank of the TP group"
+            warnings.warn(f"[magicdec_amd] hipGraph capture of step {key} failed ({why}); this back-end continues "
+                          "WITHOUT graphs on every rank", RuntimeWarning, stacklevel=2)
             backend._use_graphs = False
             backend._graphs.clear()
+            del g
             return fn(input_ids)
         ent.graph = g
         backend._graphs[full_key] = ent

@@ -14,7 +14,8 @@ available to the development box -- so on a real xGMI node `try_create` treats t
 (allocation, handle export, peer mapping) is agreed on collectively, then a self-test compares all-reduces of every
 algorithm with the bootstrap backend's (RCCL) results; any rank failing any stage makes ALL ranks fall back to RCCL,
 loudly.  A peer that goes missing later is never papered over: the kernel poisons its output with NaN and sets the
-status word, `check()` (called by the decode loops once per batch) raises."""
+status word; the decode loops read the status word with every iteration's flag read (`status_async`) and raise at
+the iteration it happened in, and `check(collective=True)` at the end of a batch makes every rank raise together."""
 from __future__ import annotations
 
 import ctypes
@@ -142,15 +143,37 @@ class OneShotAllReduce:
               "md_allreduce_add_rmsnorm")
         return h, y
 
-    def check(self):
+    def check(self, collective: bool = False):
         """Raise if any call since the last check gave up waiting for a peer (its output rows are NaN).
-        Synchronises the device: call it per batch, not per step."""
-        if self.status() != 0:
-            raise AllReduceTimeout(f"rank {self.rank}: an xGMI all-reduce timed out waiting for a peer; the affected "
-                                   "hidden states were poisoned with NaN -- this rank's results are invalid")
+        Synchronises the device.  collective=True (the decode loops' end-of-batch check; every rank of the group must
+        call it): the status words are max-reduced over the bootstrap backend first, so that all ranks raise together
+        instead of one rank raising while the others wait for it in their next collective."""
+        bad = self.status()
+        if collective and self.world > 1:
+            dev = "cuda" if dist.get_backend(self.group) == "nccl" else "cpu"
+            t = torch.tensor([bad], dtype=torch.int32, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+            bad = int(t.item())
+        if bad != 0:
+            raise AllReduceTimeout(f"rank {self.rank}: an xGMI all-reduce timed out waiting for a peer (on this rank or "
+                                   "another rank of its group); the affected hidden states were poisoned with NaN -- "
+                                   "the results are invalid")
+
+    def status_async(self):
+        """Queue a 4-byte copy of the status word into pinned host memory on the current stream and return the pinned
+        tensor: after the stream's next synchronisation `int(t[0]) != 0` means a time-out.  The decode loops piggyback
+        this on the one host read of an iteration (harness._read_flags), so a time-out stops the loop at the iteration
+        it happened in instead of iterating on NaN hidden states until the end of the batch."""
+        if getattr(self, "_status_host", None) is None:
+            self._status_host = torch.zeros(1, dtype=torch.int32).pin_memory()
+        check(self.lib.md_ar_status_async(self.comm, ctypes.c_void_p(self._status_host.data_ptr()),
+                                          ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)),
+              "md_ar_status_async")
+        return self._status_host
 
     def self_test(self) -> bool:
-        """Local verdict: a few all-reduces agree with the bootstrap backend's (different summation order, so a bf16
+        """Local verdict: all-reduces of every algorithm -- plain AND fused with the residual add + RMSNorm, the form the
+        decode path actually runs -- agree with the bootstrap backend's (different summation order, so a bf16
         tolerance) and no spin timed out.  Collective (all ranks must call it)."""
         dev = torch.device("cuda", torch.cuda.current_device())
         ok = True
@@ -165,6 +188,28 @@ class OneShotAllReduce:
                 torch.cuda.synchronize()
                 tol = 2.0 ** -6 * float(ref.float().abs().max()) + 1e-3
                 ok = ok and bool((y.float() - ref.float()).abs().max() <= tol) and bool(torch.isfinite(y.float()).all())
+        # the decode path runs the FUSED instantiations (Transformer._reduce_add_norm): validate them too, against the
+        # bootstrap backend's all-reduce followed by the add + RMSNorm kernel (h: bf16 tolerance of the summation order;
+        # y: the same tolerance relative to |y|)
+        from .. import ops
+        for k, (rows, dim) in enumerate(((64, 2048), (256, 4096))):
+            if rows * dim * 2 > self.max_bytes:
+                continue
+            for rep, algo in enumerate((ALGO_ONESHOT, ALGO_TWOSHOT, ALGO_ONESHOT, ALGO_TWOSHOT)):
+                g = torch.Generator(device=dev).manual_seed(5000 + 100 * k + 10 * rep + self.rank)
+                part = torch.randn(rows, dim, device=dev, generator=g, dtype=torch.float32).to(torch.bfloat16)
+                g2 = torch.Generator(device=dev).manual_seed(7000 + 100 * k + rep)        # same on every rank
+                resid = torch.randn(rows, dim, device=dev, generator=g2, dtype=torch.float32).to(torch.bfloat16)
+                w = (1.0 + 0.1 * torch.randn(dim, device=dev, generator=g2, dtype=torch.float32)).to(torch.bfloat16)
+                ref = part.clone()
+                dist.all_reduce(ref, group=self.group)
+                h_ref, y_ref = ops.add_rmsnorm(resid, ref, w, 1e-5)
+                h, y = self.all_reduce_add_rmsnorm(part, resid, w, 1e-5, algo)
+                torch.cuda.synchronize()
+                for got, want in ((h, h_ref), (y, y_ref)):
+                    tol = 2.0 ** -5 * float(want.float().abs().max()) + 1e-3
+                    ok = (ok and bool(torch.isfinite(got.float()).all())
+                          and bool((got.float() - want.float()).abs().max() <= tol))
         return ok and self.status() == 0
 
     def status(self) -> int:

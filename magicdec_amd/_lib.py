@@ -41,6 +41,7 @@ _SIGNATURES = {
     "md_allreduce": (c_int, [P, P, P, c_size_t, I, P]),
     "md_allreduce_add_rmsnorm": (c_int, [P, P, P, P, P, P, I, I, c_float, I, P]),
     "md_ar_status": (c_int, [P, P]),
+    "md_ar_status_async": (c_int, [P, P, P]),
     "md_ar_destroy": (c_int, [P]),
     "md_streaming_shift_append": (c_int, [P, P, L, L, P, I, I, I, I, I, I, I, I, P]),
     "md_streaming_rotate": (c_int, [P, P, I, I, I, I, I, I, P, I, P]),

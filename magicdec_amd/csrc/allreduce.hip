@@ -254,6 +254,14 @@ __global__ __launch_bounds__(kThreads) void allreduce_kernel(const ArDev c, cons
             u32x4 s[kMaxVecPerLane];
             if (!bad) {
                 reduce_row(row, nv, s);
+            } else {
+                // a peer's partial never arrived: the rows this rank owns are NaN for EVERYONE -- the peers gather
+                // them from `myres` in step 3c, and must not find the rows of two calls ago there
+                const u32x4 nan = {0x7fc07fc0u, 0x7fc07fc0u, 0x7fc07fc0u, 0x7fc07fc0u};
+#pragma unroll
+                for (int i = 0; i < kMaxVecPerLane; ++i) s[i] = nan;
+            }
+            {
                 const size_t base = (size_t)row * a.row_vecs;
 #pragma unroll
                 for (int i = 0; i < kMaxVecPerLane; ++i)
@@ -484,6 +492,16 @@ extern "C" int md_ar_status(md_ar_comm* c, int* status_host) {
         return MD_ERR_LAUNCH;
     }
     *status_host = (int)s;
+    return MD_OK;
+}
+
+extern "C" int md_ar_status_async(md_ar_comm* c, int* status_host_pinned, md_stream_t stream) {
+    MD_CHECK_ARG(c && status_host_pinned, "md_ar_status_async: null argument");
+    if (hipMemcpyAsync(status_host_pinned, &((Signal*)c->my_sig)->status, sizeof(uint32_t), hipMemcpyDeviceToHost,
+                       (hipStream_t)stream) != hipSuccess) {
+        md_set_error("md_ar_status_async: copy failed: %s", hipGetErrorString(hipGetLastError()));
+        return MD_ERR_LAUNCH;
+    }
     return MD_OK;
 }
 

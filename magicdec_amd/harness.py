@@ -59,14 +59,32 @@ def _sync(t):
         torch.cuda.synchronize(t.device)
 
 
-def _read_flags(st: LoopState):
-    """The one host read of an iteration: (terminal, next_double)."""
+def _read_flags(st: LoopState, collectives=()):
+    """The one host read of an iteration: (terminal, next_double).  With xGMI all-reduce communicators attached
+    (`collectives`, Engine/oneshot.py) their time-out status words ride on the same stream synchronisation, and a
+    time-out raises HERE -- at the iteration whose hidden states were poisoned, not at the end of the batch."""
     if st.flags.is_cuda:
         st.flags_host.copy_(st.flags, non_blocking=True)
+        status = [ar.status_async() for ar in collectives]
         torch.cuda.current_stream().synchronize()
+        for ar, s in zip(collectives, status):
+            if int(s[0]) != 0:
+                from .Engine.oneshot import AllReduceTimeout
+                raise AllReduceTimeout(f"rank {ar.rank}: an xGMI all-reduce timed out waiting for a peer during "
+                                       f"iteration {st.iters}; its hidden states were poisoned with NaN")
     else:
         st.flags_host.copy_(st.flags)
     return bool(st.flags_host[0]), bool(st.flags_host[1])
+
+
+def _collectives_of(*engines):
+    """The xGMI all-reduce communicators attached to the engines' models (tp.apply_tp, MAGICDEC_ONESHOT_AR=1)."""
+    out = []
+    for e in engines:
+        ar = getattr(getattr(e, "model", None), "_oneshot", None) if e is not None else None
+        if ar is not None and ar not in out:
+            out.append(ar)
+    return tuple(out)
 
 
 class PhaseTimers:
@@ -110,12 +128,10 @@ def warn_on_page_overflow(where):
 
 
 def check_collectives(*engines):
-    """Raise if an xGMI all-reduce of any engine timed out since the last check (its hidden states were poisoned with
-    NaN, Engine/oneshot.py): a rank must never carry on with a partial sum.  Once per batch (synchronises)."""
-    for e in engines:
-        ar = getattr(getattr(e, "model", None), "_oneshot", None) if e is not None else None
-        if ar is not None:
-            ar.check()
+    """End-of-batch check, collective over each communicator's group: raise on EVERY rank if an xGMI all-reduce of any
+    rank timed out (Engine/oneshot.py; the per-iteration read in _read_flags catches a rank's own time-outs earlier)."""
+    for ar in _collectives_of(*engines):
+        ar.check(collective=True)
 
 
 def _draft_round(step_fn, st: LoopState, gamma, next_double):
@@ -138,7 +154,7 @@ def _iterate(engine, draft, st: LoopState, key, body, forced, timers):
     else:
         body(forced)
     st.iters += 1
-    return _read_flags(st)
+    return _read_flags(st, _collectives_of(engine, draft))
 
 
 def longspec_iteration(engine, draft, st: LoopState, gamma, eot_1, eot_2, max_nodes, next_double,

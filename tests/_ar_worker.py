@@ -38,6 +38,10 @@ def expected_fused(world, rows, dim, seed, eps):
 
 def main():
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    # the expected values are computed on the host between kernel launches: on the GPU boxes' 256-core hosts torch's
+    # default intra-op pool (x 3 processes) can stall a small CPU op for seconds -- longer than the kernels' 2 s
+    # bounded spin, which then (correctly) reports a missing peer (seen once: GPU call r03_call1)
+    torch.set_num_threads(4)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.cuda.set_device(0)
     from magicdec_amd.Engine import oneshot
@@ -67,6 +71,7 @@ def main():
             call += 1
             ins, want = expected(world, n, call)
             t = ins[rank].to(dev)
+            dist.barrier()
             ar.all_reduce_(t, algos[rep])
             got = t.cpu()
             assert torch.equal(got.view(torch.int16), want.view(torch.int16)), (n, rep, "eager mismatch")
@@ -78,6 +83,7 @@ def main():
         for algo in algos:
             call += 1
             ins, x, w, h_want, y_want = expected_fused(world, rows, dim, call, 1e-5)
+            dist.barrier()         # host-side skew (the CPU reference above) must not eat into the kernels' spin bound
             h, y = ar.all_reduce_add_rmsnorm(ins[rank].contiguous().to(dev), x.to(dev), w.to(dev), 1e-5, algo)
             h, y = h.cpu(), y.cpu()
             if not torch.equal(h.view(torch.int16), h_want.view(torch.int16)):

@@ -29,10 +29,14 @@ if line is not None:
 
 
 @pytest.mark.parametrize("world,draft_tp,workload", [(1, 4, "tiny"), (2, 4, "tiny"), (2, 1, "tiny"),
-                                                    (1, 4, "tiny-selfspec-snapkv"), (2, 1, "tiny-longspec-stream")])
+                                                    (1, 4, "tiny-selfspec-snapkv"), (2, 1, "tiny-longspec-stream"),
+                                                    (4, 2, "tiny-kh8"), (8, 4, "tiny-kh8")])
 def test_bench_control_flow_on_cpu(world, draft_tp, workload):
     """(2,1): the draft runs on rank 0 only -> rank 1 has no draft model and receives the tokens by broadcast, the
-    8-GPU layout of the reference's README (target TP8, draft TP4) in miniature."""
+    8-GPU layout of the reference's README (target TP8, draft TP4) in miniature.  (4,2) and (8,4) on "tiny-kh8" (eight
+    kv heads) ARE that layout at 4 and 8 ranks: one kv head per rank at TP8, the draft on the first half of the ranks,
+    the other half idle during drafting and fed by the token broadcast -- the exact launch the driver's scaling run
+    makes (`--gpus 4` / `--gpus 8`), over gloo."""
     out = tempfile.mkdtemp(prefix="md_bench_")
     script = os.path.join(out, "w.py")
     Path(script).write_text(WORKER)
@@ -41,7 +45,7 @@ def test_bench_control_flow_on_cpu(world, draft_tp, workload):
     for r in range(world):
         env = dict(os.environ, LOCAL_RANK=str(r), LOCAL_WORLD_SIZE=str(world), RANK=str(r), WORLD_SIZE=str(world),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), MD_ROOT=str(ROOT), MD_OUT=os.path.join(out, "line.json"), MD_DRAFT_TP=str(draft_tp),
-                   MD_WORKLOAD=workload, OMP_NUM_THREADS="2")
+                   MD_WORKLOAD=workload, OMP_NUM_THREADS="2" if world <= 2 else "1")
         procs.append(subprocess.Popen([sys.executable, script], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
                                       cwd=out))
     logs = [p.communicate(timeout=1200)[0].decode() for p in procs]
