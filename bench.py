@@ -100,31 +100,47 @@ def _sync(dev):
 
 
 class AttnTimer:
-    """HIP events around every md_paged_attn launch of the verify pass, recorded on the launching stream."""
+    """Duration of every verify-attention launch (md_paged_attn with gamma+1 query rows per request) of an eager pass,
+    taken from the kernel's OWN begin / end timestamps (md_debug_attn_timing: hipExtLaunchKernel start / stop events on
+    the launching stream) -- the quantity a rocprofv3 kernel trace reports as the kernel's duration, so that
+    roofline.avg_launch_ms can be checked against profiles/*_kernel_stats.csv.  (Stream events recorded around a launch
+    also see the dispatch overhead: +1.2 % at this kernel's 0.62 ms, r03_call1.)"""
 
     def __init__(self, dev="cuda"):
-        self.pairs = []
-        self.enabled = False
+        self.ms = []
         self.cuda = torch.device(dev).type == "cuda"
         self.n_verify = 0      # only launches with this many query rows per request (gamma+1) are timed
+        self._on = False
 
-    def wrap(self, model):
-        timer = self
-        orig = model._attend
+    @property
+    def enabled(self):
+        return self._on
 
-        def timed(q_rot, cache, qo_indptr, tab, n, *args, **kw):
-            if not (timer.enabled and timer.cuda and n == timer.n_verify):
-                return orig(q_rot, cache, qo_indptr, tab, n, *args, **kw)
-            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            s.record()
-            o = orig(q_rot, cache, qo_indptr, tab, n, *args, **kw)
-            e.record()
-            timer.pairs.append((s, e))
-            return o
-        model._attend = timed
+    @enabled.setter
+    def enabled(self, on):
+        self._on = bool(on)
+        if self.cuda:
+            from magicdec_amd import _lib
+            lib = _lib.load()
+            if not on:
+                self.collect()
+            lib.md_debug_attn_timing(1 if on else 0, self.n_verify)
+
+    def collect(self):
+        if self.cuda:
+            import ctypes
+            from magicdec_amd import _lib
+            buf = (ctypes.c_float * 4096)()
+            n = _lib.load().md_debug_attn_timing_read(buf, 4096)
+            self.ms.extend(buf[:n])
+
+    def clear(self):
+        self.collect()
+        self.ms = []
 
     def mean_ms(self):
-        return sum(s.elapsed_time(e) for s, e in self.pairs) / max(len(self.pairs), 1)
+        self.collect()
+        return sum(self.ms) / max(len(self.ms), 1)
 
 
 def truncated_geometric(alpha, gamma, shape, gen, device):
@@ -248,7 +264,6 @@ def run(args, dev):
             draft.compile()
     timer = AttnTimer(dev)
     timer.n_verify = G + 1
-    timer.wrap(engine.model)
     t_load = time.time() - t_load
 
     # synthetic PG-19-shaped batch: uniform token ids, BOS in column 0 (Data/data_converter.py:54), seed 123
@@ -323,7 +338,7 @@ def run(args, dev):
                 restore()
                 nd = False
         tokens.zero_()
-        timer.pairs.clear()
+        timer.clear()
         timer.enabled = True
         barrier()
         t0 = time.perf_counter()
@@ -383,7 +398,7 @@ def run(args, dev):
         run_spec(1, min(args.steps, 8), forced)
         engine._use_graphs = was
     attn_ms = timer.mean_ms()
-    n_attn = len(timer.pairs)
+    n_attn = len(timer.ms)
     dt_meas, tok_meas = run_spec(min(args.warmup, 2), max(args.steps // 4, 4), None)
     meas_steps = max(args.steps // 4, 4)
     # sensitivity of the headline to the assumed acceptance rate: the same loop replayed at other alphas (short runs)
@@ -455,8 +470,6 @@ def run(args, dev):
                    "acceptance": f"fixed replay alpha={args.alpha} (E[tokens/iter]={tok_replay / args.steps / B:.3f})",
                    "weights": "seeded random init (no checkpoints on the box)",
                    "hip_graphs": bool(engine._use_graphs),
-                   "iteration_graph": bool(getattr(engine, "_iter_graphs", None) is not None
-                                           and any(b.graph is not None for b in engine._iter_graphs.bodies.values())),
                    "gemm": gemm_mode,
                    **({"emulated_tp_rank0_of": emu} if emu > 1 else {}),
                    "allreduce": (None if not use_tp else
@@ -474,11 +487,15 @@ def run(args, dev):
                                     "ms_per_step": round(dt_meas / meas_steps * 1e3, 4)},
         "prefill_s": round(t_pf, 2), "load_s": round(t_load, 2),
         "roofline": {"kernel": f"paged_attn_kernel<{D},{1 if (G + 1) * (H_loc // KH_loc) <= 16 else 2},"
-                               f"{'true' if args.kv_dtype == 'fp8' else 'false'}> (verify attention, md_paged_attn)",
+                               f"{'true' if args.kv_dtype == 'fp8' else 'false'}> (verify attention, md_paged_attn, "
+                               f"{kv_layout} pages)",
                      "bound": "hbm",
                      "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
-                     "bytes_per_launch": attn_bytes, "avg_launch_ms": round(attn_ms, 4), "launches_timed": n_attn},
+                     "bytes_per_launch": attn_bytes, "avg_launch_ms": round(attn_ms, 4), "launches_timed": n_attn,
+                     "timing": "kernel begin/end timestamps of every verify-attention launch of an eager pass "
+                               "(hipExtLaunchKernel start/stop events on the launching stream) = the duration a "
+                               "rocprofv3 kernel trace reports"},
     }
     if rank == 0 and not args.no_cpu_baseline and world == 1 and not selfspec:
         line["cpu_baseline"] = cpu_baseline(tgt_name, drf_name, S, BUDGET, G, args.alpha)
@@ -728,6 +745,7 @@ def cpu_baseline(tgt_name, drf_name, S, budget, gamma, alpha, Bc=4):
     t_k6 = time.perf_counter() - t0
     nb_k6 = S * cfg_d.n_local_heads * cfg_d.head_dim * 2 + 2 * budget * cfg_d.n_local_heads * cfg_d.head_dim * 2
 
+    cfg1 = cpu_baseline_cfg1()
     iter_s = gamma * (n_d * tl_d + th_d + te_d) + (n_t * tl_t + th_t + te_t)
     e_tok = sum(alpha ** j for j in range(gamma + 1))
     return {"value": round(Bc * e_tok / iter_s, 4), "unit": "tokens/s", "cores": ncores,
@@ -741,7 +759,40 @@ def cpu_baseline(tgt_name, drf_name, S, budget, gamma, alpha, Bc=4):
             "micro_GBps": {"K1_verify_attention": round(nb_t / ta_t / 1e9, 2),
                            "K2_draft_attention": round(nb_d / ta_d / 1e9, 3),
                            "K6_snapkv_select_one_request": round(nb_k6 / t_k6 / 1e9, 3)},
+            "cfg1_end_to_end": cfg1,
             "wall_s": round(time.perf_counter() - t_all, 1)}
+
+
+def cpu_baseline_cfg1(prefix=129, max_len=256):
+    """BASELINE.json configs[0] END TO END on the host cores (the reference's own
+    CPU-runnable case): the reference's "68m" model entry (Engine/SnapKV/model.py:67: MHA, 12 heads, dim 768, 2 layers,
+    vocab 32000; seeded random weights), B = 1, prefix 129, greedy autoregressive decode to 256 positions with the
+    loop of tests/baseline_benchmark.py:72-90 -- the whole run of the oracle (oracle/harness_ref.baseline_batch:
+    prefill + 126 decode steps), not an extrapolation.  tokens/s is generated tokens over the decode loop's wall time,
+    as the script reports it."""
+    from magicdec_amd.Engine.model_core import ModelArgs
+    from oracle import harness_ref as hr
+    from oracle import magicdec_ref as mr
+    a = ModelArgs.from_name("68m")
+    cfg = mr.RefConfig(n_layer=a.n_layer, n_head=a.n_head, n_local_heads=a.n_local_heads, dim=a.dim,
+                       intermediate_size=a.intermediate_size, vocab_size=a.vocab_size, rope_base=a.rope_base)
+    sd = mr.init_state_dict(cfg, 68)
+    eng = mr.RefEngine("target", cfg, sd, 1, max_len)
+    g = torch.Generator().manual_seed(123)
+    ids = torch.randint(4, cfg.vocab_size, (1, prefix), generator=g)
+    ids[:, 0] = 1
+    t0 = time.perf_counter()
+    first = eng.encode(ids)[:, -1:]
+    t_prefill = time.perf_counter() - t0
+    steps, nt = 0, first
+    t0 = time.perf_counter()
+    while prefix + 1 + steps < max_len:
+        nt = eng.inference(nt.clone())
+        steps += 1
+    t_decode = time.perf_counter() - t0
+    return {"workload": f"cfg1: llama-68m (reference '68m' entry, MHA) autoregressive, B=1 prefix={prefix} -> {max_len}",
+            "tokens_per_s": round(steps / t_decode, 2), "decode_steps": steps, "decode_s": round(t_decode, 3),
+            "prefill_s": round(t_prefill, 3), "kind": "port (the oracle run end to end)"}
 
 
 if __name__ == "__main__":

@@ -141,6 +141,13 @@ size_t md_paged_attn_workspace_bytes(int B, int n_max, int H, int KH, int D,
 /* development knob (kernel tuning sweeps only): target number of workgroups of the split-KV decomposition;
  * n <= 0 restores the default (256 = one per CU). Host, not thread-safe. */
 void md_debug_set_attn_target_wgs(int n);
+/* measurement (bench.py's roofline): while enabled, every decode / verify launch of md_paged_attn with n_max ==
+ * n_rows query rows per request is bracketed by the kernel's OWN begin / end timestamps (hipExtLaunchKernel start /
+ * stop events = what a rocprofv3 kernel trace reports; stream events around a launch also see the dispatch overhead).
+ * md_debug_attn_timing_read synchronises the device, writes the durations in ms (launch order, at most `cap`) and
+ * returns their count; the list is cleared.  Eager launches only (not inside a graph capture). */
+void md_debug_attn_timing(int enable, int n_rows);
+int md_debug_attn_timing_read(float* ms_out, int cap);
 int md_paged_attn(const void* q, int64_t q_row_stride, const void* cache, void* out,
                   const int32_t* qo_indptr, const int32_t* page_indices,
                   const int32_t* page_indptr, const int32_t* last_page_len, int B, int n_max,

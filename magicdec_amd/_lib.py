@@ -30,6 +30,8 @@ _SIGNATURES = {
     "md_rope_append": (c_int, [P, P, P, L, L, L, P, P, P, I, I, I, I, I, P, I, P, P, P, P, P, P, P, P, I, I, P, P, P]),
     "md_paged_attn_workspace_bytes": (c_size_t, [I, I, I, I, I, I, I]),
     "md_debug_set_attn_target_wgs": (None, [I]),
+    "md_debug_attn_timing": (None, [I, I]),
+    "md_debug_attn_timing_read": (c_int, [P, I]),
     "md_paged_attn": (c_int, [P, L, P, P, P, P, P, P, I, I, I, I, I, I, I, c_float, I, I, P, P, P, c_size_t, P]),
     "md_snapkv_workspace_bytes": (c_size_t, [I, I, I, I, I]),
     "md_snapkv_scores_offset": (c_size_t, [I, I, I, I, I]),

@@ -34,6 +34,10 @@
 
 #include "md_common.h"
 
+#include <hip/hip_ext.h>
+
+#include <vector>
+
 namespace {
 
 struct AttnParams {
@@ -840,6 +844,14 @@ struct AttnPlan {
 // per-workgroup prologue/epilogue and the partial-result round trip dominate once a wave owns < ~30 tiles
 int g_target_wgs = 256;  // dev knob: md_debug_set_attn_target_wgs
 
+// measurement mode of the decode / verify kernel (bench.py's roofline): see md_debug_attn_timing
+struct TimedLaunch { hipEvent_t e0, e1; };
+constexpr size_t kMaxTimed = 4096;
+bool g_time_launches = false;
+int g_time_rows = 0;
+bool g_time_this = false;  // set by md_paged_attn for the launch it is about to make
+std::vector<TimedLaunch> g_timed;
+
 AttnPlan make_plan(int B, int n_max, int H, int KH, int max_pages, int page_size, bool fp8) {
     AttnPlan pl;
     pl.nw = 4;
@@ -887,6 +899,17 @@ int launch_attn(const AttnParams& p, int grid, hipStream_t st) {
             return MD_ERR_LAUNCH;
         }
     }
+    if (g_time_this && g_timed.size() < kMaxTimed) {
+        // measurement mode (md_debug_attn_timing): the kernel's own begin / end timestamps -- what a rocprofv3 kernel
+        // trace reports -- instead of stream events around the launch, which also see the dispatch overhead
+        hipEvent_t e0, e1;
+        if (hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess) {
+            hipExtLaunchKernelGGL((paged_attn_kernel<D, QT, FP8>), dim3(grid), dim3(256), lds, st, e0, e1, 0, p);
+            g_timed.push_back({e0, e1});
+            MD_CHECK_LAUNCH("md_paged_attn");
+            return MD_OK;
+        }
+    }
     hipLaunchKernelGGL((paged_attn_kernel<D, QT, FP8>), dim3(grid), dim3(256), lds, st, p);
     MD_CHECK_LAUNCH("md_paged_attn");
     return MD_OK;
@@ -906,6 +929,24 @@ int launch_prefill(const AttnParams& p, int grid, int nw, hipStream_t st) {
 }  // namespace
 
 extern "C" void md_debug_set_attn_target_wgs(int n) { g_target_wgs = n > 0 ? n : 256; }
+
+extern "C" void md_debug_attn_timing(int enable, int n_rows) {
+    g_time_launches = enable != 0;
+    g_time_rows = n_rows;
+}
+
+extern "C" int md_debug_attn_timing_read(float* ms_out, int cap) {
+    (void)hipDeviceSynchronize();
+    int n = 0;
+    for (auto& t : g_timed) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, t.e0, t.e1) == hipSuccess && ms_out && n < cap) ms_out[n++] = ms;
+        (void)hipEventDestroy(t.e0);
+        (void)hipEventDestroy(t.e1);
+    }
+    g_timed.clear();
+    return n;
+}
 
 extern "C" size_t md_paged_attn_workspace_bytes(int B, int n_max, int H, int KH, int D,
                                                 int max_pages_per_req, int page_size) {
@@ -983,6 +1024,7 @@ extern "C" int md_paged_attn(const void* q, int64_t q_row_stride, const void* ca
     hipStream_t st = (hipStream_t)stream;
     const int npairs8 = (B * KH + 7) / 8 * 8;
     const int grid = npairs8 * pl.n_qgroups * pl.nsplit;
+    g_time_this = g_time_launches && n_max == g_time_rows;
     int rc;
 #define MD_ATTN_DISPATCH(DD, FP)                                                                                  \
     (pl.splitq ? (pl.qt == 2 ? launch_prefill<DD, 2, FP>(p, grid, pl.nw, st)                                         \

@@ -145,14 +145,12 @@ def _draft_round(step_fn, st: LoopState, gamma, next_double):
             st.tokens_buffer[:, i + 1:i + 2] = step_fn(st.tokens_buffer[:, i].view(-1, 1), None)
 
 
-def _iterate(engine, draft, st: LoopState, key, body, forced, timers):
-    """Runs one iteration body: as ONE hipGraph when the back-ends were compile()d (Engine/itergraph.py), else (or
-    with per-phase timers, which need host synchronisation inside the iteration) launch by launch."""
-    from .Engine import itergraph
-    if timers is None and itergraph.enabled(engine, draft):
-        itergraph.get(engine, draft).run(key, st, body, forced)
-    else:
-        body(forced)
+def _iterate(engine, draft, st: LoopState, body, forced):
+    """Runs one iteration body (each decode step inside it is one hipGraph replay when the back-ends were compile()d)
+    and makes the iteration's one host read.  (A whole-iteration graph was built and measured in rounds 2 and 3: 31.6
+    vs 31.6 ms at TP1, 8.77 vs 8.85 ms for a TP8 rank's compute -- the host already runs ahead of the GPU -- and was
+    removed: profiles/r02_ab_iteration_graph.txt, profiles/r03_ab_iteration_graph_tp8.txt.)"""
+    body(forced)
     st.iters += 1
     return _read_flags(st, _collectives_of(engine, draft))
 
@@ -185,9 +183,7 @@ def longspec_iteration(engine, draft, st: LoopState, gamma, eot_1, eot_2, max_no
                             draft.paged_kv_last_page_len if draft is not None else None, gamma,
                             gamma, gamma, eot_1, eot_2, max_nodes, st.accept_nums, st.bonus, st.double_buffer,
                             st.cachelens_update, st.flags)
-    key = ("longspec", bool(next_double), forced_accept is not None, gamma, int(eot_1), int(eot_2), int(max_nodes),
-           bcast is not None)
-    res = _iterate(engine, draft, st, key, body, forced_accept, timers)
+    res = _iterate(engine, draft, st, body, forced_accept)
     if timers is not None:
         timers.lap("verify_loop")
     return res
@@ -221,9 +217,7 @@ def selfspec_iteration(engine, st: LoopState, gamma, eot_1, eot_2, max_nodes, ne
                                 engine.paged_kv_last_page_len, engine.draft_cachelens,
                                 engine.draft_paged_kv_last_page_len, gamma, gamma + 1, gamma + 1, eot_1, eot_2,
                                 max_nodes, st.accept_nums, st.bonus, None, None, st.flags)
-    key = ("selfspec", bool(streaming), bool(next_double) and bool(streaming), forced_accept is not None, gamma,
-           int(eot_1), int(eot_2), int(max_nodes))
-    res = _iterate(engine, None, st, key, body, forced_accept, timers)
+    res = _iterate(engine, None, st, body, forced_accept)
     if timers is not None:
         timers.lap("verify_loop")
     return res
