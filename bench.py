@@ -81,10 +81,10 @@ def parse():
                     help="full-context KV cache storage (fp8 = OCP e4m3fn, BASELINE configs[4]; default bf16 = the "
                          "reference's)")
     ap.add_argument("--kv-layout", default="HND", choices=["NHD", "HND"],
-                    help="page layout of the full-context KV cache: HND (default here) keeps the rows of a kv head "
-                         "contiguous -- same tokens, verify attention 85 %% instead of 82 %% of the HBM peak (bf16), 81 %% "
-                         "instead of 71 %% (fp8), profiles/r02_layout_ab.txt; NHD = the reference's flashinfer layout and "
-                         "the Engine API's default (DESIGN.md section 3.1)")
+                    help="page layout of the full-context KV cache: HND (the Engine API's default) keeps the rows of a "
+                         "kv head contiguous -- same tokens, verify attention 85 %% instead of 82 %% of the HBM peak "
+                         "(bf16), 81 %% instead of 71 %% (fp8), profiles/r02_layout_ab.txt; NHD = the reference's "
+                         "flashinfer layout (DESIGN.md section 3.1)")
     ap.add_argument("--draft-tp", type=int, default=4, help="size of the draft sub-group (reference README: 4 of 8)")
     ap.add_argument("--pmc", dest="pmc", action="store_true", default=None,
                     help="measure roofline.traffic live: two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of the "

@@ -248,6 +248,53 @@ int md_linear(const void* x, int64_t ldx, const void* w, int w_dtype, int w_pack
               size_t workspace_bytes, md_stream_t stream);
 
 /* ------------------------------------------------------------------------
+ * K8b  fused small-problem linear: a linear of a decode / verify step TOGETHER with the op that consumes its output,
+ *      one launch (csrc/tilegemm.hip; no split-K across workgroups, no workspace, deterministic)
+ *     reference: Engine/SnapKV/model.py:322-336 (wqkv -> apply_rope -> update_kv), :260-278 (h = x + attention(...),
+ *                out = h + feed_forward(...)), :451-455 (w2(silu(w1 x) * w3 x))
+ * out = epilogue(x[M][K] . W[N][K]^T + bias), W in the streaming layout of md_linear (w_packed = 1, bf16), M <= 256,
+ * K % 128 == 0, N % 32 == 0.  Epilogues (the reference's rounding points: the linear's output is rounded to bf16 first):
+ *   MD_FL_NONE         out[M][N]   = bf16(acc + bias)
+ *   MD_FL_SWIGLU       out[M][N/2] = bf16(bf16(silu(bf16(h1))) * bf16(h3)); W packed for MD_EPI_SWIGLU, no bias
+ *   MD_FL_RESID        out[M][N]   = bf16(resid + bf16(acc + bias))                 (the bf16 residual add)
+ *   MD_FL_ROPE_APPEND  N = (H + 2 KH) * D fused qkv rows [q; k; v]: q columns -> interleaved RoPE -> out = q_rot
+ *                      [M][H*D] (contiguous); k columns -> RoPE -> paged cache; v columns -> paged cache.  Request b
+ *                      owns rows [b * rows_per_req, (b+1) * rows_per_req) (uniform append, what a decode step has);
+ *                      row j of request b has RoPE position offsets[b] + j and cache position len_b - rows_per_req + j
+ *                      (page table already advanced, as md_rope_append); kv_dtype / scales / cache2 as md_rope_append.
+ *                      Results are bit-identical to md_linear_fused(MD_FL_NONE) followed by md_rope_append.
+ * ---------------------------------------------------------------------- */
+#define MD_FL_NONE 0
+#define MD_FL_SWIGLU 1
+#define MD_FL_RESID 2
+#define MD_FL_ROPE_APPEND 3
+typedef struct md_fused_linear_args {
+    const void* x;            /* [M][K] bf16, row stride ldx (elements) */
+    const void* w_packed;     /* streaming layout (md_linear, w_packed = 1) */
+    const void* bias;         /* bf16 [N] or NULL */
+    void* out;                /* row stride ldo */
+    const void* resid;        /* MD_FL_RESID: bf16 [M][N], row stride ldr */
+    int64_t ldx, ldo, ldr;
+    int M, N, K, epilogue;
+    /* MD_FL_ROPE_APPEND */
+    int H, KH, D, rows_per_req, max_pos, page_size, kv_dtype;
+    const int32_t* offsets;   /* [M / rows_per_req] RoPE position of each request's first row */
+    const float* cos_sin;     /* [max_pos][D/2][2] fp32 table (md_rope_fill_table_host) */
+    void* cache;
+    const int32_t* page_indices;
+    const int32_t* page_indptr;
+    const int32_t* last_page_len;
+    void* cache2;             /* optional second cache (bf16, NHD) or NULL */
+    const int32_t* page_indices2;
+    const int32_t* page_indptr2;
+    const int32_t* last_page_len2;
+    const float* k_scale;     /* fp8 pages: per-kv-head scales */
+    const float* v_scale;
+} md_fused_linear_args;
+int md_linear_fused_supported(int M, int N, int K, int epilogue);
+int md_linear_fused(const md_fused_linear_args* args, md_stream_t stream);
+
+/* ------------------------------------------------------------------------
  * K10  argmax over a vocab shard / TP merge
  *     reference: Engine/SnapKV/model.py:175-188
  * argmax: per row, max bf16 logit and its lowest index (+index_offset).

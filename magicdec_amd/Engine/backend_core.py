@@ -27,11 +27,15 @@ CHUNK = 128        # Engine/SnapKV/backend.py:236
 
 
 def default_kv_layout():
-    """Page layout of the full-context cache when setup_caches() is not told one: the reference's "NHD"
-    (Engine/SnapKV/backend.py:30) unless MAGICDEC_KV_LAYOUT=HND.  Tokens are identical either way (the layout moves
-    bytes, not arithmetic); HND reads the verify stream in longer runs."""
+    """Page layout of the full-context cache when setup_caches() is not told one: "HND" (rows of one kv head contiguous
+    inside a page: the verify step's stream is read in 128-row runs, 85 % instead of 82 % of the HBM peak in bf16, 81 %
+    instead of 71 % in fp8 -- DESIGN.md section 3.1) unless MAGICDEC_KV_LAYOUT=NHD asks for the reference's flashinfer
+    layout (Engine/SnapKV/backend.py:30).  The layout is internal to the Engine API (the harness never touches the
+    cache tensors) and moves bytes, not arithmetic: every kernel's output is bit-identical between the two
+    (tests/test_gpu_hnd.py), and the whole GPU suite is green under either default (profiles/r03_hnd_suite_summary.txt).
+    The mylib::* operator boundary (magicdec_amd/mylib_ops.py) keeps the reference's NHD signature default."""
     import os
-    v = os.environ.get("MAGICDEC_KV_LAYOUT", "NHD").upper()
+    v = os.environ.get("MAGICDEC_KV_LAYOUT", "HND").upper()
     if v not in ("NHD", "HND"):
         raise ValueError(f"MAGICDEC_KV_LAYOUT must be NHD or HND, got {v!r}")
     return v

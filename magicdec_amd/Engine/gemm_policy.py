@@ -11,14 +11,24 @@ every decode / verify shape of the BASELINE models timed on both, weights cycled
     split-K combine of md_linear costs a second launch) and everything at M = 256 with K <= 4096 (there the product is
     MFMA / LDS bound, not HBM bound: a 256-row activation slab has to be re-read per 128 output columns).
 
-A weight that md_linear will serve is re-packed once at setup_caches (Transformer._pack_weights); the row-major copy
-stays for the prefill-sized products.  MAGICDEC_GEMM=hip forces md_linear wherever it supports the shape (packing
-everything), MAGICDEC_GEMM=lib forces the library (the A/B switch)."""
+  * round 3: the LAUNCH-BOUND small products (every linear of the 1B draft model, every tensor-parallel shard, the
+    narrow projections of an 8B step) go to md_linear_fused (csrc/tilegemm.hip): one launch for the product AND the op
+    behind it (rope+append, residual add, SiLU*mul), no split-K combine, no partial sums in HBM.
+
+A weight a hand-written kernel will serve is re-packed once at setup_caches (Transformer._pack_weights); the row-major
+copy stays for the prefill-sized products.  MAGICDEC_GEMM=hip forces md_linear wherever it supports the shape,
+MAGICDEC_GEMM=lib forces the library, MAGICDEC_FUSED=0/1 switches md_linear_fused off / on everywhere (the A/B
+switches)."""
 import os
 
 _MODE = os.environ.get("MAGICDEC_GEMM", "auto")
+_FUSED = os.environ.get("MAGICDEC_FUSED", "auto")     # "0": never md_linear_fused, "1": wherever it supports the shape
 MIN_STREAM_BYTES = 60e6        # bf16 weight bytes of one call above which the streaming kernel wins at M <= 64
 MIN_STREAM_BYTES_M128 = 100e6
+# md_linear_fused reads a weight tile once per 32-row M tile (through L2) and the activations once per weight tile: it
+# is the launch-bound regime's kernel.  Rule (tools/fused_bench.py A/B, profiles/r03_fused_ab.txt): take it while the
+# bytes its workgroups pull on chip, m_tiles x weight bytes, stay below FUSED_MAX_L2_BYTES
+FUSED_MAX_L2_BYTES = 150e6
 
 
 def set_mode(mode: str):
@@ -27,15 +37,36 @@ def set_mode(mode: str):
     _MODE = mode
 
 
+def set_fused(mode: str):
+    global _FUSED
+    assert mode in ("auto", "0", "1")
+    _FUSED = mode
+
+
 def mode() -> str:
     return _MODE
 
 
+def fused_mode() -> str:
+    return _FUSED
+
+
 def want_packed(N: int, K: int) -> bool:
-    """Re-pack this weight into the streaming layout at load time?"""
+    """Re-pack this weight into the streaming layout at load time?  Every linear either hand-written kernel may serve:
+    md_linear takes the long streams, md_linear_fused the small products (any bf16 weight with K % 128 == 0)."""
     if _MODE == "lib" or K % 128:
         return False
-    return _MODE == "hip" or N * K * 2 >= MIN_STREAM_BYTES
+    if _MODE == "hip" or N * K * 2 >= MIN_STREAM_BYTES:
+        return True
+    return _FUSED != "0" and N % 32 == 0
+
+
+def use_fused(M: int, N: int, K: int) -> bool:
+    if _MODE == "lib" or _FUSED == "0" or M > 256 or K % 128 or N % 32:
+        return False
+    if _FUSED == "1":
+        return True
+    return ((M + 31) // 32) * N * K * 2 <= FUSED_MAX_L2_BYTES
 
 
 def use_skinny(M: int, N: int, K: int, swiglu: bool, int8: bool, packed: bool) -> bool:
@@ -51,3 +82,11 @@ def use_skinny(M: int, N: int, K: int, swiglu: bool, int8: bool, packed: bool) -
     if M <= 128:
         return nbytes >= MIN_STREAM_BYTES_M128
     return K >= 8192 and nbytes >= MIN_STREAM_BYTES_M128
+
+
+def choose(M: int, N: int, K: int, swiglu: bool, int8: bool, packed: bool) -> str:
+    """"fused" (md_linear_fused), "skinny" (md_linear) or "lib" (hipBLASLt) for one linear of a step."""
+    if packed and not int8 and use_fused(M, N, K) and not (_FUSED == "auto" and use_skinny(M, N, K, swiglu, int8, packed)
+                                                           and N * K * 2 >= MIN_STREAM_BYTES):
+        return "fused"
+    return "skinny" if use_skinny(M, N, K, swiglu, int8, packed) else "lib"

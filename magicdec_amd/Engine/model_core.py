@@ -310,16 +310,21 @@ class Transformer(nn.Module):
         self._pack_weights()
 
     def _pack_weights(self):
-        """Streaming-layout copies (ops.PackedWeight) of the weights md_linear serves in decode / verify steps
-        (Engine/gemm_policy.py); keyed by the id of the row-major tensor the step would otherwise use."""
+        """Streaming-layout copies (ops.PackedWeight) of the weights the hand-written GEMMs serve in decode / verify
+        steps -- md_linear for the long weight streams, md_linear_fused for the launch-bound small products
+        (Engine/gemm_policy.py); keyed by the id of the row-major tensor the step would otherwise use.  The row-major
+        tensors stay for the prefill-sized library GEMMs; the extra bytes are reported once (`packed_bytes`)."""
         from .gemm_policy import want_packed
         self._packed = {}
+        self.packed_bytes = 0
         if not self.output.weight.is_cuda:
             return
 
         def pack(w, swiglu=False):
             if want_packed(w.shape[0], w.shape[1]):
-                self._packed[id(w)] = ops.PackedWeight(w.data if isinstance(w, nn.Parameter) else w, swiglu=swiglu)
+                pw = ops.PackedWeight(w.data if isinstance(w, nn.Parameter) else w, swiglu=swiglu)
+                self._packed[id(w)] = pw
+                self.packed_bytes += pw.data.numel() * pw.data.element_size()
         for i, b in enumerate(self.layers):
             pack(self._w13[i], swiglu=True)
             pack(b.attention.wqkv.weight)
@@ -340,11 +345,15 @@ class Transformer(nn.Module):
                 dist.all_reduce(y, group=group)
         return y
 
-    def _linear(self, x2d, lin, swiglu_w13=None):
-        """One linear of a step: the hand-written weight-streaming skinny GEMM (md_linear, csrc/gemm.hip) for the
-        decode / verify shapes it wins on (Engine/gemm_policy.py, measured A/B against hipBLASLt), the library GEMM
-        otherwise (prefill-sized M).  `swiglu_w13 = (w13, s13)`: the fused w1|w3 product with the SiLU*mul epilogue."""
-        from .gemm_policy import use_skinny
+    def _linear(self, x2d, lin, swiglu_w13=None, resid=None):
+        """One linear of a step.  Three implementations, chosen per shape by the measured rules of
+        Engine/gemm_policy.py: md_linear_fused (csrc/tilegemm.hip: the launch-bound small products -- draft-model
+        linears, tensor-parallel shards -- in one launch together with their epilogue), md_linear (csrc/gemm.hip: the
+        long weight streams, split-K + combine) or the library GEMM (prefill-sized M, and whatever the A/B gave it).
+        `swiglu_w13 = (w13, s13)`: the fused w1|w3 product with the SiLU*mul epilogue.
+        `resid`: return bf16(resid + linear) instead (the residual add of the block; only honoured by the fused
+        kernel -- callers check `_fusable_resid` first)."""
+        from .gemm_policy import choose
         if swiglu_w13 is not None:
             w, scales, bias = swiglu_w13[0], swiglu_w13[1], None
         else:
@@ -353,8 +362,11 @@ class Transformer(nn.Module):
         N = w.shape[0]
         swiglu = swiglu_w13 is not None
         pk = self._packed.get(id(w))
-        if (x2d.is_cuda and use_skinny(M, N, K, swiglu, w.dtype == torch.int8, pk is not None)
-                and ops.linear_supported(M, N, K, swiglu)):
+        how = choose(M, N, K, swiglu, w.dtype == torch.int8, pk is not None) if x2d.is_cuda else "lib"
+        if how == "fused" and ops.fused_linear_supported(M, N, K):
+            return ops.fused_linear(x2d, pk, bias, swiglu=swiglu, resid=resid)
+        assert resid is None, "the residual epilogue exists on the fused kernel only"
+        if how in ("fused", "skinny") and ops.linear_supported(M, N, K, swiglu):
             return ops.linear(x2d, pk if pk is not None else w, bias, scales, swiglu, self.workspace)
         if w.dtype == torch.int8:      # WeightOnlyInt8Linear.forward (Engine/quantize.py:84-86), dequantised on the fly
             h = F.linear(x2d, w.to(dtype=x2d.dtype)) * scales
@@ -364,6 +376,25 @@ class Transformer(nn.Module):
             inter = N // 2
             return ops.silu_mul(h[:, :inter], h[:, inter:])
         return h
+
+    def _fused_here(self, x2d, w):
+        """Does the fused kernel serve the linear `w` for these rows?  (policy + shape support + a packed bf16 copy)"""
+        from .gemm_policy import choose
+        M, K = x2d.shape
+        N = w.shape[0]
+        pk = self._packed.get(id(w))
+        return (x2d.is_cuda and pk is not None and w.dtype != torch.int8
+                and choose(M, N, K, False, False, True) == "fused" and ops.fused_linear_supported(M, N, K))
+
+    def _proj_add_norm(self, inp, lin, x, norm, group):
+        """Output projection of a sub-layer (wo / w2), the residual add and the RMSNorm for the next sub-layer:
+        (h, y) = (x + sum_ranks(inp . W^T), rmsnorm(h) * w).  Without tensor parallelism and on a launch-bound shape the
+        projection and the residual add are one launch (md_linear_fused, MD_FL_RESID) and the norm reads h; otherwise
+        the projection, then `_reduce_add_norm` (collective + fused add + norm)."""
+        if group is None and x.is_contiguous() and self._fused_here(inp, lin.weight):
+            h = self._linear(inp, lin, resid=x)
+            return h, ops.rmsnorm(h, norm.weight, norm.eps)
+        return self._reduce_add_norm(self._linear(inp, lin), x, norm, group)
 
     def _reduce_add_norm(self, partial, x, norm, group):
         """all-reduce of a sub-layer's partial output (C1), residual add, RMSNorm for the next sub-layer:
@@ -388,13 +419,10 @@ class Transformer(nn.Module):
         v = qkv[:, (H + KH) * D:].unflatten(1, (KH, D))
         return q, k, v, rows
 
-    def _mlp(self, i, layer, y2d):
-        act = self._linear(y2d, None, swiglu_w13=(self._w13[i], self._s13[i]))
-        return self._linear(act, layer.feed_forward.w2)
-
     def _run(self, idx, attn_fn):
         """embed -> L x (norm, attention, +res, norm, mlp, +res) -> norm -> head -> argmax.
-        attn_fn(i, layer, q, k, v, n) -> attention output [rows, H, D].
+        attn_fn(i, layer, y, n) -> attention output [rows, H, D]: the qkv projection, RoPE, the KV append and the
+        attention of layer i over the normalised hidden states y [rows, dim].
         With self.skip_head set (non-final prefill chunks, whose tokens the reference computes and discards,
         Engine/SnapKV/backend.py:239-263) the lm head is skipped and None is returned."""
         assert self._ready, "call setup_caches first"
@@ -403,13 +431,12 @@ class Transformer(nn.Module):
         layers = self.layers
         y = ops.rmsnorm(x, layers[0].attention_norm.weight, layers[0].attention_norm.eps)
         for i, layer in enumerate(layers):
-            q, k, v, rows = self._qkv(layer, y)
-            o = attn_fn(i, layer, q, k, v, n)
-            a = self._linear(o.view(rows, -1), layer.attention.wo)
-            x, y = self._reduce_add_norm(a, x, layer.ffn_norm, layer.attention.process_group)
-            f = self._mlp(i, layer, y)
+            o = attn_fn(i, layer, y, n)
+            x, y = self._proj_add_norm(o.view(o.shape[0], -1), layer.attention.wo, x, layer.ffn_norm,
+                                       layer.attention.process_group)
+            act = self._linear(y, None, swiglu_w13=(self._w13[i], self._s13[i]))
             nxt = layers[i + 1].attention_norm if i + 1 < len(layers) else self.norm
-            x, y = self._reduce_add_norm(f, x, nxt, layer.feed_forward.process_group)
+            x, y = self._proj_add_norm(act, layer.feed_forward.w2, x, nxt, layer.feed_forward.process_group)
         if self.skip_head:
             return None
         logits = self._linear(y, self.output)                         # [rows, vocab / tp]
@@ -443,23 +470,34 @@ class Transformer(nn.Module):
         draft_forward / prefill of Engine/SnapKV/model.py:322-387."""
         c = self.config
 
-        def fn(i, layer, q, k, v, n):
+        def fn(i, layer, y, n):
             kvc = layer.attention.kv_cache
+            att = layer.attention
             cache = getattr(kvc, which)
             cache2 = kvc.draft_cache if tab2 is not None else None
             scales = kvc.scales(which)
             layout = kvc.layout_of(which)
-            if scales is not None and calibrate and not kvc.calibrated:
-                if self.kv_scale_override is not None:
-                    kvc.k_scale.copy_(self.kv_scale_override[i][0])
-                    kvc.v_scale.copy_(self.kv_scale_override[i][1])
-                    kvc.calibrated = True
-                else:
-                    kvc.calibrate(k, v)
-            q_rot = ops.rope_append(q, k, v, qo_indptr, offsets, self.rope_table, cache, tab.indices, tab.indptr,
-                                    tab.last_page_len, cache2, tab2.indices if tab2 else None,
-                                    tab2.indptr if tab2 else None, tab2.last_page_len if tab2 else None, n_max=n,
-                                    kv_scales=scales, kv_layout=layout)
+            need_calib = scales is not None and calibrate and not kvc.calibrated
+            if not need_calib and self._fused_here(y, att.wqkv.weight) and c.head_dim in (64, 128):
+                # wqkv + bias + RoPE + paged append (both caches of a self-speculation verify): ONE launch
+                q_rot = ops.fused_qkv_rope_append(
+                    y, self._packed[id(att.wqkv.weight)], att.wqkv.bias, c.n_head, c.n_local_heads, c.head_dim, n,
+                    offsets, self.rope_table, cache, tab.indices, tab.indptr, tab.last_page_len, cache2,
+                    tab2.indices if tab2 else None, tab2.indptr if tab2 else None,
+                    tab2.last_page_len if tab2 else None, kv_scales=scales, kv_layout=layout)
+            else:
+                q, k, v, _ = self._qkv(layer, y)
+                if need_calib:
+                    if self.kv_scale_override is not None:
+                        kvc.k_scale.copy_(self.kv_scale_override[i][0])
+                        kvc.v_scale.copy_(self.kv_scale_override[i][1])
+                        kvc.calibrated = True
+                    else:
+                        kvc.calibrate(k, v)
+                q_rot = ops.rope_append(q, k, v, qo_indptr, offsets, self.rope_table, cache, tab.indices, tab.indptr,
+                                        tab.last_page_len, cache2, tab2.indices if tab2 else None,
+                                        tab2.indptr if tab2 else None, tab2.last_page_len if tab2 else None, n_max=n,
+                                        kv_scales=scales, kv_layout=layout)
             o = self._attend(q_rot, cache, qo_indptr, tab, n, scales, layout)
             if snap_tab is not None:
                 ops.snapkv_select(q_rot, cache, tab.indices, tab.indptr, self._snap_ctx_len, self.window_size,
@@ -498,7 +536,8 @@ class Transformer(nn.Module):
         kv_len = self.draft_budget
         dev = idx.device
 
-        def fn(i, layer, q, k, v, n):
+        def fn(i, layer, y, n):
+            q, k, v, _ = self._qkv(layer, y)
             cache = getattr(layer.attention.kv_cache, which)
             ppr = cache.shape[0] // B
             overflow = ctx + n > kv_len

@@ -11,7 +11,7 @@ from ctypes import c_char_p, c_double, c_float, c_int, c_int64, c_size_t, c_void
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmagicdec_hip.so")
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 _lib = None
 _err = None
@@ -19,6 +19,18 @@ _err = None
 P = c_void_p
 I = c_int
 L = c_int64
+
+class FusedLinearArgs(ctypes.Structure):
+    """md_fused_linear_args of include/magicdec_hip.h (field order and types must match)."""
+    _fields_ = [("x", P), ("w_packed", P), ("bias", P), ("out", P), ("resid", P),
+                ("ldx", L), ("ldo", L), ("ldr", L),
+                ("M", I), ("N", I), ("K", I), ("epilogue", I),
+                ("H", I), ("KH", I), ("D", I), ("rows_per_req", I), ("max_pos", I), ("page_size", I), ("kv_dtype", I),
+                ("offsets", P), ("cos_sin", P),
+                ("cache", P), ("page_indices", P), ("page_indptr", P), ("last_page_len", P),
+                ("cache2", P), ("page_indices2", P), ("page_indptr2", P), ("last_page_len2", P),
+                ("k_scale", P), ("v_scale", P)]
+
 
 _SIGNATURES = {
     "md_abi_version": (c_int, []),
@@ -51,6 +63,8 @@ _SIGNATURES = {
     "md_linear_workspace_bytes": (c_size_t, [I, I, I, I]),
     "md_debug_set_gemm_target_blocks": (None, [I]),
     "md_linear": (c_int, [P, L, P, I, I, P, P, P, L, I, I, I, I, P, c_size_t, P]),
+    "md_linear_fused_supported": (c_int, [I, I, I, I]),
+    "md_linear_fused": (c_int, [ctypes.POINTER(FusedLinearArgs), P]),
     "md_rmsnorm": (c_int, [P, P, P, I, I, c_float, P]),
     "md_add_rmsnorm": (c_int, [P, P, P, P, P, I, I, c_float, P]),
     "md_silu_mul": (c_int, [P, P, L, L, P, I, I, P]),

@@ -238,6 +238,13 @@ bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
 }  // namespace
 
+// device address of the dropped-row counter, for kernels of other translation units (csrc/tilegemm.hip)
+unsigned int* md_page_overflow_counter_device() {
+    void* p = nullptr;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_md_page_overflow)) != hipSuccess) return nullptr;
+    return (unsigned int*)p;
+}
+
 extern "C" int md_page_overflow_count(unsigned int* count_host, int reset) {
     MD_CHECK_ARG(count_host, "md_page_overflow_count: null pointer argument");
     hipError_t e = hipMemcpyFromSymbol(count_host, HIP_SYMBOL(g_md_page_overflow), sizeof(unsigned int));

@@ -1,0 +1,376 @@
+// Fused small-problem GEMM for the launch-bound linears of a decode / verify step (gfx950):
+//     out = epilogue( x[M][K] . W[N][K]^T + bias )            M <= 256, weights in the streaming layout of md_linear
+//
+// replaces: nn.Linear of Attention / FeedForward in a decode step TOGETHER with the op that consumes its output --
+//   wqkv   + RoPE + paged KV append        (Engine/SnapKV/model.py:322-336: wqkv, apply_rope, update_kv)
+//   wo     + residual add                  (model.py:260-278: h = x + attention(...))
+//   w1|w3  + SiLU * mul                    (model.py:451-455)
+//   w2     + residual add                  (model.py:260-278: out = h + feed_forward(...))
+//
+// Why a second GEMM kernel.  md_linear (gemm.hip) is a weight-STREAMING kernel: split-K over ~256 workgroups + a combine
+// launch; right for 60..500 MB of weights.  The 1B draft model's linears, every tensor-parallel shard, and the qkv / wo
+// of an 8B step are 2..30 MB: there the whole call is latency (hipBLASLt: 7-12 us for 3 MB of weights,
+// profiles/r02_gemm_ab_short_stream_rejected.txt) and each is followed by a 5 us elementwise launch (rope+append,
+// add, SiLU*mul) -- a 1B draft step is ~150 launches for 0.4 ms of HBM time (profiles/r03_emulated_tp8_iter_breakdown_before.csv:
+// 40 % of a TP8 rank's iteration is such GEMMs, another 20 % the small kernels behind them).  This kernel removes the
+// second launch of every pair and runs the product itself with nothing between "all loads issued" and "all data there":
+//
+//   * a workgroup (8 wavefronts) owns one 32-row x 32-column output tile and the WHOLE K range: no split-K across
+//     workgroups, no partial sums in HBM, no combine launch; grid = (M/32) x (N/32) tiles, block id -> tile mapping
+//     keeps the M-tiles of one weight tile on one XCD (they share its L2 lines);
+//   * the K range is split over the 8 wavefronts (K/8 each); every wavefront is an independent pipeline with NO
+//     barrier in its loop: W fragments stream global -> registers (one contiguous KiB per instruction, 8-deep rolling
+//     ring, non-temporal), its private slice of the activations goes global -> registers -> wave-private LDS image ->
+//     MFMA A fragments (full 256-B row segments per 16 lanes from L2 instead of fragment-shaped 32-B pieces -- the
+//     latter is what made round 2's "short-stream" attempt 1.4-3x slower) with the next 128-deep chunk's loads in flight
+//     under the current chunk's MFMAs;
+//   * v_mfma_f32_32x32x16_bf16, fp32 accumulators; the 8 partial tiles are summed through LDS in wave order
+//     (deterministic: eager, graph replay and every TP rank see the same bits);
+//   * epilogue on the finished tile, one thread per adjacent column pair, with the reference's rounding points:
+//       NONE         out = bf16(acc + bias)
+//       RESID        out = bf16(resid + bf16(acc + bias))                                   (bf16 add)
+//       SWIGLU       out = bf16(bf16(silu(bf16(h1))) * bf16(h3))   (tile = 16 rows of w1 + the same 16 of w3)
+//       ROPE_APPEND  qkv = bf16(acc + bias); q columns: interleaved RoPE (fp32 table, un-fused mul/add: bit-identical
+//                    to md_rope_append) -> q_out; k columns: RoPE -> paged cache(s); v columns -> paged cache(s)
+//                    (bf16 or fp8 e4m3 pages, NHD or HND, optional second bf16 cache; page table read on the device).
+#include "md_common.h"
+
+unsigned int* md_page_overflow_counter_device();   // kvops.hip: rows dropped beyond a request's mapped pages
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kNW = 8;                   // wavefronts per workgroup = K slices
+constexpr int kKC = 128;                 // k depth of one activation chunk
+constexpr int kPitch = kKC * 2 + 16;     // LDS row pitch (272 B: consecutive rows start 4 banks apart)
+constexpr int kWaveLds = 32 * kPitch;    // wave-private activation image (8704 B >= the 4 KiB partial tile)
+
+enum { FL_NONE = 0, FL_SWIGLU = 1, FL_RESID = 2, FL_ROPE_APPEND = 3 };
+
+struct KvTable {
+    void* cache;
+    const int32_t* indices;
+    const int32_t* indptr;
+    const int32_t* last;
+};
+
+struct TileParams {
+    const bf16_t* x;
+    const bf16_t* w;          // streaming layout [N/32][K/16][64][8]
+    const bf16_t* bias;
+    bf16_t* out;
+    const bf16_t* resid;
+    int64_t ldx, ldo, ldr;
+    int M, N, K, n_tiles, m_tiles;
+    // ROPE_APPEND
+    int H, KH, D, rows_per_req, max_pos, page_size, hnd;
+    const int32_t* offsets;
+    const float* cos_sin;
+    KvTable t1, t2;
+    const float* k_scale;
+    const float* v_scale;
+    unsigned int* overflow;   // dropped-row counter (md_page_overflow_count)
+};
+
+__device__ __forceinline__ float silu_bf16(float h1) {
+    return bf16_to_f32(f32_to_bf16(h1 / (1.0f + expf(-h1))));     // same expression as md_silu_mul / md_linear
+}
+
+__device__ __forceinline__ unsigned int pack2(float a, float b) {
+    const bf16x2 pk = {f32_to_bf16(a), f32_to_bf16(b)};
+    return *reinterpret_cast<const unsigned int*>(&pk);
+}
+
+// store an adjacent pair (two consecutive cache elements) of a bf16 / fp8 page
+template <bool FP8>
+__device__ __forceinline__ void store_pair(void* cache, int64_t off, float a, float b, float inv_scale) {
+    if constexpr (FP8) {
+        const float qa = fminf(fmaxf(__fmul_rn(a, inv_scale), -448.f), 448.f);
+        const float qb = fminf(fmaxf(__fmul_rn(b, inv_scale), -448.f), 448.f);
+        const unsigned int r = __builtin_amdgcn_cvt_pk_fp8_f32(qa, qb, 0u, false);
+        *reinterpret_cast<unsigned short*>(reinterpret_cast<unsigned char*>(cache) + off) = (unsigned short)(r & 0xffffu);
+    } else {
+        *reinterpret_cast<unsigned int*>(reinterpret_cast<bf16_t*>(cache) + off) = pack2(a, b);
+    }
+}
+
+// element offset of (row `pos` of the request, kv head h, element d) in the K half of a paged cache; -1: not stored
+__device__ __forceinline__ int64_t kv_elem_offset(const KvTable& t, int b, int rows_per_req, int jrow, int page_size,
+                                                  int KH, int D, int h, int d, bool hnd, bool* overflow) {
+    const int p0 = t.indptr[b];
+    const int np = t.indptr[b + 1] - p0;
+    const int len = np > 0 ? (np - 1) * page_size + t.last[b] : 0;
+    const int pos = len - rows_per_req + jrow;
+    *overflow = pos >= np * page_size;
+    if (pos < 0 || *overflow) return -1;
+    const int page = pos / page_size;
+    const int slot = pos - page * page_size;
+    const int64_t base = (int64_t)t.indices[p0 + page] * 2 * page_size * KH * D;
+    return hnd ? base + ((int64_t)h * page_size + slot) * D + d : base + ((int64_t)slot * KH + h) * D + d;
+}
+
+template <int EPI, bool FP8>
+__global__ __launch_bounds__(512, 4) void tile_gemm_kernel(const TileParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];   // kNW x kWaveLds
+    const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, kh = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // provably wave-uniform: scalar base addresses
+    // block id -> (weight tile, M tile): block b runs on XCD b % 8; the M tiles of one weight tile stay on one XCD
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int tn = (slot / p.m_tiles) * 8 + xcd, tm = slot % p.m_tiles;
+    if (tn >= p.n_tiles) return;
+    const int m0 = tm * 32;
+
+    const int ksteps_w = (p.K >> 4) / kNW;          // 16-deep MFMA k-steps of this wavefront's slice
+    const int ks0 = wave * ksteps_w;
+    const bf16_t* wbase = p.w + ((int64_t)tn * (p.K >> 4) + ks0) * 512;     // wave-uniform; + lane * 8 per lane
+    unsigned char* my_lds = lds + wave * kWaveLds;
+
+    // activation staging: instruction i covers rows 4i + (lane >> 4), 16 lanes read one 256-B row segment
+    const int ar = lane >> 4, c16 = lane & 15;
+    const unsigned char* xbase = reinterpret_cast<const unsigned char*>(p.x + ks0 * 16);   // wave-uniform
+    unsigned int xrow[8];                            // byte offsets of the lane's 8 rows (M * ldx * 2 < 2^32)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int r = m0 + 4 * i + ar;
+        xrow[i] = (unsigned int)(r < p.M ? r : p.M - 1) * (unsigned int)p.ldx * 2u;   // rows >= M re-read row M-1
+    }
+    const int nchunk = (ksteps_w + 7) >> 3;
+    u32x4 xa[8];
+    auto a_load = [&](int c) {
+        const int klen = min(ksteps_w - c * 8, 8) * 16;               // k elements of this chunk (wave-uniform)
+        const unsigned int cc = (unsigned int)(c * kKC + (c16 * 8 < klen ? c16 : 0) * 8) * 2u;   // lanes past a short
+                                                                      // tail chunk re-read its column 0
+#pragma unroll
+        for (int i = 0; i < 8; ++i) xa[i] = *reinterpret_cast<const u32x4*>(xbase + (xrow[i] + cc));
+    };
+    auto a_store = [&]() {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            *reinterpret_cast<u32x4*>(my_lds + (4 * i + ar) * kPitch + c16 * 16) = xa[i];
+    };
+
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+    bf16x8 wr[8];
+    a_load(0);
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        const u32x4 v = __builtin_nontemporal_load(
+            reinterpret_cast<const u32x4*>(wbase + (s < ksteps_w ? s : ksteps_w - 1) * 512 + lane * 8));
+        wr[s] = *reinterpret_cast<const bf16x8*>(&v);
+    }
+    const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    const unsigned char* a_frag = my_lds + j * kPitch + kh * 16;
+#pragma unroll 1
+    for (int c = 0; c < nchunk; ++c) {
+        const int nst = min(ksteps_w - c * 8, 8);
+        a_store();
+        if (c + 1 < nchunk) a_load(c + 1);
+#pragma unroll
+        for (int st = 0; st < 8; ++st) {
+            const bool live = st < nst;                               // wave-uniform; only the last chunk can be short
+            bf16x8 b = wr[st];
+            const int nxt = c * 8 + st + 8;
+            const u32x4 v = __builtin_nontemporal_load(
+                reinterpret_cast<const u32x4*>(wbase + (nxt < ksteps_w ? nxt : ksteps_w - 1) * 512 + lane * 8));
+            wr[st] = *reinterpret_cast<const bf16x8*>(&v);
+            bf16x8 a = *reinterpret_cast<const bf16x8*>(a_frag + st * 32);
+            if (!live) {                                              // stale LDS may hold NaN: 0 x 0, not 0 x garbage
+                a = zero8;
+                b = zero8;
+            }
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+        }
+    }
+
+    // ---- the 8 partial tiles -> LDS (each wavefront overwrites its own, fully consumed, activation image)
+    // acc[r] = D[row (r&3) + 8*(r>>2) + 4*kh][column j]
+    float* red = reinterpret_cast<float*>(my_lds);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[((r & 3) + 8 * (r >> 2) + 4 * kh) * 32 + j] = acc[r];
+    __syncthreads();
+
+    const int row = tid >> 4, cp = tid & 15;
+    const int gm = m0 + row;
+    auto tile_sum2 = [&](int col) -> f32x2 {              // columns col, col+1 of row `row`, summed in wave order
+        f32x2 s = {0.f, 0.f};
+#pragma unroll
+        for (int w = 0; w < kNW; ++w)
+            s += *reinterpret_cast<const f32x2*>(lds + w * kWaveLds + (row * 32 + col) * 4);
+        return s;
+    };
+    auto tile_sum1 = [&](int col) -> float {
+        float s = 0.f;
+#pragma unroll
+        for (int w = 0; w < kNW; ++w) s += *reinterpret_cast<const float*>(lds + w * kWaveLds + (row * 32 + col) * 4);
+        return s;
+    };
+
+    if constexpr (EPI == FL_SWIGLU) {
+        const int I = p.N >> 1;
+        const int i = tn * 16 + cp;
+        const float h1 = bf16_to_f32(f32_to_bf16(tile_sum1(cp)));
+        const float h3 = bf16_to_f32(f32_to_bf16(tile_sum1(16 + cp)));
+        if (gm < p.M && i < I) p.out[(int64_t)gm * p.ldo + i] = f32_to_bf16(silu_bf16(h1) * h3);
+        return;
+    } else {
+        const int n = tn * 32 + 2 * cp;
+        f32x2 s = tile_sum2(2 * cp);
+        if (p.bias) {
+            s[0] += bf16_to_f32(p.bias[n]);
+            s[1] += bf16_to_f32(p.bias[n + 1]);
+        }
+        if (gm >= p.M) return;
+        // the linear's own output, rounded to bf16 as nn.Linear returns it
+        const float o0 = bf16_to_f32(f32_to_bf16(s[0])), o1 = bf16_to_f32(f32_to_bf16(s[1]));
+        if constexpr (EPI == FL_NONE) {
+            *reinterpret_cast<unsigned int*>(p.out + (int64_t)gm * p.ldo + n) = pack2(o0, o1);
+        } else if constexpr (EPI == FL_RESID) {
+            const unsigned int rv = *reinterpret_cast<const unsigned int*>(p.resid + (int64_t)gm * p.ldr + n);
+            const float r0 = __uint_as_float(rv << 16), r1 = __uint_as_float(rv & 0xffff0000u);
+            *reinterpret_cast<unsigned int*>(p.out + (int64_t)gm * p.ldo + n) = pack2(r0 + o0, r1 + o1);
+        } else {                                            // FL_ROPE_APPEND
+            const int HD = p.H * p.D, KD = p.KH * p.D;
+            const int b = gm / p.rows_per_req, jrow = gm - b * p.rows_per_req;
+            const bool is_v = n >= HD + KD;
+            float y0 = o0, y1 = o1;
+            if (!is_v) {
+                int pos = p.offsets[b] + jrow;
+                pos = pos < 0 ? 0 : (pos >= p.max_pos ? p.max_pos - 1 : pos);
+                const int d = (n < HD ? n : n - HD) % p.D;          // even: (d, d+1) is one interleaved pair
+                const f32x2 cs = *reinterpret_cast<const f32x2*>(p.cos_sin + (int64_t)pos * p.D + d);
+                y0 = __fsub_rn(__fmul_rn(o0, cs[0]), __fmul_rn(o1, cs[1]));
+                y1 = __fadd_rn(__fmul_rn(o1, cs[0]), __fmul_rn(o0, cs[1]));
+            }
+            if (n < HD) {
+                *reinterpret_cast<unsigned int*>(p.out + (int64_t)gm * p.ldo + n) = pack2(y0, y1);
+                return;
+            }
+            const int nn = is_v ? n - HD - KD : n - HD;
+            const int h = nn / p.D, d = nn - h * p.D;
+            const int64_t half = (int64_t)p.page_size * KD;
+            bool over;
+            const int64_t d1 = kv_elem_offset(p.t1, b, p.rows_per_req, jrow, p.page_size, p.KH, p.D, h, d, p.hnd != 0,
+                                              &over);
+            // one count per dropped row (as md_rope_append): the thread holding the row's first K pair reports it
+            if (over && !is_v && nn == 0) atomicAdd(p.overflow, 1u);
+            if (d1 >= 0) {
+                float inv = 1.f;
+                if constexpr (FP8) inv = 1.0f / (is_v ? p.v_scale[h] : p.k_scale[h]);
+                store_pair<FP8>(p.t1.cache, d1 + (is_v ? half : 0), y0, y1, inv);
+            }
+            if (p.t2.cache) {                                 // second cache (self-speculation draft cache): bf16, NHD
+                const int64_t d2 = kv_elem_offset(p.t2, b, p.rows_per_req, jrow, p.page_size, p.KH, p.D, h, d, false,
+                                                  &over);
+                if (over && !is_v && nn == 0) atomicAdd(p.overflow, 1u);
+                if (d2 >= 0) store_pair<false>(p.t2.cache, d2 + (is_v ? half : 0), y0, y1, 1.f);
+            }
+        }
+    }
+}
+
+template <int EPI, bool FP8>
+int launch_tile(const TileParams& p, hipStream_t st) {
+    constexpr int lds = kNW * kWaveLds;
+    auto k = tile_gemm_kernel<EPI, FP8>;
+    static MdPerDeviceOnce once;
+    if (once.first()) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds) !=
+            hipSuccess) {
+            once.undo();
+            md_set_error("md_linear_fused: hipFuncSetAttribute(%d B LDS) failed", lds);
+            return MD_ERR_LAUNCH;
+        }
+    }
+    const int grid = ((p.n_tiles + 7) / 8) * 8 * p.m_tiles;
+    hipLaunchKernelGGL(k, dim3(grid), dim3(512), lds, st, p);
+    return MD_OK;
+}
+
+bool aligned16(const void* q) { return ((uintptr_t)q & 15) == 0; }
+
+}  // namespace
+
+extern "C" int md_linear_fused_supported(int M, int N, int K, int epilogue) {
+    if (M < 1 || M > 256 || K < 128 || K % 128 || N < 32 || N % 32) return 0;
+    return (epilogue >= FL_NONE && epilogue <= FL_ROPE_APPEND) ? 1 : 0;
+}
+
+extern "C" int md_linear_fused(const md_fused_linear_args* a, md_stream_t stream) {
+    MD_CHECK_ARG(a && a->x && a->w_packed && a->out, "md_linear_fused: null pointer argument");
+    MD_CHECK_ARG(md_linear_fused_supported(a->M, a->N, a->K, a->epilogue),
+                 "md_linear_fused: unsupported shape M=%d N=%d K=%d epilogue=%d (need 1 <= M <= 256, K %% 128 == 0, "
+                 "N %% 32 == 0)", a->M, a->N, a->K, a->epilogue);
+    MD_CHECK_ARG(aligned16(a->x) && aligned16(a->w_packed) && aligned16(a->out) && a->ldx % 8 == 0 && a->ldo % 2 == 0,
+                 "md_linear_fused: x / w / out must be 16-byte aligned, ldx %% 8 == 0, ldo %% 2 == 0");
+    MD_CHECK_ARG(!(a->epilogue == FL_SWIGLU && a->bias), "md_linear_fused: the SwiGLU epilogue takes no bias");
+    TileParams p = {};
+    p.x = (const bf16_t*)a->x;
+    p.w = (const bf16_t*)a->w_packed;
+    p.bias = (const bf16_t*)a->bias;
+    p.out = (bf16_t*)a->out;
+    p.ldx = a->ldx;
+    p.ldo = a->ldo;
+    p.M = a->M;
+    p.N = a->N;
+    p.K = a->K;
+    p.n_tiles = a->N / 32;
+    p.m_tiles = (a->M + 31) / 32;
+    hipStream_t st = (hipStream_t)stream;
+    int rc = MD_OK;
+    switch (a->epilogue) {
+    case FL_NONE:
+        rc = launch_tile<FL_NONE, false>(p, st);
+        break;
+    case FL_SWIGLU:
+        rc = launch_tile<FL_SWIGLU, false>(p, st);
+        break;
+    case FL_RESID:
+        MD_CHECK_ARG(a->resid && ((uintptr_t)a->resid & 3) == 0 && a->ldr % 2 == 0,
+                     "md_linear_fused: the residual epilogue needs `resid` (4-byte aligned, ldr %% 2 == 0)");
+        p.resid = (const bf16_t*)a->resid;
+        p.ldr = a->ldr;
+        rc = launch_tile<FL_RESID, false>(p, st);
+        break;
+    default: {
+        MD_CHECK_ARG(a->H > 0 && a->KH > 0 && (a->D == 64 || a->D == 128) && a->N == (a->H + 2 * a->KH) * a->D,
+                     "md_linear_fused: rope+append needs N == (H + 2 KH) * D with D in {64, 128} (H=%d KH=%d D=%d N=%d)",
+                     a->H, a->KH, a->D, a->N);
+        MD_CHECK_ARG(a->rows_per_req > 0 && a->M % a->rows_per_req == 0 && a->offsets && a->cos_sin && a->max_pos > 0 &&
+                         a->page_size > 0,
+                     "md_linear_fused: rope+append needs rows_per_req | M, offsets, the RoPE table and page_size");
+        MD_CHECK_ARG(a->cache && a->page_indices && a->page_indptr && a->last_page_len,
+                     "md_linear_fused: rope+append needs the paged cache and its page table");
+        MD_CHECK_ARG(!a->cache2 || (a->page_indices2 && a->page_indptr2 && a->last_page_len2),
+                     "md_linear_fused: the second cache needs its page table");
+        MD_CHECK_ARG(a->ldo == (int64_t)a->H * a->D, "md_linear_fused: q_out must be contiguous [M][H*D]");
+        int kvd = a->kv_dtype;
+        p.hnd = (kvd & MD_KV_LAYOUT_HND) ? 1 : 0;
+        MD_CHECK_ARG((kvd & ~(MD_KV_DTYPE_MASK | MD_KV_LAYOUT_HND)) == 0, "md_linear_fused: unknown kv_dtype flags");
+        kvd &= MD_KV_DTYPE_MASK;
+        MD_CHECK_ARG(kvd == MD_KV_BF16 || (kvd == MD_KV_FP8_E4M3 && a->k_scale && a->v_scale),
+                     "md_linear_fused: kv_dtype must be MD_KV_BF16 or MD_KV_FP8_E4M3 (with per-head scales)");
+        p.H = a->H;
+        p.KH = a->KH;
+        p.D = a->D;
+        p.rows_per_req = a->rows_per_req;
+        p.max_pos = a->max_pos;
+        p.page_size = a->page_size;
+        p.offsets = a->offsets;
+        p.cos_sin = a->cos_sin;
+        p.t1 = KvTable{a->cache, a->page_indices, a->page_indptr, a->last_page_len};
+        p.t2 = KvTable{a->cache2, a->page_indices2, a->page_indptr2, a->last_page_len2};
+        p.k_scale = a->k_scale;
+        p.v_scale = a->v_scale;
+        p.overflow = md_page_overflow_counter_device();
+        MD_CHECK_ARG(p.overflow, "md_linear_fused: cannot resolve the page-overflow counter");
+        rc = kvd == MD_KV_FP8_E4M3 ? launch_tile<FL_ROPE_APPEND, true>(p, st) : launch_tile<FL_ROPE_APPEND, false>(p, st);
+    }
+    }
+    if (rc != MD_OK) return rc;
+    MD_CHECK_LAUNCH("md_linear_fused");
+    return MD_OK;
+}

@@ -351,6 +351,88 @@ def linear(x, weight, bias=None, scales=None, swiglu=False, workspace: "AttnWork
     return out
 
 
+# ----------------------------------------------------------------------------- K8b
+FL_NONE, FL_SWIGLU, FL_RESID, FL_ROPE_APPEND = 0, 1, 2, 3
+
+
+def fused_linear_supported(M, N, K, epilogue=FL_NONE):
+    """True when md_linear_fused (csrc/tilegemm.hip) takes this shape."""
+    return bool(_lib.load().md_linear_fused_supported(int(M), int(N), int(K), int(epilogue)))
+
+
+def _fused_args(x, weight: "PackedWeight", bias, epilogue):
+    _gpu(x, weight.data, bias)
+    if x.dim() != 2 or x.stride(1) != 1 or x.dtype != torch.bfloat16:
+        raise ValueError("fused linear expects x [M, K] bf16 with unit inner stride")
+    if weight.dtype != torch.bfloat16:
+        raise TypeError("fused linear streams bf16 weights")
+    M, K = x.shape
+    if weight.K != K:
+        raise ValueError(f"fused linear: x has K={K}, weight has K={weight.K}")
+    if weight.swiglu != (epilogue == FL_SWIGLU):
+        raise ValueError("PackedWeight was packed for a different epilogue")
+    a = _lib.FusedLinearArgs()
+    a.x, a.ldx, a.w_packed, a.bias = x.data_ptr(), x.stride(0), weight.data.data_ptr(), (bias.data_ptr() if bias is not None else None)
+    a.M, a.N, a.K, a.epilogue = M, weight.N, K, epilogue
+    return a
+
+
+def _run_fused(a):
+    check(_lib.load().md_linear_fused(ctypes.byref(a), _stream()), "md_linear_fused")
+
+
+def fused_linear(x, weight: "PackedWeight", bias=None, swiglu=False, resid=None, out=None):
+    """One launch (md_linear_fused): F.linear(x, W, bias) for M <= 256 rows over a PackedWeight, optionally followed by
+    SiLU(h1) * h3 (swiglu=True, weight = [w1; w3]) or by the bf16 residual add `resid + linear` (resid [M, N])."""
+    epi = FL_SWIGLU if swiglu else (FL_RESID if resid is not None else FL_NONE)
+    a = _fused_args(x, weight, bias, epi)
+    n_out = weight.N // 2 if swiglu else weight.N
+    if out is None:
+        out = torch.empty((x.shape[0], n_out), dtype=x.dtype, device=x.device)
+    a.out, a.ldo = out.data_ptr(), out.stride(0)
+    if resid is not None:
+        _gpu(resid)
+        if resid.shape != out.shape or resid.stride(1) != 1 or resid.dtype != torch.bfloat16:
+            raise ValueError("fused linear: resid must be bf16 [M, N] with unit inner stride")
+        a.resid, a.ldr = resid.data_ptr(), resid.stride(0)
+    _run_fused(a)
+    return out
+
+
+def fused_qkv_rope_append(x, weight: "PackedWeight", bias, H, KH, D, rows_per_req, offsets, table: RopeTable, kv_cache,
+                          page_indices, page_indptr, last_page_len, kv_cache2=None, page_indices2=None,
+                          page_indptr2=None, last_page_len2=None, kv_scales=None, kv_layout="NHD"):
+    """wqkv + RoPE + paged KV append in one launch (md_linear_fused, MD_FL_ROPE_APPEND): x [M, K] are the normalised
+    hidden states of a decode / verify step in which request b owns rows [b * rows_per_req, (b+1) * rows_per_req).
+    Returns the rotated q [M, H, D]; rotated k and v go to the paged cache (and to kv_cache2, bf16 NHD, when given).
+    Same results as linear -> rope_append."""
+    a = _fused_args(x, weight, bias, FL_ROPE_APPEND)
+    _gpu(kv_cache, kv_cache2)
+    M = x.shape[0]
+    if weight.N != (H + 2 * KH) * D:
+        raise ValueError("fused qkv: weight rows must be (H + 2 KH) * D")
+    if M % rows_per_req:
+        raise ValueError("fused qkv: every request must own rows_per_req rows")
+    q_out = torch.empty((M, H, D), dtype=x.dtype, device=x.device)
+    a.out, a.ldo = q_out.data_ptr(), H * D
+    a.H, a.KH, a.D, a.rows_per_req, a.max_pos = H, KH, D, rows_per_req, table.max_pos
+    offsets = _i32(offsets)
+    pi, pp, lp = _i32(page_indices), _i32(page_indptr), _i32(last_page_len)
+    a.offsets, a.cos_sin = offsets.data_ptr(), table.table.data_ptr()
+    a.cache, a.page_indices, a.page_indptr, a.last_page_len = kv_cache.data_ptr(), pi.data_ptr(), pp.data_ptr(), lp.data_ptr()
+    keep = [offsets, pi, pp, lp]
+    if kv_cache2 is not None:
+        pi2, pp2, lp2 = _i32(page_indices2), _i32(page_indptr2), _i32(last_page_len2)
+        keep += [pi2, pp2, lp2]
+        a.cache2, a.page_indices2, a.page_indptr2, a.last_page_len2 = (kv_cache2.data_ptr(), pi2.data_ptr(),
+                                                                       pp2.data_ptr(), lp2.data_ptr())
+    a.page_size = _kv_geom(kv_cache, kv_layout)[0]
+    kvd, ks, vs = _kv_args(kv_cache, kv_scales, kv_layout)
+    a.kv_dtype, a.k_scale, a.v_scale = kvd, ks, vs
+    _run_fused(a)
+    return q_out
+
+
 # ----------------------------------------------------------------------------- K9
 def rmsnorm(x, weight, eps):
     _gpu(x, weight)

@@ -94,7 +94,17 @@ def test_every_entry_point_rejects_null_arguments():
     skip = {"md_abi_version", "md_last_error_string", "md_debug_set_attn_target_wgs", "md_ar_destroy",
             "md_debug_set_gemm_target_blocks", "md_debug_attn_timing", "md_debug_attn_timing_read"}
     assert lib.md_linear_supported(0, 0, 0, 0) == 0 and lib.md_linear_supported(64, 128, 256, 0) == 1
-    skip.add("md_linear_supported")
+    assert lib.md_linear_fused_supported(0, 0, 0, 0) == 0 and lib.md_linear_fused_supported(64, 768, 2048, 3) == 1
+    assert lib.md_linear_fused_supported(64, 770, 2048, 0) == 0 and lib.md_linear_fused_supported(300, 768, 2048, 0) == 0
+    skip |= {"md_linear_supported", "md_linear_fused_supported"}
+    # md_linear_fused takes a struct: NULL struct, then a zeroed struct (null tensors), then tensors but a bad shape
+    assert lib.md_linear_fused(None, None) < 0 and "md_linear_fused" in lib.md_last_error_string().decode()
+    fa = _lib.FusedLinearArgs()
+    assert lib.md_linear_fused(ctypes.byref(fa), None) < 0 and "md_linear_fused" in lib.md_last_error_string().decode()
+    fa.x = fa.w_packed = fa.out = 4096
+    fa.M, fa.N, fa.K = 64, 100, 256
+    assert lib.md_linear_fused(ctypes.byref(fa), None) < 0 and "unsupported shape" in lib.md_last_error_string().decode()
+    skip.add("md_linear_fused")
     for name, (restype, argtypes) in _lib._SIGNATURES.items():
         if name in skip:
             continue
@@ -758,12 +768,13 @@ def test_c_abi_rejects_unknown_kv_dtype_flags():
 
 
 def test_default_kv_layout_env(monkeypatch, cpu_ops_patched, ckpt_dir):
-    """setup_caches() without kv_layout: the reference's NHD, or what MAGICDEC_KV_LAYOUT says."""
+    """setup_caches() without kv_layout: HND (round 3: the layout bench.py measures is the Engine API's default), or
+    what MAGICDEC_KV_LAYOUT says (NHD = the reference's flashinfer layout)."""
     from magicdec_amd.Engine import backend_core
     from magicdec_amd.Engine.SnapKV.backend import LMBackend
-    monkeypatch.delenv("MAGICDEC_KV_LAYOUT", raising=False)
+    monkeypatch.setenv("MAGICDEC_KV_LAYOUT", "nhd")
     assert backend_core.default_kv_layout() == "NHD"
-    monkeypatch.setenv("MAGICDEC_KV_LAYOUT", "hnd")
+    monkeypatch.delenv("MAGICDEC_KV_LAYOUT", raising=False)
     assert backend_core.default_kv_layout() == "HND"
     eng = LMBackend(dtype=torch.bfloat16, device="cpu", dec_len=gc.GAMMA + 1, draft_dec_len=1)
     eng.load_model(ckpt_dir / "tinytgt" / "model.pth", use_tp=False)
