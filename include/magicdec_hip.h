@@ -141,6 +141,8 @@ size_t md_paged_attn_workspace_bytes(int B, int n_max, int H, int KH, int D,
 /* development knob (kernel tuning sweeps only): target number of workgroups of the split-KV decomposition;
  * n <= 0 restores the default (256 = one per CU). Host, not thread-safe. */
 void md_debug_set_attn_target_wgs(int n);
+void md_debug_set_prefill_kt(int kt, int nw); /* development: keys per shared tile of the bf16 prefill kernel (32 | 64 =
+                                               * default) and waves per workgroup (4 | 8; 0 = the measured rule) */
 /* measurement (bench.py's roofline): while enabled, every decode / verify launch of md_paged_attn with n_max ==
  * n_rows query rows per request is bracketed by the kernel's OWN begin / end timestamps (hipExtLaunchKernel start /
  * stop events = what a rocprofv3 kernel trace reports; stream events around a launch also see the dispatch overhead).
@@ -292,6 +294,7 @@ typedef struct md_fused_linear_args {
     const float* v_scale;
 } md_fused_linear_args;
 int md_linear_fused_supported(int M, int N, int K, int epilogue);
+void md_debug_set_fused_nw(int nw); /* development: wavefronts (K slices) per workgroup, 8 | 16; 0 = the measured rule */
 int md_linear_fused(const md_fused_linear_args* args, md_stream_t stream);
 
 /* ------------------------------------------------------------------------

@@ -42,6 +42,7 @@ _SIGNATURES = {
     "md_rope_append": (c_int, [P, P, P, L, L, L, P, P, P, I, I, I, I, I, P, I, P, P, P, P, P, P, P, P, I, I, P, P, P]),
     "md_paged_attn_workspace_bytes": (c_size_t, [I, I, I, I, I, I, I]),
     "md_debug_set_attn_target_wgs": (None, [I]),
+    "md_debug_set_prefill_kt": (None, [I, I]),
     "md_debug_attn_timing": (None, [I, I]),
     "md_debug_attn_timing_read": (c_int, [P, I]),
     "md_paged_attn": (c_int, [P, L, P, P, P, P, P, P, I, I, I, I, I, I, I, c_float, I, I, P, P, P, c_size_t, P]),
@@ -64,6 +65,7 @@ _SIGNATURES = {
     "md_debug_set_gemm_target_blocks": (None, [I]),
     "md_linear": (c_int, [P, L, P, I, I, P, P, P, L, I, I, I, I, P, c_size_t, P]),
     "md_linear_fused_supported": (c_int, [I, I, I, I]),
+    "md_debug_set_fused_nw": (None, [I]),
     "md_linear_fused": (c_int, [ctypes.POINTER(FusedLinearArgs), P]),
     "md_rmsnorm": (c_int, [P, P, P, I, I, c_float, P]),
     "md_add_rmsnorm": (c_int, [P, P, P, P, P, I, I, c_float, P]),

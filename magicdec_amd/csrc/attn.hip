@@ -71,9 +71,9 @@ __host__ __device__ constexpr int attn_wave_lds() {
     return (m + 255) / 256 * 256;
 }
 
-template <int D>
+template <int D, int KT = 32>
 __host__ __device__ constexpr int prefill_stage_bytes() {
-    return 32 * (D * 2 + 16) + (D / 16) * kVSub;   // one shared K + V tile image (prefill kernel)
+    return KT * (D * 2 + 16) + (KT / 32) * (D / 16) * kVSub;   // one shared KT-key K + V tile image (prefill kernel)
 }
 
 __device__ __forceinline__ bf16x8 lds_read_b128(const unsigned char* p) {
@@ -570,18 +570,24 @@ __global__ __launch_bounds__(256) void attn_merge_kernel(const AttnParams p, int
 // kernel) and consumed by the four waves after one s_barrier per tile.  Versus the wave-private staging of the
 // decode kernel this divides the L2->CU traffic and the LDS writes by 4.  Causal: a wave stops computing at its own
 // last needed tile but keeps staging until the workgroup's last tile.
-template <int D, int QT, bool FP8, int NW>
+// KT = keys per shared tile (32 or 64).  64 halves the per-tile fixed cost a wave pays between its MFMAs -- one barrier,
+// one pair of cross-lane max reductions and one rescale test per query tile, the loop and staging bookkeeping -- while
+// the MFMA work per key is unchanged (the round-2 kernel spent ~190 VALU per 32 MFMAs: VALU-bound).
+template <int D, int QT, bool FP8, int NW, int KT>
 __global__ __launch_bounds__(64 * NW, 2) void prefill_attn_kernel(const AttnParams p) {
+    constexpr int KG = KT / 32;            // 32-key groups per tile (V sub-tile images, PV MFMA k-groups)
+    constexpr int KBN = KT / 16;           // 16-key MFMA blocks per tile
     constexpr int EB = FP8 ? 1 : 2;
     constexpr int CH = D * EB / 16;
     constexpr int RPI = 64 / CH;
-    constexpr int NL = 32 / RPI;           // wave-wide load instructions per 32-key tile (K or V) ...
+    constexpr int NL = KT / RPI;           // wave-wide load instructions per KT-key tile (K or V) ...
     constexpr int NLW = (NL + NW - 1) / NW;   // ... of which wave w issues j = w, w+NW, ... (< NL)
     constexpr int KS = D / 32;
     constexpr int NB = D / 16;
     constexpr int KROW = D * 2 + 16;
-    constexpr int K_BYTES = 32 * KROW;
-    constexpr int STAGE = prefill_stage_bytes<D>();
+    constexpr int K_BYTES = KT * KROW;
+    constexpr int VG = NB * kVSub;         // bytes of one 32-key V group image
+    constexpr int STAGE = prefill_stage_bytes<D, KT>();
     constexpr bool FP8_SWAP = FP8 && D == 128;
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // 2 x STAGE, then int[NW]
@@ -632,8 +638,8 @@ __global__ __launch_bounds__(64 * NW, 2) void prefill_attn_kernel(const AttnPara
     int kv_end_wg = 0;
 #pragma unroll
     for (int w = 0; w < NW; ++w) kv_end_wg = max(kv_end_wg, s_end[w]);
-    const int ntiles_wg = kv_end_wg > 0 ? (kv_end_wg + 31) >> 5 : 0;
-    const int my_ntiles = kv_end > 0 ? (kv_end + 31) >> 5 : 0;
+    const int ntiles_wg = kv_end_wg > 0 ? (kv_end_wg + KT - 1) / KT : 0;
+    const int my_ntiles = kv_end > 0 ? (kv_end + KT - 1) / KT : 0;
 
     bf16x8 qf[QT][KS];
 #pragma unroll
@@ -668,30 +674,27 @@ __global__ __launch_bounds__(64 * NW, 2) void prefill_attn_kernel(const AttnPara
     int kw[NLW], kw2[NLW], vw[NLW], vw2[NLW];
 #pragma unroll
     for (int s = 0; s < NLW; ++s) {
-        const int row = wrow + (wave + NW * s) * RPI;
+        const int row = wrow + (wave + NW * s) * RPI;      // key row of the tile, 0 .. KT-1
+        const int vrow = K_BYTES + (row >> 5) * VG + (row & 31) * 32;
         if constexpr (FP8) {
             kw[s] = row * KROW + ((2 * wch + (swp ? 1 : 0)) << 4);
             kw2[s] = row * KROW + ((2 * wch + (swp ? 0 : 1)) << 4);
-            vw[s] = K_BYTES + wch * kVSub + row * 32 + (swp ? 16 : 0);
-            vw2[s] = K_BYTES + wch * kVSub + row * 32 + (swp ? 0 : 16);
+            vw[s] = vrow + wch * kVSub + (swp ? 16 : 0);
+            vw2[s] = vrow + wch * kVSub + (swp ? 0 : 16);
         } else {
             kw[s] = row * KROW + (wch << 4);
             kw2[s] = 0;
-            vw[s] = K_BYTES + (wch >> 1) * kVSub + row * 32 + (wch & 1) * 16;
+            vw[s] = vrow + (wch >> 1) * kVSub + (wch & 1) * 16;
             vw2[s] = 0;
         }
     }
-    int kra[2][KS];
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int s = 0; s < KS; ++s) kra[kb][s] = (kb * 16 + lq) * KROW + ((s * 4 + lc) << 4);
+    const int kra0 = lq * KROW + (lc << 4);       // K fragment (kb, ks) at kra0 + kb * 16 * KROW + ks * 64: immediates
     const int vra = K_BYTES + (lc * 4 + (lq >> 2)) * 32 + (lq & 3) * 8;
     const unsigned goff = (unsigned)((wrow * p.slot_stride + kvh * p.head_stride) * EB + wch * 16);
 
     u32x4 kreg[NLW], vreg[NLW];
     auto issue = [&](int tt) {
-        const int pos0 = tt * 32;
+        const int pos0 = tt * KT;
         const int page = pos0 / p.page_size;
         const int slot0 = pos0 - page * p.page_size;
         const int pid = __builtin_amdgcn_readfirstlane(p.page_indices[pg0 + page]);
@@ -711,7 +714,7 @@ __global__ __launch_bounds__(64 * NW, 2) void prefill_attn_kernel(const AttnPara
         for (int s = 0; s < NLW; ++s)
             if (wave + NW * s < NL) {
                 // rows past the request's length may hold anything (even NaN): zero V so 0*V stays 0
-                if (t * 32 + wrow + (wave + NW * s) * RPI >= kv_len) vreg[s] = u32x4{0u, 0u, 0u, 0u};
+                if (t * KT + wrow + (wave + NW * s) * RPI >= kv_len) vreg[s] = u32x4{0u, 0u, 0u, 0u};
                 if constexpr (FP8) {
                     u32x4 a, c;
                     cvt16_fp8_bf16(kreg[s], a, c);
@@ -726,45 +729,47 @@ __global__ __launch_bounds__(64 * NW, 2) void prefill_attn_kernel(const AttnPara
                 }
             }
     };
-    auto compute = [&](int t, const unsigned char* img) {
-        const bool need_mask = (t * 32 + 31) > lo;
-        f32x4 s[QT][2];
+    // MASK is a compile-time property of the call: only the last few tiles of a causal chunk reach past the smallest
+    // limit of the wave's rows; every tile before them runs a body without a single compare / select
+    auto compute = [&](int t, const unsigned char* img, auto mask_c) {
+        constexpr bool need_mask = decltype(mask_c)::value;
+        f32x4 s[QT][KBN];
 #pragma unroll
-        for (int qt = 0; qt < QT; ++qt) {
-            s[qt][0] = f32x4{0.f, 0.f, 0.f, 0.f};
-            s[qt][1] = f32x4{0.f, 0.f, 0.f, 0.f};
-        }
+        for (int qt = 0; qt < QT; ++qt)
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
+            for (int kb = 0; kb < KBN; ++kb) s[qt][kb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kb = 0; kb < KBN; ++kb)
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
-                const bf16x8 kf = lds_read_b128(img + kra[kb][ks]);
+                const bf16x8 kf = lds_read_b128(img + kra0 + kb * 16 * KROW + ks * 64);
 #pragma unroll
                 for (int qt = 0; qt < QT; ++qt)
                     s[qt][kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qt][ks], s[qt][kb], 0, 0, 0);
             }
-        bf16x8 pf[QT];
+        bf16x8 pf[QT][KG];
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt) {
-            float v[8];
+            float v[KBN * 4];                      // raw scores q.k (the softmax scale is folded into the exp2 below)
 #pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
+            for (int kb = 0; kb < KBN; ++kb)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) v[kb * 4 + j] = s[qt][kb][j] * sl2;
-            if (need_mask) {
+                for (int j = 0; j < 4; ++j) v[kb * 4 + j] = s[qt][kb][j];
+            if constexpr (need_mask) {
 #pragma unroll
-                for (int kb = 0; kb < 2; ++kb)
+                for (int kb = 0; kb < KBN; ++kb)
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        const int pos = t * 32 + kb * 16 + lc * 4 + j;
+                        const int pos = t * KT + kb * 16 + lc * 4 + j;
                         if (pos > lim[qt]) v[kb * 4 + j] = -INFINITY;
                     }
             }
             float mx = v[0];
 #pragma unroll
-            for (int e = 1; e < 8; ++e) mx = fmaxf(mx, v[e]);
+            for (int e = 1; e < KBN * 4; ++e) mx = fmaxf(mx, v[e]);
             mx = fmaxf(mx, __shfl_xor(mx, 16));
             mx = fmaxf(mx, __shfl_xor(mx, 32));
+            mx *= sl2;                             // sl2 > 0: max(v) * sl2 == max(v * sl2)
             // lazy rescale: after the first tiles the running maxima rarely move; when no query of the wave raised
             // its maximum (wave-uniform test) the D/4 accumulator multiplies per lane are skipped (alpha == 1)
             if (__builtin_amdgcn_ballot_w64(mx > m[qt]) != 0) {
@@ -776,25 +781,31 @@ __global__ __launch_bounds__(64 * NW, 2) void prefill_attn_kernel(const AttnPara
                 for (int nb = 0; nb < NB; ++nb) o[qt][nb] *= alpha;
             }
             float ps = 0.f;
-            f32x8 pv;
+            const float mneg = -m[qt];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const float pe = __builtin_amdgcn_exp2f(v[e] - m[qt]);
-                pv[e] = pe;
-                ps += pe;
+            for (int kg = 0; kg < KG; ++kg) {
+                f32x8 pv;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float pe = __builtin_amdgcn_exp2f(fmaf(v[kg * 8 + e], sl2, mneg));   // one v_fma + v_exp
+                    pv[e] = pe;
+                    ps += pe;
+                }
+                pf[qt][kg] = __builtin_convertvector(pv, bf16x8);
             }
             l[qt] += ps;
-            pf[qt] = __builtin_convertvector(pv, bf16x8);
         }
 #pragma unroll
-        for (int nb = 0; nb < NB; ++nb) {
-            const bf16x4 v0 = lds_read_tr(img + nb * kVSub + vra);
-            const bf16x4 v1 = lds_read_tr(img + nb * kVSub + 512 + vra);
-            const bf16x8 vf = __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7);
+        for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-            for (int qt = 0; qt < QT; ++qt)
-                o[qt][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[qt], o[qt][nb], 0, 0, 0);
-        }
+            for (int kg = 0; kg < KG; ++kg) {
+                const bf16x4 v0 = lds_read_tr(img + kg * VG + nb * kVSub + vra);
+                const bf16x4 v1 = lds_read_tr(img + kg * VG + nb * kVSub + 512 + vra);
+                const bf16x8 vf = __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+                for (int qt = 0; qt < QT; ++qt)
+                    o[qt][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[qt][kg], o[qt][nb], 0, 0, 0);
+            }
     };
 
     // tile t is staged into image t&1; iteration t+2 overwrites it only after every wave has passed the barrier of
@@ -805,7 +816,12 @@ __global__ __launch_bounds__(64 * NW, 2) void prefill_attn_kernel(const AttnPara
         stage(t, img);
         if (t + 1 < ntiles_wg) issue(t + 1);
         __syncthreads();
-        if (t < my_ntiles) compute(t, img);
+        if (t < my_ntiles) {
+            if ((t * KT + KT - 1) > lo)
+                compute(t, img, std::true_type{});
+            else
+                compute(t, img, std::false_type{});
+        }
     }
 
 #pragma unroll
@@ -843,6 +859,7 @@ struct AttnPlan {
 // step (B=64, 16K: 81 % / 80 % / 75 % / 70 % of HBM peak at KH_local = 8 / 4 / 2 / 1 vs 77 / 77 / 72 / 47 % at 1024);
 // per-workgroup prologue/epilogue and the partial-result round trip dominate once a wave owns < ~30 tiles
 int g_target_wgs = 256;  // dev knob: md_debug_set_attn_target_wgs
+int g_prefill_nw = 0;     // dev knob (md_debug_set_prefill_kt): 0 = the measured rule below, 4 / 8 = forced
 
 // measurement mode of the decode / verify kernel (bench.py's roofline): see md_debug_attn_timing
 struct TimedLaunch { hipEvent_t e0, e1; };
@@ -878,6 +895,7 @@ AttnPlan make_plan(int B, int n_max, int H, int KH, int max_pages, int page_size
         // fills the chip (128 workgroups); fp8 staging (4 load instructions per tile, plus the conversion) is
         // better spread over 4-wave workgroups (measured: 2.9 vs 3.3 ms)
         pl.nw = (!fp8 && rows >= 16 * pl.qt * 8) ? 8 : 4;
+        if (g_prefill_nw == 4 || (g_prefill_nw == 8 && rows >= 16 * pl.qt * 8)) pl.nw = g_prefill_nw;   // dev knob
         const int wg_rows = 16 * pl.qt * pl.nw;
         pl.n_qgroups = (rows + wg_rows - 1) / wg_rows;
         pl.nsplit = 1;
@@ -915,20 +933,46 @@ int launch_attn(const AttnParams& p, int grid, hipStream_t st) {
     return MD_OK;
 }
 
-template <int D, int QT, bool FP8>
-int launch_prefill(const AttnParams& p, int grid, int nw, hipStream_t st) {
-    constexpr int lds = 2 * prefill_stage_bytes<D>() + 32;
-    if (nw == 8)
-        hipLaunchKernelGGL((prefill_attn_kernel<D, QT, FP8, 8>), dim3(grid), dim3(512), lds, st, p);
-    else
-        hipLaunchKernelGGL((prefill_attn_kernel<D, QT, FP8, 4>), dim3(grid), dim3(256), lds, st, p);
+int g_prefill_kt = 64;    // dev knob (md_debug_set_prefill_kt): keys per shared tile of the bf16 prefill kernel
+
+template <int D, int QT, bool FP8, int NW, int KT>
+int launch_prefill_kt(const AttnParams& p, int grid, hipStream_t st) {
+    constexpr int lds = 2 * prefill_stage_bytes<D, KT>() + 32;
+    auto k = prefill_attn_kernel<D, QT, FP8, NW, KT>;
+    if (lds > 64 * 1024) {
+        static MdPerDeviceOnce once;
+        if (once.first()) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds) !=
+                hipSuccess) {
+                once.undo();
+                md_set_error("md_paged_attn(prefill): hipFuncSetAttribute(%d B LDS) failed", lds);
+                return MD_ERR_LAUNCH;
+            }
+        }
+    }
+    hipLaunchKernelGGL(k, dim3(grid), dim3(64 * NW), lds, st, p);
     MD_CHECK_LAUNCH("md_paged_attn(prefill)");
     return MD_OK;
+}
+
+template <int D, int QT, bool FP8>
+int launch_prefill(const AttnParams& p, int grid, int nw, hipStream_t st) {
+    if constexpr (!FP8) {
+        // 64-key shared tiles (bf16 pages); the fp8 staging path (two conversions per load) keeps 32-key tiles
+        if (g_prefill_kt == 64)
+            return nw == 8 ? launch_prefill_kt<D, QT, FP8, 8, 64>(p, grid, st)
+                           : launch_prefill_kt<D, QT, FP8, 4, 64>(p, grid, st);
+    }
+    return nw == 8 ? launch_prefill_kt<D, QT, FP8, 8, 32>(p, grid, st) : launch_prefill_kt<D, QT, FP8, 4, 32>(p, grid, st);
 }
 
 }  // namespace
 
 extern "C" void md_debug_set_attn_target_wgs(int n) { g_target_wgs = n > 0 ? n : 256; }
+extern "C" void md_debug_set_prefill_kt(int kt, int nw) {
+    g_prefill_kt = kt == 32 ? 32 : 64;
+    g_prefill_nw = (nw == 4 || nw == 8) ? nw : 0;
+}
 
 extern "C" void md_debug_attn_timing(int enable, int n_rows) {
     g_time_launches = enable != 0;

@@ -41,7 +41,6 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int kNW = 8;                   // wavefronts per workgroup = K slices
 constexpr int kKC = 128;                 // k depth of one activation chunk
 constexpr int kPitch = kKC * 2 + 16;     // LDS row pitch (272 B: consecutive rows start 4 banks apart)
 constexpr int kWaveLds = 32 * kPitch;    // wave-private activation image (8704 B >= the 4 KiB partial tile)
@@ -82,6 +81,12 @@ __device__ __forceinline__ unsigned int pack2(float a, float b) {
     return *reinterpret_cast<const unsigned int*>(&pk);
 }
 
+template <bool NT>
+__device__ __forceinline__ u32x4 ld_w(const bf16_t* p) {
+    if constexpr (NT) return __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
+    return *reinterpret_cast<const u32x4*>(p);
+}
+
 // store an adjacent pair (two consecutive cache elements) of a bf16 / fp8 page
 template <bool FP8>
 __device__ __forceinline__ void store_pair(void* cache, int64_t off, float a, float b, float inv_scale) {
@@ -110,9 +115,14 @@ __device__ __forceinline__ int64_t kv_elem_offset(const KvTable& t, int b, int r
     return hnd ? base + ((int64_t)h * page_size + slot) * D + d : base + ((int64_t)slot * KH + h) * D + d;
 }
 
-template <int EPI, bool FP8>
-__global__ __launch_bounds__(512, 4) void tile_gemm_kernel(const TileParams p) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];   // kNW x kWaveLds
+// NW = wavefronts per workgroup = K slices (8, or 16 when the grid cannot give every CU two workgroups: the bytes a CU
+// has in flight -- NW x (8 KiB of W + 8 KiB of x) -- are what its ingest rate is made of, ~50 GB/s per CU at NW = 8);
+// WNT = stream W with non-temporal loads (one M tile: every weight byte is read once) or keep it in L2 for the sibling
+// M tiles of the same weight tile.
+template <int EPI, bool FP8, int NW, bool WNT>
+__global__ __launch_bounds__(64 * NW, 4) void tile_gemm_kernel(const TileParams p) {
+    constexpr int kNW = NW;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];   // NW x kWaveLds
     const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, kh = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // provably wave-uniform: scalar base addresses
     // block id -> (weight tile, M tile): block b runs on XCD b % 8; the M tiles of one weight tile stay on one XCD
@@ -158,8 +168,7 @@ __global__ __launch_bounds__(512, 4) void tile_gemm_kernel(const TileParams p) {
     a_load(0);
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
-        const u32x4 v = __builtin_nontemporal_load(
-            reinterpret_cast<const u32x4*>(wbase + (s < ksteps_w ? s : ksteps_w - 1) * 512 + lane * 8));
+        const u32x4 v = ld_w<WNT>(wbase + (s < ksteps_w ? s : ksteps_w - 1) * 512 + lane * 8);
         wr[s] = *reinterpret_cast<const bf16x8*>(&v);
     }
     const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -174,8 +183,7 @@ __global__ __launch_bounds__(512, 4) void tile_gemm_kernel(const TileParams p) {
             const bool live = st < nst;                               // wave-uniform; only the last chunk can be short
             bf16x8 b = wr[st];
             const int nxt = c * 8 + st + 8;
-            const u32x4 v = __builtin_nontemporal_load(
-                reinterpret_cast<const u32x4*>(wbase + (nxt < ksteps_w ? nxt : ksteps_w - 1) * 512 + lane * 8));
+            const u32x4 v = ld_w<WNT>(wbase + (nxt < ksteps_w ? nxt : ksteps_w - 1) * 512 + lane * 8);
             wr[st] = *reinterpret_cast<const bf16x8*>(&v);
             bf16x8 a = *reinterpret_cast<const bf16x8*>(a_frag + st * 32);
             if (!live) {                                              // stale LDS may hold NaN: 0 x 0, not 0 x garbage
@@ -193,6 +201,7 @@ __global__ __launch_bounds__(512, 4) void tile_gemm_kernel(const TileParams p) {
     for (int r = 0; r < 16; ++r) red[((r & 3) + 8 * (r >> 2) + 4 * kh) * 32 + j] = acc[r];
     __syncthreads();
 
+    if (NW > 8 && tid >= 512) return;                     // 512 threads finish the 32 x 32 tile (one column pair each)
     const int row = tid >> 4, cp = tid & 15;
     const int gm = m0 + row;
     auto tile_sum2 = [&](int col) -> f32x2 {              // columns col, col+1 of row `row`, summed in wave order
@@ -257,6 +266,10 @@ __global__ __launch_bounds__(512, 4) void tile_gemm_kernel(const TileParams p) {
                                               &over);
             // one count per dropped row (as md_rope_append): the thread holding the row's first K pair reports it
             if (over && !is_v && nn == 0) atomicAdd(p.overflow, 1u);
+            // what the cache receives is the bf16 tensor k / v of the reference (RoPE output rounded to bf16) -- an fp8
+            // page quantises THAT value, not the fp32 rotation result (md_rope_append does the same)
+            y0 = bf16_to_f32(f32_to_bf16(y0));
+            y1 = bf16_to_f32(f32_to_bf16(y1));
             if (d1 >= 0) {
                 float inv = 1.f;
                 if constexpr (FP8) inv = 1.0f / (is_v ? p.v_scale[h] : p.k_scale[h]);
@@ -272,10 +285,10 @@ __global__ __launch_bounds__(512, 4) void tile_gemm_kernel(const TileParams p) {
     }
 }
 
-template <int EPI, bool FP8>
-int launch_tile(const TileParams& p, hipStream_t st) {
-    constexpr int lds = kNW * kWaveLds;
-    auto k = tile_gemm_kernel<EPI, FP8>;
+template <int EPI, bool FP8, int NW, bool WNT>
+int launch_tile_cfg(const TileParams& p, hipStream_t st) {
+    constexpr int lds = NW * kWaveLds;
+    auto k = tile_gemm_kernel<EPI, FP8, NW, WNT>;
     static MdPerDeviceOnce once;
     if (once.first()) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds) !=
@@ -286,13 +299,29 @@ int launch_tile(const TileParams& p, hipStream_t st) {
         }
     }
     const int grid = ((p.n_tiles + 7) / 8) * 8 * p.m_tiles;
-    hipLaunchKernelGGL(k, dim3(grid), dim3(512), lds, st, p);
+    hipLaunchKernelGGL(k, dim3(grid), dim3(64 * NW), lds, st, p);
     return MD_OK;
+}
+
+int g_force_nw = 0;   // dev knob (md_debug_set_fused_nw): 0 = the rule below, 8 / 16 = forced where the shape allows
+
+template <int EPI, bool FP8>
+int launch_tile(const TileParams& p, hipStream_t st) {
+    // 16 wavefronts (K/16 slices) when the grid is too small to put two 8-wave workgroups on every CU
+    const int wgs = p.n_tiles * p.m_tiles;
+    bool nw16 = p.K % 256 == 0 && wgs <= 384;
+    if (g_force_nw == 8) nw16 = false;
+    if (g_force_nw == 16) nw16 = p.K % 256 == 0;
+    const bool wnt = p.m_tiles == 1;
+    if (nw16) return wnt ? launch_tile_cfg<EPI, FP8, 16, true>(p, st) : launch_tile_cfg<EPI, FP8, 16, false>(p, st);
+    return wnt ? launch_tile_cfg<EPI, FP8, 8, true>(p, st) : launch_tile_cfg<EPI, FP8, 8, false>(p, st);
 }
 
 bool aligned16(const void* q) { return ((uintptr_t)q & 15) == 0; }
 
 }  // namespace
+
+extern "C" void md_debug_set_fused_nw(int nw) { g_force_nw = (nw == 8 || nw == 16) ? nw : 0; }
 
 extern "C" int md_linear_fused_supported(int M, int N, int K, int epilogue) {
     if (M < 1 || M > 256 || K < 128 || K % 128 || N < 32 || N % 32) return 0;

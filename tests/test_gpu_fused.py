@@ -108,6 +108,9 @@ QKV_CASES = [
     ("fp8-pages-hnd", 3, 4, 10, 2, 128, 640, [260, 131, 9], "HND", True, False, True, True),
     ("fp8-pages-nhd", 2, 1, 4, 1, 64, 256, [129, 64], "NHD", True, False, False, False),
     ("tp8-shard-one-kv-head", 64, 4, 4, 1, 128, 4096, [16036 % 640 + 130] * 64, "HND", False, False, False, False),
+    ("two-m-tiles-small-k", 16, 4, 4, 1, 128, 256, [166] * 16, "NHD", False, False, False, False),
+    ("eight-m-tiles-k512", 64, 4, 4, 1, 128, 512, [166] * 64, "NHD", False, False, False, False),
+    ("draft-1b-tp1-b64", 64, 1, 32, 8, 64, 2048, [258] * 64, "NHD", False, False, False, False),
 ]
 
 
@@ -149,7 +152,13 @@ def test_fused_qkv_rope_append_bit_exact(ops, name, B, n, H, KH, D, K, lens, lay
                                       d(last2) if two else None, kv_scales=scales, kv_layout=layout)
     torch.cuda.synchronize()
     raw = (lambda t: t.contiguous().view(torch.uint8)) if fp8 else bits
-    assert torch.equal(bits(got_q), bits(want_q))
+    if not torch.equal(bits(got_q), bits(want_q)):
+        neq = torch.nonzero(bits(got_q.view(M, -1)) != bits(want_q.view(M, -1))).cpu()
+        rows, cols = sorted(set(neq[:, 0].tolist())), sorted(set(neq[:, 1].tolist()))
+        r0, c0 = int(neq[0, 0]), int(neq[0, 1])
+        raise AssertionError(("q differs", len(neq), "rows", rows[:40], len(rows), "cols", cols[:40], len(cols), "first",
+                              (r0, c0), float(got_q.view(M, -1)[r0, c0]), float(want_q.view(M, -1)[r0, c0]),
+                              "plain", float(qkv[r0, c0])))
     assert torch.equal(raw(c1b), raw(c1a))
     assert not torch.equal(raw(c1b), raw(d(cache)))                  # something was appended
     if two:
