@@ -471,10 +471,18 @@ def run(args, dev):
                    "weights": "seeded random init (no checkpoints on the box)",
                    "hip_graphs": bool(engine._use_graphs),
                    "gemm": gemm_mode,
+                   "fused_linear": {"auto": "md_linear_fused (linear + rope/append | residual add | SiLU*mul in one "
+                                            "launch) for the launch-bound small products (Engine/gemm_policy.py)",
+                                    "0": "off", "1": "forced on"}[gemm_policy.fused_mode()],
+                   "packed_weight_copies_bytes": int(getattr(engine.model, "packed_bytes", 0)
+                                                     + (getattr(draft.model, "packed_bytes", 0) if draft is not None
+                                                        else 0)),
                    **({"emulated_tp_rank0_of": emu} if emu > 1 else {}),
                    "allreduce": (None if not use_tp else
                                  "oneshot-ipc" if getattr(engine.model, "_oneshot", None) is not None else "rccl"),
-                   "allreduce_timeouts": ar_timeouts},
+                   "allreduce_timeouts": ar_timeouts,
+                   "allreduce_plan": allreduce_plan(engine, draft, B, G, len(rank_group), len(draft_ranks)) if use_tp
+                   else None},
         "speedup_vs_autoregressive": round(value / base_tps, 4),
         "alpha_sensitivity": {f"{al:.1f}": {"tokens_per_s": round(tok / dt, 1), "speedup": round(tok / dt / base_tps, 3),
                                             "tokens_per_iter_per_seq": round(tok / B, 3),
@@ -512,6 +520,27 @@ def run(args, dev):
         dist.barrier()
         dist.destroy_process_group()
     return line if rank == 0 else None
+
+
+def allreduce_plan(engine, draft, B, G, tp, draft_tp):
+    """Which implementation carries each per-layer all-reduce of this run, by message (what the JSON line documents so
+    that a scaling number can be attributed): RCCL (captured inside the step's hipGraph), or -- MAGICDEC_ONESHOT_AR=1 and
+    the start-up self-test against RCCL passed -- the xGMI kernels of csrc/allreduce.hip under MD_AR_ALGO_AUTO
+    (two-shot for >= 4 ranks and messages > 512 KiB, else one-shot), fused with the residual add + RMSNorm."""
+    def one(model, rows, world):
+        if model is None or world <= 1:
+            return None
+        dim = model.tok_embeddings.weight.shape[1]
+        nbytes = rows * dim * 2
+        if getattr(model, "_oneshot", None) is None:
+            algo = "rccl all_reduce (in-graph) + md_add_rmsnorm"
+        else:
+            algo = ("xgmi two-shot" if (world >= 4 and nbytes > 512 * 1024) else "xgmi one-shot") + " fused add+rmsnorm"
+        return {"rows": rows, "bytes": nbytes, "ranks": world, "per_forward": 2 * len(model.layers), "impl": algo}
+    return {"verify": one(engine.model, B * (G + 1), tp), "autoregressive": one(engine.model, B, tp),
+            "draft_step": one(draft.model if draft is not None else None, B, draft_tp),
+            "argmax_merge": "2 x rccl all_reduce of [rows, ranks] per forward", "draft_tokens": "rccl broadcast per iteration"
+            if draft_tp != tp else None}
 
 
 def collective_microbench_isolated(shapes, iters=30, timeout_s=240, dry=False):

@@ -25,10 +25,19 @@ _MODE = os.environ.get("MAGICDEC_GEMM", "auto")
 _FUSED = os.environ.get("MAGICDEC_FUSED", "auto")     # "0": never md_linear_fused, "1": wherever it supports the shape
 MIN_STREAM_BYTES = 60e6        # bf16 weight bytes of one call above which the streaming kernel wins at M <= 64
 MIN_STREAM_BYTES_M128 = 100e6
-# md_linear_fused reads a weight tile once per 32-row M tile (through L2) and the activations once per weight tile: it
-# is the launch-bound regime's kernel.  Rule (tools/fused_bench.py A/B, profiles/r03_fused_ab.txt): take it while the
-# bytes its workgroups pull on chip, m_tiles x weight bytes, stay below FUSED_MAX_L2_BYTES
-FUSED_MAX_L2_BYTES = 150e6
+# md_linear_fused reads a weight tile once per 32-row M tile (through L2) and a 32-row slab of the activations once per
+# weight tile: it is the launch-bound regime's kernel.  Rules from the A/B of tools/fused_bench.py
+# (profiles/r03_fused_ab.txt; "unfused" there = hipBLASLt + the small kernel behind it, graph-captured, weights cycled):
+#   * M <= 128 (draft steps, autoregressive target steps): fused while m_tiles x weight bytes <= 70 MB and K <= 4096 --
+#     the 1B model's wqkv 8.0 vs 15.6 us, wo 10.3 vs 12.2, every TP4 shard of it (6.1-9.8 vs 10.0-15.0), every TP8
+#     shard of the 8B model at M = 64 (8.9-12.9 vs 10.8-15.7).  Above that the x slab (M x K, one hot MB) is re-read by
+#     every column tile through the same L2 channels and the kernel falls behind (1B w2, K = 8192: 23.6 vs 19.0;
+#     1B w1|w3, 1024 tiles: 22.2 vs 20.4) -- those stay on md_linear / the library;
+#   * M = 256 (verify): only the qkv projection with its rope+append epilogue (8B/8: 9.2 vs 14.0 us, 8B/4: 18.5 vs
+#     19.8); wo / w1|w3 / w2 shards are served faster by the library (14.4 vs 14.1, 30.2 vs 22.9, 23.0 vs 16.6).
+FUSED_MAX_L2_BYTES = 70e6
+FUSED_MAX_K = 4096
+FUSED_QKV_M256_MAX_L2_BYTES = 110e6
 
 
 def set_mode(mode: str):
@@ -61,12 +70,16 @@ def want_packed(N: int, K: int) -> bool:
     return _FUSED != "0" and N % 32 == 0
 
 
-def use_fused(M: int, N: int, K: int) -> bool:
+def use_fused(M: int, N: int, K: int, kind: str = "plain") -> bool:
+    """kind: "qkv" (rope+append epilogue), "resid", "swiglu" or "plain"."""
     if _MODE == "lib" or _FUSED == "0" or M > 256 or K % 128 or N % 32:
         return False
     if _FUSED == "1":
         return True
-    return ((M + 31) // 32) * N * K * 2 <= FUSED_MAX_L2_BYTES
+    l2_bytes = ((M + 31) // 32) * N * K * 2
+    if M <= 128:
+        return l2_bytes <= FUSED_MAX_L2_BYTES and K <= FUSED_MAX_K
+    return kind == "qkv" and l2_bytes <= FUSED_QKV_M256_MAX_L2_BYTES and K <= FUSED_MAX_K
 
 
 def use_skinny(M: int, N: int, K: int, swiglu: bool, int8: bool, packed: bool) -> bool:
@@ -84,9 +97,9 @@ def use_skinny(M: int, N: int, K: int, swiglu: bool, int8: bool, packed: bool) -
     return K >= 8192 and nbytes >= MIN_STREAM_BYTES_M128
 
 
-def choose(M: int, N: int, K: int, swiglu: bool, int8: bool, packed: bool) -> str:
+def choose(M: int, N: int, K: int, swiglu: bool, int8: bool, packed: bool, kind: str = None) -> str:
     """"fused" (md_linear_fused), "skinny" (md_linear) or "lib" (hipBLASLt) for one linear of a step."""
-    if packed and not int8 and use_fused(M, N, K) and not (_FUSED == "auto" and use_skinny(M, N, K, swiglu, int8, packed)
-                                                           and N * K * 2 >= MIN_STREAM_BYTES):
+    kind = kind or ("swiglu" if swiglu else "plain")
+    if packed and not int8 and use_fused(M, N, K, kind):
         return "fused"
     return "skinny" if use_skinny(M, N, K, swiglu, int8, packed) else "lib"

@@ -362,7 +362,8 @@ class Transformer(nn.Module):
         N = w.shape[0]
         swiglu = swiglu_w13 is not None
         pk = self._packed.get(id(w))
-        how = choose(M, N, K, swiglu, w.dtype == torch.int8, pk is not None) if x2d.is_cuda else "lib"
+        kind = "swiglu" if swiglu else ("resid" if resid is not None else "plain")
+        how = choose(M, N, K, swiglu, w.dtype == torch.int8, pk is not None, kind) if x2d.is_cuda else "lib"
         if how == "fused" and ops.fused_linear_supported(M, N, K):
             return ops.fused_linear(x2d, pk, bias, swiglu=swiglu, resid=resid)
         assert resid is None, "the residual epilogue exists on the fused kernel only"
@@ -377,21 +378,22 @@ class Transformer(nn.Module):
             return ops.silu_mul(h[:, :inter], h[:, inter:])
         return h
 
-    def _fused_here(self, x2d, w):
-        """Does the fused kernel serve the linear `w` for these rows?  (policy + shape support + a packed bf16 copy)"""
+    def _fused_here(self, x2d, w, kind):
+        """Does the fused kernel serve the linear `w` with epilogue `kind` ("qkv" | "resid") for these rows?
+        (policy + shape support + a packed bf16 copy)"""
         from .gemm_policy import choose
         M, K = x2d.shape
         N = w.shape[0]
         pk = self._packed.get(id(w))
         return (x2d.is_cuda and pk is not None and w.dtype != torch.int8
-                and choose(M, N, K, False, False, True) == "fused" and ops.fused_linear_supported(M, N, K))
+                and choose(M, N, K, False, False, True, kind) == "fused" and ops.fused_linear_supported(M, N, K))
 
     def _proj_add_norm(self, inp, lin, x, norm, group):
         """Output projection of a sub-layer (wo / w2), the residual add and the RMSNorm for the next sub-layer:
         (h, y) = (x + sum_ranks(inp . W^T), rmsnorm(h) * w).  Without tensor parallelism and on a launch-bound shape the
         projection and the residual add are one launch (md_linear_fused, MD_FL_RESID) and the norm reads h; otherwise
         the projection, then `_reduce_add_norm` (collective + fused add + norm)."""
-        if group is None and x.is_contiguous() and self._fused_here(inp, lin.weight):
+        if group is None and x.is_contiguous() and self._fused_here(inp, lin.weight, "resid"):
             h = self._linear(inp, lin, resid=x)
             return h, ops.rmsnorm(h, norm.weight, norm.eps)
         return self._reduce_add_norm(self._linear(inp, lin), x, norm, group)
@@ -478,7 +480,7 @@ class Transformer(nn.Module):
             scales = kvc.scales(which)
             layout = kvc.layout_of(which)
             need_calib = scales is not None and calibrate and not kvc.calibrated
-            if not need_calib and self._fused_here(y, att.wqkv.weight) and c.head_dim in (64, 128):
+            if not need_calib and self._fused_here(y, att.wqkv.weight, "qkv") and c.head_dim in (64, 128):
                 # wqkv + bias + RoPE + paged append (both caches of a self-speculation verify): ONE launch
                 q_rot = ops.fused_qkv_rope_append(
                     y, self._packed[id(att.wqkv.weight)], att.wqkv.bias, c.n_head, c.n_local_heads, c.head_dim, n,

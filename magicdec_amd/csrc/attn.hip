@@ -933,7 +933,8 @@ int launch_attn(const AttnParams& p, int grid, hipStream_t st) {
     return MD_OK;
 }
 
-int g_prefill_kt = 64;    // dev knob (md_debug_set_prefill_kt): keys per shared tile of the bf16 prefill kernel
+int g_prefill_kt = 64;    // dev knob (md_debug_set_prefill_kt): keys per shared tile of the bf16 prefill kernel (D = 64)
+bool g_prefill_kt_force128 = false;   // ... forced to 64 at D = 128 as well (experiments; slower, see launch_prefill)
 
 template <int D, int QT, bool FP8, int NW, int KT>
 int launch_prefill_kt(const AttnParams& p, int grid, hipStream_t st) {
@@ -957,9 +958,17 @@ int launch_prefill_kt(const AttnParams& p, int grid, hipStream_t st) {
 
 template <int D, int QT, bool FP8>
 int launch_prefill(const AttnParams& p, int grid, int nw, hipStream_t st) {
-    if constexpr (!FP8) {
-        // 64-key shared tiles (bf16 pages); the fp8 staging path (two conversions per load) keeps 32-key tiles
+    if constexpr (!FP8 && D == 64) {
+        // 64-key shared tiles where the registers allow it: D = 64, bf16 pages -- 580 vs 450 TFLOP/s at the 1B draft
+        // model's prefill shape (profiles/r03_prefill_ab.txt).  At D = 128 the 64-key body needs 256 VGPRs + 43 spilled
+        // (o 64 + q 32 + s 32 + p 16 ...) and LOSES (587 vs 663 TFLOP/s); the fp8 staging path (two conversions per
+        // load) was not generalised.  md_debug_set_prefill_kt(64, .) still forces it at D = 128 for experiments.
         if (g_prefill_kt == 64)
+            return nw == 8 ? launch_prefill_kt<D, QT, FP8, 8, 64>(p, grid, st)
+                           : launch_prefill_kt<D, QT, FP8, 4, 64>(p, grid, st);
+    }
+    if constexpr (!FP8 && D == 128) {
+        if (g_prefill_kt_force128)
             return nw == 8 ? launch_prefill_kt<D, QT, FP8, 8, 64>(p, grid, st)
                            : launch_prefill_kt<D, QT, FP8, 4, 64>(p, grid, st);
     }
@@ -971,6 +980,7 @@ int launch_prefill(const AttnParams& p, int grid, int nw, hipStream_t st) {
 extern "C" void md_debug_set_attn_target_wgs(int n) { g_target_wgs = n > 0 ? n : 256; }
 extern "C" void md_debug_set_prefill_kt(int kt, int nw) {
     g_prefill_kt = kt == 32 ? 32 : 64;
+    g_prefill_kt_force128 = kt == 128;          // kt = 128: 64-key tiles at D = 128 too
     g_prefill_nw = (nw == 4 || nw == 8) ? nw : 0;
 }
 
