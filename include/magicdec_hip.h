@@ -265,6 +265,7 @@ int md_linear(const void* x, int64_t ldx, const void* w, int w_dtype, int w_pack
  *                      row j of request b has RoPE position offsets[b] + j and cache position len_b - rows_per_req + j
  *                      (page table already advanced, as md_rope_append); kv_dtype / scales / cache2 as md_rope_append.
  *                      Results are bit-identical to md_linear_fused(MD_FL_NONE) followed by md_rope_append.
+ * Deferred RMSNorm: see the last five fields of md_fused_linear_args.
  * ---------------------------------------------------------------------- */
 #define MD_FL_NONE 0
 #define MD_FL_SWIGLU 1
@@ -292,6 +293,16 @@ typedef struct md_fused_linear_args {
     const int32_t* last_page_len2;
     const float* k_scale;     /* fp8 pages: per-kv-head scales */
     const float* v_scale;
+    /* deferred RMSNorm (both optional).  MD_FL_RESID with ssq_out: also writes ssq_out[M][N/32] = per row, the sum of
+     * squares of each 32-column tile of `out`.  MD_FL_SWIGLU / MD_FL_ROPE_APPEND with pro_ssq: x is the UN-normalised
+     * hidden state h [M][K]; the kernel forms rstd = rsqrt(sum_t pro_ssq[row][t] / K + pro_eps) (t < pro_tiles, fixed
+     * order) and feeds y = bf16(bf16(h * rstd) * pro_norm_w) into the product -- md_rmsnorm's arithmetic, only the
+     * order of the fp32 sum of squares differs. */
+    float* ssq_out;
+    const float* pro_ssq;
+    const void* pro_norm_w;   /* bf16 [K] */
+    float pro_eps;
+    int pro_tiles;
 } md_fused_linear_args;
 int md_linear_fused_supported(int M, int N, int K, int epilogue);
 void md_debug_set_fused_nw(int nw); /* development: wavefronts (K slices) per workgroup, 8 | 16; 0 = the measured rule */

@@ -38,6 +38,10 @@ MIN_STREAM_BYTES_M128 = 100e6
 FUSED_MAX_L2_BYTES = 70e6
 FUSED_MAX_K = 4096
 FUSED_QKV_M256_MAX_L2_BYTES = 110e6
+# a linear that can ALSO absorb the RMSNorm in front of it (deferred norm: its input is the un-normalised h of a fused
+# residual epilogue) saves that launch (~5 us + a boundary): the 1B w1|w3 at M = 64 (134 MB of tile traffic, 22.2 us
+# against md_linear's 21.9) then wins on the fused kernel
+FUSED_MAX_L2_BYTES_WITH_NORM = 140e6
 
 
 def set_mode(mode: str):
@@ -70,15 +74,16 @@ def want_packed(N: int, K: int) -> bool:
     return _FUSED != "0" and N % 32 == 0
 
 
-def use_fused(M: int, N: int, K: int, kind: str = "plain") -> bool:
-    """kind: "qkv" (rope+append epilogue), "resid", "swiglu" or "plain"."""
+def use_fused(M: int, N: int, K: int, kind: str = "plain", absorbs_norm: bool = False) -> bool:
+    """kind: "qkv" (rope+append epilogue), "resid", "swiglu" or "plain"; absorbs_norm: the call would also apply a
+    deferred RMSNorm to its input."""
     if _MODE == "lib" or _FUSED == "0" or M > 256 or K % 128 or N % 32:
         return False
     if _FUSED == "1":
         return True
     l2_bytes = ((M + 31) // 32) * N * K * 2
     if M <= 128:
-        return l2_bytes <= FUSED_MAX_L2_BYTES and K <= FUSED_MAX_K
+        return l2_bytes <= (FUSED_MAX_L2_BYTES_WITH_NORM if absorbs_norm else FUSED_MAX_L2_BYTES) and K <= FUSED_MAX_K
     return kind == "qkv" and l2_bytes <= FUSED_QKV_M256_MAX_L2_BYTES and K <= FUSED_MAX_K
 
 
@@ -97,9 +102,10 @@ def use_skinny(M: int, N: int, K: int, swiglu: bool, int8: bool, packed: bool) -
     return K >= 8192 and nbytes >= MIN_STREAM_BYTES_M128
 
 
-def choose(M: int, N: int, K: int, swiglu: bool, int8: bool, packed: bool, kind: str = None) -> str:
+def choose(M: int, N: int, K: int, swiglu: bool, int8: bool, packed: bool, kind: str = None,
+           absorbs_norm: bool = False) -> str:
     """"fused" (md_linear_fused), "skinny" (md_linear) or "lib" (hipBLASLt) for one linear of a step."""
     kind = kind or ("swiglu" if swiglu else "plain")
-    if packed and not int8 and use_fused(M, N, K, kind):
+    if packed and not int8 and use_fused(M, N, K, kind, absorbs_norm):
         return "fused"
     return "skinny" if use_skinny(M, N, K, swiglu, int8, packed) else "lib"

@@ -345,27 +345,37 @@ class Transformer(nn.Module):
                 dist.all_reduce(y, group=group)
         return y
 
-    def _linear(self, x2d, lin, swiglu_w13=None, resid=None):
+    def _linear(self, x2d, lin, swiglu_w13=None, resid=None, want_ssq=False):
         """One linear of a step.  Three implementations, chosen per shape by the measured rules of
         Engine/gemm_policy.py: md_linear_fused (csrc/tilegemm.hip: the launch-bound small products -- draft-model
         linears, tensor-parallel shards -- in one launch together with their epilogue), md_linear (csrc/gemm.hip: the
         long weight streams, split-K + combine) or the library GEMM (prefill-sized M, and whatever the A/B gave it).
         `swiglu_w13 = (w13, s13)`: the fused w1|w3 product with the SiLU*mul epilogue.
         `resid`: return bf16(resid + linear) instead (the residual add of the block; only honoured by the fused
-        kernel -- callers check `_fusable_resid` first)."""
+        kernel -- callers check `_fused_here` first); with `want_ssq` also the per-row partial sums of squares of the
+        result (the producer half of a deferred RMSNorm).  `x2d` may be an `ops.DeferredNorm`: the fused w1|w3 kernel
+        applies it on the fly, every other path materialises it first."""
         from .gemm_policy import choose
         if swiglu_w13 is not None:
             w, scales, bias = swiglu_w13[0], swiglu_w13[1], None
         else:
             w, scales, bias = lin.weight, getattr(lin, "scales", None), lin.bias
+        pro = x2d if isinstance(x2d, ops.DeferredNorm) else None      # a norm still to be applied to the input
+        if pro is not None:
+            x2d = pro.h
         M, K = x2d.shape
         N = w.shape[0]
         swiglu = swiglu_w13 is not None
         pk = self._packed.get(id(w))
         kind = "swiglu" if swiglu else ("resid" if resid is not None else "plain")
-        how = choose(M, N, K, swiglu, w.dtype == torch.int8, pk is not None, kind) if x2d.is_cuda else "lib"
+        how = (choose(M, N, K, swiglu, w.dtype == torch.int8, pk is not None, kind, pro is not None and swiglu)
+               if x2d.is_cuda else "lib")
         if how == "fused" and ops.fused_linear_supported(M, N, K):
-            return ops.fused_linear(x2d, pk, bias, swiglu=swiglu, resid=resid)
+            if pro is not None and not swiglu:
+                x2d, pro = pro.materialize(), None
+            return ops.fused_linear(x2d, pk, bias, swiglu=swiglu, resid=resid, want_ssq=want_ssq, pro=pro)
+        if pro is not None:
+            x2d = pro.materialize()
         assert resid is None, "the residual epilogue exists on the fused kernel only"
         if how in ("fused", "skinny") and ops.linear_supported(M, N, K, swiglu):
             return ops.linear(x2d, pk if pk is not None else w, bias, scales, swiglu, self.workspace)
@@ -378,7 +388,7 @@ class Transformer(nn.Module):
             return ops.silu_mul(h[:, :inter], h[:, inter:])
         return h
 
-    def _fused_here(self, x2d, w, kind):
+    def _fused_here(self, x2d, w, kind, absorbs_norm=False):
         """Does the fused kernel serve the linear `w` with epilogue `kind` ("qkv" | "resid") for these rows?
         (policy + shape support + a packed bf16 copy)"""
         from .gemm_policy import choose
@@ -386,16 +396,20 @@ class Transformer(nn.Module):
         N = w.shape[0]
         pk = self._packed.get(id(w))
         return (x2d.is_cuda and pk is not None and w.dtype != torch.int8
-                and choose(M, N, K, False, False, True, kind) == "fused" and ops.fused_linear_supported(M, N, K))
+                and choose(M, N, K, False, False, True, kind, absorbs_norm) == "fused"
+                and ops.fused_linear_supported(M, N, K))
 
     def _proj_add_norm(self, inp, lin, x, norm, group):
         """Output projection of a sub-layer (wo / w2), the residual add and the RMSNorm for the next sub-layer:
         (h, y) = (x + sum_ranks(inp . W^T), rmsnorm(h) * w).  Without tensor parallelism and on a launch-bound shape the
-        projection and the residual add are one launch (md_linear_fused, MD_FL_RESID) and the norm reads h; otherwise
-        the projection, then `_reduce_add_norm` (collective + fused add + norm)."""
+        projection and the residual add are one launch (md_linear_fused, MD_FL_RESID) and y is returned as an
+        `ops.DeferredNorm`; otherwise the projection, then `_reduce_add_norm` (collective + fused add + norm)."""
         if group is None and x.is_contiguous() and self._fused_here(inp, lin.weight, "resid"):
-            h = self._linear(inp, lin, resid=x)
-            return h, ops.rmsnorm(h, norm.weight, norm.eps)
+            # the norm is DEFERRED: the residual epilogue leaves the per-row partial sums of squares, and the linear that
+            # consumes the normalised rows (w1|w3, the next layer's wqkv) applies rmsnorm on the fly; a consumer that
+            # cannot (library GEMM, lm head) materialises it with the stand-alone kernel
+            h, ssq = self._linear(inp, lin, resid=x, want_ssq=True)
+            return h, ops.DeferredNorm(h, ssq, norm.weight, norm.eps)
         return self._reduce_add_norm(self._linear(inp, lin), x, norm, group)
 
     def _reduce_add_norm(self, partial, x, norm, group):
@@ -441,7 +455,7 @@ class Transformer(nn.Module):
             x, y = self._proj_add_norm(act, layer.feed_forward.w2, x, nxt, layer.feed_forward.process_group)
         if self.skip_head:
             return None
-        logits = self._linear(y, self.output)                         # [rows, vocab / tp]
+        logits = self._linear(y, self.output)                         # [rows, vocab / tp]; materialises a deferred norm
         self._last_logits = logits
         return self._argmax(logits).view(B, n)
 
@@ -480,14 +494,19 @@ class Transformer(nn.Module):
             scales = kvc.scales(which)
             layout = kvc.layout_of(which)
             need_calib = scales is not None and calibrate and not kvc.calibrated
-            if not need_calib and self._fused_here(y, att.wqkv.weight, "qkv") and c.head_dim in (64, 128):
-                # wqkv + bias + RoPE + paged append (both caches of a self-speculation verify): ONE launch
+            pro = y if isinstance(y, ops.DeferredNorm) else None
+            yin = pro.h if pro is not None else y
+            if not need_calib and self._fused_here(yin, att.wqkv.weight, "qkv", pro is not None) and c.head_dim in (64, 128):
+                # (deferred RMSNorm +) wqkv + bias + RoPE + paged append (both caches of a self-speculation verify):
+                # ONE launch
                 q_rot = ops.fused_qkv_rope_append(
-                    y, self._packed[id(att.wqkv.weight)], att.wqkv.bias, c.n_head, c.n_local_heads, c.head_dim, n,
+                    yin, self._packed[id(att.wqkv.weight)], att.wqkv.bias, c.n_head, c.n_local_heads, c.head_dim, n,
                     offsets, self.rope_table, cache, tab.indices, tab.indptr, tab.last_page_len, cache2,
                     tab2.indices if tab2 else None, tab2.indptr if tab2 else None,
-                    tab2.last_page_len if tab2 else None, kv_scales=scales, kv_layout=layout)
+                    tab2.last_page_len if tab2 else None, kv_scales=scales, kv_layout=layout, pro=pro)
             else:
+                if pro is not None:
+                    y = pro.materialize()
                 q, k, v, _ = self._qkv(layer, y)
                 if need_calib:
                     if self.kv_scale_override is not None:
@@ -539,6 +558,8 @@ class Transformer(nn.Module):
         dev = idx.device
 
         def fn(i, layer, y, n):
+            if isinstance(y, ops.DeferredNorm):
+                y = y.materialize()
             q, k, v, _ = self._qkv(layer, y)
             cache = getattr(layer.attention.kv_cache, which)
             ppr = cache.shape[0] // B

@@ -11,7 +11,7 @@ from ctypes import c_char_p, c_double, c_float, c_int, c_int64, c_size_t, c_void
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmagicdec_hip.so")
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 _lib = None
 _err = None
@@ -29,7 +29,8 @@ class FusedLinearArgs(ctypes.Structure):
                 ("offsets", P), ("cos_sin", P),
                 ("cache", P), ("page_indices", P), ("page_indptr", P), ("last_page_len", P),
                 ("cache2", P), ("page_indices2", P), ("page_indptr2", P), ("last_page_len2", P),
-                ("k_scale", P), ("v_scale", P)]
+                ("k_scale", P), ("v_scale", P),
+                ("ssq_out", P), ("pro_ssq", P), ("pro_norm_w", P), ("pro_eps", c_float), ("pro_tiles", I)]
 
 
 _SIGNATURES = {

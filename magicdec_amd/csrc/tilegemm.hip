@@ -33,6 +33,15 @@
 //       ROPE_APPEND  qkv = bf16(acc + bias); q columns: interleaved RoPE (fp32 table, un-fused mul/add: bit-identical
 //                    to md_rope_append) -> q_out; k columns: RoPE -> paged cache(s); v columns -> paged cache(s)
 //                    (bf16 or fp8 e4m3 pages, NHD or HND, optional second bf16 cache; page table read on the device).
+//
+// Deferred RMSNorm (the norm between two fused linears without a launch of its own).  The reference's block is
+// h = x + wo(...); y = rmsnorm(h) * w; ... = w13(y).  A tile kernel cannot normalise what it produces (a row's sum of
+// squares spans all column tiles), so the work is split: the RESID epilogue also writes, per row, the sum of squares of
+// ITS 32 columns of h (`ssq_out[M][N/32]`, a fixed-order 16-lane reduction), and the consuming linear (PRO = true) takes
+// the un-normalised h as x: it adds a row's N/32 partials in a fixed order, forms rstd = rsqrt(sum / K + eps) exactly as
+// md_rmsnorm does, and applies y = bf16(bf16(h * rstd) * w) -- the reference's rounding points
+// (Engine/SnapKV/model.py:464-469) -- to its activation slice on the way from registers to the LDS image.  Only the
+// order of the fp32 sum of squares differs from the stand-alone kernel's.
 #include "md_common.h"
 
 unsigned int* md_page_overflow_counter_device();   // kvops.hip: rows dropped beyond a request's mapped pages
@@ -70,6 +79,12 @@ struct TileParams {
     const float* k_scale;
     const float* v_scale;
     unsigned int* overflow;   // dropped-row counter (md_page_overflow_count)
+    // deferred RMSNorm (see the kernel header): producer side (RESID) / consumer side (PRO)
+    float* ssq_out;           // RESID: [M][n_tiles] sum of squares of the tile's 32 output columns per row, or null
+    const float* pro_ssq;     // PRO: [M][pro_tiles] partial sums of squares of the rows of x (x = the un-normalised h)
+    const bf16_t* pro_w;      // PRO: RMSNorm weight [K]
+    float pro_eps;
+    int pro_tiles;
 };
 
 __device__ __forceinline__ float silu_bf16(float h1) {
@@ -119,10 +134,10 @@ __device__ __forceinline__ int64_t kv_elem_offset(const KvTable& t, int b, int r
 // has in flight -- NW x (8 KiB of W + 8 KiB of x) -- are what its ingest rate is made of, ~50 GB/s per CU at NW = 8);
 // WNT = stream W with non-temporal loads (one M tile: every weight byte is read once) or keep it in L2 for the sibling
 // M tiles of the same weight tile.
-template <int EPI, bool FP8, int NW, bool WNT>
+template <int EPI, bool FP8, int NW, bool WNT, bool PRO>
 __global__ __launch_bounds__(64 * NW, 4) void tile_gemm_kernel(const TileParams p) {
     constexpr int kNW = NW;
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];   // NW x kWaveLds
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];   // NW x kWaveLds (+ 32 floats rstd when PRO)
     const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, kh = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // provably wave-uniform: scalar base addresses
     // block id -> (weight tile, M tile): block b runs on XCD b % 8; the M tiles of one weight tile stay on one XCD
@@ -147,17 +162,50 @@ __global__ __launch_bounds__(64 * NW, 4) void tile_gemm_kernel(const TileParams 
     }
     const int nchunk = (ksteps_w + 7) >> 3;
     u32x4 xa[8];
+    u32x4 nwv = {0u, 0u, 0u, 0u};                   // PRO: the norm weights of this lane's 8 columns of the chunk
+    float rs8[8];                                   // PRO: rstd of this lane's 8 staging rows
+    if constexpr (PRO) {
+        float* rstd_lds = reinterpret_cast<float*>(lds + NW * kWaveLds);
+        if (tid < 512) {
+            const int r = tid >> 4, part = tid & 15;
+            const int gr = m0 + r < p.M ? m0 + r : p.M - 1;
+            float t = 0.f;
+            for (int i = part; i < p.pro_tiles; i += 16) t += p.pro_ssq[(int64_t)gr * p.pro_tiles + i];
+            t += __shfl_xor(t, 1);
+            t += __shfl_xor(t, 2);
+            t += __shfl_xor(t, 4);
+            t += __shfl_xor(t, 8);
+            if (part == 0) rstd_lds[r] = rsqrtf(t / (float)p.K + p.pro_eps);      // md_rmsnorm's expression
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 8; ++i) rs8[i] = rstd_lds[4 * i + ar];
+    }
     auto a_load = [&](int c) {
         const int klen = min(ksteps_w - c * 8, 8) * 16;               // k elements of this chunk (wave-uniform)
         const unsigned int cc = (unsigned int)(c * kKC + (c16 * 8 < klen ? c16 : 0) * 8) * 2u;   // lanes past a short
                                                                       // tail chunk re-read its column 0
 #pragma unroll
         for (int i = 0; i < 8; ++i) xa[i] = *reinterpret_cast<const u32x4*>(xbase + (xrow[i] + cc));
+        if constexpr (PRO)
+            nwv = *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned char*>(p.pro_w + ks0 * 16) + cc);
     };
     auto a_store = [&]() {
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
-            *reinterpret_cast<u32x4*>(my_lds + (4 * i + ar) * kPitch + c16 * 16) = xa[i];
+        for (int i = 0; i < 8; ++i) {
+            u32x4 v = xa[i];
+            if constexpr (PRO) {
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    // y = bf16(bf16(h * rstd) * weight), element by element (two bf16 per dword)
+                    const float h0 = __uint_as_float(v[w] << 16), h1 = __uint_as_float(v[w] & 0xffff0000u);
+                    const float g0 = __uint_as_float(nwv[w] << 16), g1 = __uint_as_float(nwv[w] & 0xffff0000u);
+                    const float n0 = bf16_to_f32(f32_to_bf16(h0 * rs8[i])), n1 = bf16_to_f32(f32_to_bf16(h1 * rs8[i]));
+                    v[w] = pack2(n0 * g0, n1 * g1);
+                }
+            }
+            *reinterpret_cast<u32x4*>(my_lds + (4 * i + ar) * kPitch + c16 * 16) = v;
+        }
     };
 
     f32x16 acc;
@@ -240,7 +288,17 @@ __global__ __launch_bounds__(64 * NW, 4) void tile_gemm_kernel(const TileParams 
         } else if constexpr (EPI == FL_RESID) {
             const unsigned int rv = *reinterpret_cast<const unsigned int*>(p.resid + (int64_t)gm * p.ldr + n);
             const float r0 = __uint_as_float(rv << 16), r1 = __uint_as_float(rv & 0xffff0000u);
-            *reinterpret_cast<unsigned int*>(p.out + (int64_t)gm * p.ldo + n) = pack2(r0 + o0, r1 + o1);
+            const float h0 = bf16_to_f32(f32_to_bf16(r0 + o0)), h1 = bf16_to_f32(f32_to_bf16(r1 + o1));
+            *reinterpret_cast<unsigned int*>(p.out + (int64_t)gm * p.ldo + n) = pack2(h0, h1);
+            if (p.ssq_out) {
+                // sum of squares of this tile's 32 columns of row gm (the 16 lanes of the row, fixed butterfly order)
+                float q = h0 * h0 + h1 * h1;
+                q += __shfl_xor(q, 1);
+                q += __shfl_xor(q, 2);
+                q += __shfl_xor(q, 4);
+                q += __shfl_xor(q, 8);
+                if (cp == 0) p.ssq_out[(int64_t)gm * p.n_tiles + tn] = q;
+            }
         } else {                                            // FL_ROPE_APPEND
             const int HD = p.H * p.D, KD = p.KH * p.D;
             const int b = gm / p.rows_per_req, jrow = gm - b * p.rows_per_req;
@@ -285,10 +343,10 @@ __global__ __launch_bounds__(64 * NW, 4) void tile_gemm_kernel(const TileParams 
     }
 }
 
-template <int EPI, bool FP8, int NW, bool WNT>
+template <int EPI, bool FP8, int NW, bool WNT, bool PRO>
 int launch_tile_cfg(const TileParams& p, hipStream_t st) {
-    constexpr int lds = NW * kWaveLds;
-    auto k = tile_gemm_kernel<EPI, FP8, NW, WNT>;
+    constexpr int lds = NW * kWaveLds + (PRO ? 128 : 0);
+    auto k = tile_gemm_kernel<EPI, FP8, NW, WNT, PRO>;
     static MdPerDeviceOnce once;
     if (once.first()) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds) !=
@@ -305,16 +363,25 @@ int launch_tile_cfg(const TileParams& p, hipStream_t st) {
 
 int g_force_nw = 0;   // dev knob (md_debug_set_fused_nw): 0 = the rule below, 8 / 16 = forced where the shape allows
 
-template <int EPI, bool FP8>
-int launch_tile(const TileParams& p, hipStream_t st) {
+template <int EPI, bool FP8, bool PRO>
+int launch_tile_pro(const TileParams& p, hipStream_t st) {
     // 16 wavefronts (K/16 slices) when the grid is too small to put two 8-wave workgroups on every CU
     const int wgs = p.n_tiles * p.m_tiles;
     bool nw16 = p.K % 256 == 0 && wgs <= 384;
     if (g_force_nw == 8) nw16 = false;
     if (g_force_nw == 16) nw16 = p.K % 256 == 0;
     const bool wnt = p.m_tiles == 1;
-    if (nw16) return wnt ? launch_tile_cfg<EPI, FP8, 16, true>(p, st) : launch_tile_cfg<EPI, FP8, 16, false>(p, st);
-    return wnt ? launch_tile_cfg<EPI, FP8, 8, true>(p, st) : launch_tile_cfg<EPI, FP8, 8, false>(p, st);
+    if (nw16)
+        return wnt ? launch_tile_cfg<EPI, FP8, 16, true, PRO>(p, st) : launch_tile_cfg<EPI, FP8, 16, false, PRO>(p, st);
+    return wnt ? launch_tile_cfg<EPI, FP8, 8, true, PRO>(p, st) : launch_tile_cfg<EPI, FP8, 8, false, PRO>(p, st);
+}
+
+template <int EPI, bool FP8>
+int launch_tile(const TileParams& p, hipStream_t st) {
+    if constexpr (EPI == FL_SWIGLU || EPI == FL_ROPE_APPEND) {       // the linears that consume a normalised input
+        if (p.pro_ssq) return launch_tile_pro<EPI, FP8, true>(p, st);
+    }
+    return launch_tile_pro<EPI, FP8, false>(p, st);
 }
 
 bool aligned16(const void* q) { return ((uintptr_t)q & 15) == 0; }
@@ -348,6 +415,18 @@ extern "C" int md_linear_fused(const md_fused_linear_args* a, md_stream_t stream
     p.K = a->K;
     p.n_tiles = a->N / 32;
     p.m_tiles = (a->M + 31) / 32;
+    if (a->pro_ssq) {
+        MD_CHECK_ARG(a->epilogue == FL_SWIGLU || a->epilogue == FL_ROPE_APPEND,
+                     "md_linear_fused: the deferred-RMSNorm prologue exists for the qkv and w1|w3 linears");
+        MD_CHECK_ARG(a->pro_norm_w && a->pro_tiles > 0 && aligned16(a->pro_norm_w),
+                     "md_linear_fused: the deferred-RMSNorm prologue needs the norm weight (16-byte aligned) and pro_tiles");
+        p.pro_ssq = a->pro_ssq;
+        p.pro_w = (const bf16_t*)a->pro_norm_w;
+        p.pro_eps = a->pro_eps;
+        p.pro_tiles = a->pro_tiles;
+    }
+    MD_CHECK_ARG(!a->ssq_out || a->epilogue == FL_RESID, "md_linear_fused: ssq_out belongs to the residual epilogue");
+    p.ssq_out = a->ssq_out;
     hipStream_t st = (hipStream_t)stream;
     int rc = MD_OK;
     switch (a->epilogue) {

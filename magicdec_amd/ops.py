@@ -381,27 +381,62 @@ def _run_fused(a):
     check(_lib.load().md_linear_fused(ctypes.byref(a), _stream()), "md_linear_fused")
 
 
-def fused_linear(x, weight: "PackedWeight", bias=None, swiglu=False, resid=None, out=None):
+class DeferredNorm:
+    """An RMSNorm that has NOT been applied yet: `h` [M, K] are the un-normalised hidden states and `ssq` [M, K/32]
+    the per-row partial sums of squares the residual epilogue of the producing linear wrote; the consuming fused
+    linear normalises on the fly (md_linear_fused, deferred RMSNorm).  `materialize()` is the stand-alone kernel."""
+
+    def __init__(self, h, ssq, weight, eps):
+        self.h, self.ssq, self.weight, self.eps = h, ssq, weight, float(eps)
+
+    def materialize(self):
+        return rmsnorm(self.h, self.weight, self.eps)
+
+
+def _set_pro(a, x, pro: "DeferredNorm"):
+    if pro.h.data_ptr() != x.data_ptr() or pro.ssq.dtype != torch.float32 or not pro.ssq.is_contiguous():
+        raise ValueError("deferred norm: x must be the un-normalised h the partial sums belong to")
+    if pro.ssq.shape[0] != x.shape[0] or pro.weight.numel() != x.shape[1] or pro.weight.dtype != torch.bfloat16:
+        raise ValueError("deferred norm: ssq [M, tiles] float32 and a bf16 norm weight [K] expected")
+    a.pro_ssq, a.pro_tiles = pro.ssq.data_ptr(), pro.ssq.shape[1]
+    a.pro_norm_w, a.pro_eps = pro.weight.data_ptr(), pro.eps
+
+
+def fused_linear(x, weight: "PackedWeight", bias=None, swiglu=False, resid=None, out=None, want_ssq=False,
+                 pro: "DeferredNorm" = None):
     """One launch (md_linear_fused): F.linear(x, W, bias) for M <= 256 rows over a PackedWeight, optionally followed by
-    SiLU(h1) * h3 (swiglu=True, weight = [w1; w3]) or by the bf16 residual add `resid + linear` (resid [M, N])."""
+    SiLU(h1) * h3 (swiglu=True, weight = [w1; w3]) or by the bf16 residual add `resid + linear` (resid [M, N]).
+    want_ssq (with resid): also return the per-row partial sums of squares [M, N/32] of the result (the producer half of
+    a deferred RMSNorm).  pro (with swiglu): x is pro.h and is normalised on the fly (the consumer half)."""
     epi = FL_SWIGLU if swiglu else (FL_RESID if resid is not None else FL_NONE)
     a = _fused_args(x, weight, bias, epi)
     n_out = weight.N // 2 if swiglu else weight.N
     if out is None:
         out = torch.empty((x.shape[0], n_out), dtype=x.dtype, device=x.device)
     a.out, a.ldo = out.data_ptr(), out.stride(0)
+    ssq = None
     if resid is not None:
         _gpu(resid)
         if resid.shape != out.shape or resid.stride(1) != 1 or resid.dtype != torch.bfloat16:
             raise ValueError("fused linear: resid must be bf16 [M, N] with unit inner stride")
         a.resid, a.ldr = resid.data_ptr(), resid.stride(0)
+        if want_ssq:
+            ssq = torch.empty((x.shape[0], weight.N // 32), dtype=torch.float32, device=x.device)
+            a.ssq_out = ssq.data_ptr()
+    elif want_ssq:
+        raise ValueError("fused linear: want_ssq belongs to the residual epilogue")
+    if pro is not None:
+        if not swiglu:
+            raise ValueError("fused linear: the deferred-norm prologue exists for the w1|w3 and qkv linears")
+        _set_pro(a, x, pro)
     _run_fused(a)
-    return out
+    return (out, ssq) if want_ssq else out
 
 
 def fused_qkv_rope_append(x, weight: "PackedWeight", bias, H, KH, D, rows_per_req, offsets, table: RopeTable, kv_cache,
                           page_indices, page_indptr, last_page_len, kv_cache2=None, page_indices2=None,
-                          page_indptr2=None, last_page_len2=None, kv_scales=None, kv_layout="NHD"):
+                          page_indptr2=None, last_page_len2=None, kv_scales=None, kv_layout="NHD",
+                          pro: "DeferredNorm" = None):
     """wqkv + RoPE + paged KV append in one launch (md_linear_fused, MD_FL_ROPE_APPEND): x [M, K] are the normalised
     hidden states of a decode / verify step in which request b owns rows [b * rows_per_req, (b+1) * rows_per_req).
     Returns the rotated q [M, H, D]; rotated k and v go to the paged cache (and to kv_cache2, bf16 NHD, when given).
@@ -429,6 +464,8 @@ def fused_qkv_rope_append(x, weight: "PackedWeight", bias, H, KH, D, rows_per_re
     a.page_size = _kv_geom(kv_cache, kv_layout)[0]
     kvd, ks, vs = _kv_args(kv_cache, kv_scales, kv_layout)
     a.kv_dtype, a.k_scale, a.v_scale = kvd, ks, vs
+    if pro is not None:                      # x is the un-normalised h: normalise on the fly (deferred RMSNorm)
+        _set_pro(a, x, pro)
     _run_fused(a)
     return q_out
 

@@ -192,3 +192,66 @@ def test_fused_qkv_append_beyond_mapped_pages_is_dropped_and_counted(ops):
     n_fused = ops.page_overflow_count(reset=True)
     assert n_unfused == n_fused == 2
     assert torch.equal(bits(cb), bits(ca))
+
+
+def _close_bf16(got, want, what, min_equal=0.99):
+    """Deferred-norm results vs the stand-alone norm: the only arithmetic difference is the ORDER of the fp32 sum of
+    squares, i.e. rstd in its last bit -- a normalised element then lands on the other side of a bf16 rounding boundary
+    with probability ~1e-5, and such a 1-ulp input change reaches an output element rarely: almost all outputs are
+    bit-equal and none is further than 2 bf16 ulps away."""
+    g, w = got.float().cpu(), want.float().cpu()
+    eq = float((bits(got.cpu()) == bits(want.cpu())).double().mean())
+    ulp = bf16_ulp(w.double()).float()
+    worst = float(((g - w).abs() / ulp).max())
+    parity_report(f"[fused-gemm] deferred norm, {what}: bit-equal to norm-then-linear {100 * eq:.3f}%, worst {worst:.2f} ulp")
+    assert eq >= min_equal and worst <= 2.0, (what, eq, worst)
+
+
+@pytest.mark.parametrize("M,dim,I", [(64, 2048, 1024), (64, 512, 256), (100, 1024, 512), (8, 256, 128)])
+def test_deferred_rmsnorm_resid_then_swiglu(ops, M, dim, I):
+    """wo + residual (writing the partial sums of squares) -> w1|w3 with the norm applied on the fly, against
+    wo + residual -> md_rmsnorm -> w1|w3."""
+    g = torch.Generator().manual_seed(M + dim + I)
+    att = torch.randn(M, dim, generator=g).to(BF)
+    wo = (torch.randn(dim, dim, generator=g) * 0.03).to(BF)
+    x = torch.randn(M, dim, generator=g).to(BF)
+    nw = (1 + 0.1 * torch.randn(dim, generator=g)).to(BF)
+    w13 = (torch.randn(2 * I, dim, generator=g) * 0.05).to(BF)
+    pwo, pw13 = ops.PackedWeight(d(wo)), ops.PackedWeight(d(w13), swiglu=True)
+    h, ssq = ops.fused_linear(d(att), pwo, resid=d(x), want_ssq=True)
+    h_plain = ops.fused_linear(d(att), pwo, resid=d(x))
+    assert torch.equal(bits(h), bits(h_plain))                          # asking for ssq does not change h
+    want_ssq = h.float().cpu().square().view(M, dim // 32, 32).sum(-1)
+    assert ssq.shape == (M, dim // 32)
+    assert torch.allclose(ssq.cpu(), want_ssq, rtol=2e-6, atol=0)
+    y = ops.rmsnorm(h, d(nw), 1e-5)
+    want = ops.fused_linear(y, pw13, swiglu=True)
+    got = ops.fused_linear(h, pw13, swiglu=True, pro=ops.DeferredNorm(h, ssq, d(nw), 1e-5))
+    _close_bf16(got, want, f"w1|w3 M={M} dim={dim} I={I}")
+
+
+@pytest.mark.parametrize("B,n,H,KH,D,dim", [(64, 1, 32, 8, 64, 2048), (3, 4, 8, 2, 128, 1024), (16, 2, 4, 4, 64, 256)])
+def test_deferred_rmsnorm_resid_then_qkv_rope_append(ops, B, n, H, KH, D, dim):
+    """w2 + residual (partial sums) -> next layer's wqkv + RoPE + append with the norm on the fly, against the
+    stand-alone norm in between: rotated q and the appended cache rows."""
+    g = torch.Generator().manual_seed(B * 7 + n + dim)
+    M, N = B * n, (H + 2 * KH) * D
+    act = torch.randn(M, 512, generator=g).to(BF)
+    w2 = (torch.randn(dim, 512, generator=g) * 0.05).to(BF)
+    x = torch.randn(M, dim, generator=g).to(BF)
+    nw = (1 + 0.1 * torch.randn(dim, generator=g)).to(BF)
+    wqkv = (torch.randn(N, dim, generator=g) * 0.05).to(BF)
+    lens = [130 + 17 * (b % 5) for b in range(B)]
+    cache, indices, indptr, last, _ = make_paged(B, lens, KH, D, seed=21)
+    offsets = torch.tensor([l - n for l in lens], dtype=torch.int32)
+    tab = ops.RopeTable(2048, D, 500000.0, 8.0, 1, 4, 8192, device=DEV)
+    pw2, pq = ops.PackedWeight(d(w2)), ops.PackedWeight(d(wqkv))
+    h, ssq = ops.fused_linear(d(act), pw2, resid=d(x), want_ssq=True)
+    y = ops.rmsnorm(h, d(nw), 1e-5)
+    ca, cb = d(cache.clone()), d(cache.clone())
+    want_q = ops.fused_qkv_rope_append(y, pq, None, H, KH, D, n, d(offsets), tab, ca, d(indices), d(indptr), d(last))
+    got_q = ops.fused_qkv_rope_append(h, pq, None, H, KH, D, n, d(offsets), tab, cb, d(indices), d(indptr), d(last),
+                                      pro=ops.DeferredNorm(h, ssq, d(nw), 1e-5))
+    _close_bf16(got_q, want_q, f"q_rot B={B} n={n} D={D}")
+    _close_bf16(cb, ca, f"cache B={B} n={n} D={D}")
+    assert not torch.equal(bits(cb), bits(d(cache)))
