@@ -249,6 +249,18 @@ int md_linear(const void* x, int64_t ldx, const void* w, int w_dtype, int w_pack
               const void* bias, void* out, int64_t ldo, int M, int N, int K, int epilogue, void* workspace,
               size_t workspace_bytes, md_stream_t stream);
 
+/* md_linear_add_rmsnorm: the output projection of a sub-layer on the weight-streaming kernel TOGETHER with what follows
+ * it (Engine/SnapKV/model.py:260-278: h = x + wo(...), out = h + w2(...); :464-469 RMSNorm): the split-K combine launch
+ * of md_linear also adds the residual and normalises --
+ *   o = bf16(x.W^T + bias) [int8: bf16(bf16(x.W^T) * scale)];  h_out[M][N] = bf16(resid + o);  y_out = rmsnorm(h) * w
+ * bit-identical to md_linear followed by md_add_rmsnorm, one launch and one pass over h fewer.  Needs a shape whose K
+ * md_linear splits (md_linear_add_rmsnorm_supported), N % 8 == 0, N <= 8192; workspace as md_linear. */
+int md_linear_add_rmsnorm_supported(int M, int N, int K);
+int md_linear_add_rmsnorm(const void* x, int64_t ldx, const void* w, int w_dtype, int w_packed, const void* scales,
+                          const void* bias, const void* resid, int64_t ldr, const void* norm_weight, float eps,
+                          void* h_out, void* y_out, int M, int N, int K, void* workspace, size_t workspace_bytes,
+                          md_stream_t stream);
+
 /* ------------------------------------------------------------------------
  * K8b  fused small-problem linear: a linear of a decode / verify step TOGETHER with the op that consumes its output,
  *      one launch (csrc/tilegemm.hip; no split-K across workgroups, no workspace, deterministic)

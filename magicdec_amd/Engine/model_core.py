@@ -410,6 +410,16 @@ class Transformer(nn.Module):
             # cannot (library GEMM, lm head) materialises it with the stand-alone kernel
             h, ssq = self._linear(inp, lin, resid=x, want_ssq=True)
             return h, ops.DeferredNorm(h, ssq, norm.weight, norm.eps)
+        if group is None and inp.is_cuda and x.stride(-1) == 1:
+            # the weight-streaming kernel's split-K combine launch also adds the residual and normalises
+            from .gemm_policy import choose
+            w = lin.weight
+            M, K = inp.shape
+            pk = self._packed.get(id(w))
+            if (choose(M, w.shape[0], K, False, w.dtype == torch.int8, pk is not None, "resid") == "skinny"
+                    and ops.linear_add_rmsnorm_supported(M, w.shape[0], K)):
+                return ops.linear_add_rmsnorm(inp, pk if pk is not None else w, x, norm.weight, norm.eps, lin.bias,
+                                              getattr(lin, "scales", None), self.workspace)
         return self._reduce_add_norm(self._linear(inp, lin), x, norm, group)
 
     def _reduce_add_norm(self, partial, x, norm, group):

@@ -65,6 +65,8 @@ _SIGNATURES = {
     "md_linear_workspace_bytes": (c_size_t, [I, I, I, I]),
     "md_debug_set_gemm_target_blocks": (None, [I]),
     "md_linear": (c_int, [P, L, P, I, I, P, P, P, L, I, I, I, I, P, c_size_t, P]),
+    "md_linear_add_rmsnorm_supported": (c_int, [I, I, I]),
+    "md_linear_add_rmsnorm": (c_int, [P, L, P, I, I, P, P, P, L, P, c_float, P, P, I, I, I, P, c_size_t, P]),
     "md_linear_fused_supported": (c_int, [I, I, I, I]),
     "md_debug_set_fused_nw": (None, [I]),
     "md_linear_fused": (c_int, [ctypes.POINTER(FusedLinearArgs), P]),

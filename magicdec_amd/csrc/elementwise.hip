@@ -70,6 +70,66 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const bf16_t* __restrict__
     }
 }
 
+// Split-K combine of md_linear + residual add + RMSNorm in one launch (md_linear_add_rmsnorm): one workgroup per row,
+// the thread -> column mapping, the order of every sum and every rounding point are those of skinny_reduce_kernel
+// (csrc/gemm.hip) followed by rmsnorm_kernel<true> above, so (h, y) are bit-identical to md_linear -> md_add_rmsnorm.
+//   o = bf16(sum_s partial[s] + bias)   [int8 weights: bf16(bf16(sum) * scale)];  h = bf16(x + o);  y = rmsnorm(h) * w
+template <bool W8>
+__global__ __launch_bounds__(256) void reduce_add_rmsnorm_kernel(const float* __restrict__ partial, int S, int M, int N,
+                                                                 const bf16_t* __restrict__ bias,
+                                                                 const bf16_t* __restrict__ scales,
+                                                                 const bf16_t* __restrict__ x, int64_t ldx,
+                                                                 const bf16_t* __restrict__ w, bf16_t* h_out,
+                                                                 bf16_t* y, float eps) {
+    __shared__ float red[8];
+    const int64_t row = blockIdx.x;
+    const int nvec = N / 8;
+    const int64_t plane = (int64_t)M * N;
+    constexpr int MAXV = 4;
+    f32x8 vals[MAXV];
+    float ss = 0.f;
+#pragma unroll
+    for (int it = 0; it < MAXV; ++it) {
+        const int i = threadIdx.x + it * 256;
+        if (i < nvec) {
+            f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+            for (int s = 0; s < S; ++s) {
+                const float* pp = partial + s * plane + row * N + i * 8;
+                a0 += *reinterpret_cast<const f32x4*>(pp);
+                a1 += *reinterpret_cast<const f32x4*>(pp + 4);
+            }
+            f32x8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float v = e < 4 ? a0[e] : a1[e - 4];
+                if (bias) v += bf16_to_f32(bias[i * 8 + e]);
+                if (W8) v = bf16_to_f32(f32_to_bf16(v)) * bf16_to_f32(scales[i * 8 + e]);
+                o[e] = bf16_to_f32(f32_to_bf16(v));
+            }
+            const f32x8 xf = __builtin_convertvector(reinterpret_cast<const bf16x8*>(x + row * ldx)[i], f32x8);
+            const bf16x8 hb = __builtin_convertvector(xf + o, bf16x8);      // bf16 add
+            reinterpret_cast<bf16x8*>(h_out + row * N)[i] = hb;
+            const f32x8 f = __builtin_convertvector(hb, f32x8);
+            vals[it] = f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) ss += f[e] * f[e];
+        }
+    }
+    const float tot = block_reduce_sum(ss, red);
+    const float rs = rsqrtf(tot / (float)N + eps);
+    const bf16x8* wv = reinterpret_cast<const bf16x8*>(w);
+#pragma unroll
+    for (int it = 0; it < MAXV; ++it) {
+        const int i = threadIdx.x + it * 256;
+        if (i < nvec) {
+            const bf16x8 nb = __builtin_convertvector(vals[it] * rs, bf16x8);
+            const f32x8 nf = __builtin_convertvector(nb, f32x8);
+            const f32x8 wf = __builtin_convertvector(wv[i], f32x8);
+            reinterpret_cast<bf16x8*>(y + row * N)[i] = __builtin_convertvector(nf * wf, bf16x8);
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void silu_mul_kernel(const bf16_t* __restrict__ a, const bf16_t* __restrict__ b,
                                                        int64_t as, int64_t bs, bf16_t* y, int rows, int dim) {
     const int nvec = dim / 8;
@@ -176,6 +236,22 @@ __global__ void tp_merge_kernel(const bf16_t* __restrict__ vals, const int64_t* 
 }
 
 }  // namespace
+
+// launched by md_linear_add_rmsnorm (csrc/gemm.hip) behind its split-K main kernel
+int md_internal_launch_reduce_add_rmsnorm(const float* partial, int S, int M, int N, const void* bias, const void* scales,
+                                          const void* x, int64_t ldx, const void* w, void* h_out, void* y, float eps,
+                                          hipStream_t st) {
+    if (scales)
+        hipLaunchKernelGGL((reduce_add_rmsnorm_kernel<true>), dim3(M), dim3(256), 0, st, partial, S, M, N,
+                           (const bf16_t*)bias, (const bf16_t*)scales, (const bf16_t*)x, ldx, (const bf16_t*)w,
+                           (bf16_t*)h_out, (bf16_t*)y, eps);
+    else
+        hipLaunchKernelGGL((reduce_add_rmsnorm_kernel<false>), dim3(M), dim3(256), 0, st, partial, S, M, N,
+                           (const bf16_t*)bias, (const bf16_t*)scales, (const bf16_t*)x, ldx, (const bf16_t*)w,
+                           (bf16_t*)h_out, (bf16_t*)y, eps);
+    return MD_OK;
+}
+
 
 extern "C" int md_rmsnorm(const void* x, const void* weight, void* y, int rows, int dim, float eps,
                           md_stream_t stream) {

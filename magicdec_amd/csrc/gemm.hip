@@ -48,6 +48,7 @@ struct GemmParams {
     int64_t ldx, ldo;
     int M, N, K, kblk, S, Nout;
     int packed;           // W is in the fragment-major streaming layout (md_pack_weight layout, see md_linear)
+    int skip_reduce;      // md_linear_add_rmsnorm: the caller launches its own combine kernel
 };
 
 __device__ __forceinline__ bf16x8 ld_frag(const bf16_t* p) { return *reinterpret_cast<const bf16x8*>(p); }
@@ -286,6 +287,16 @@ int pick_splits(int n_blocks, int K) {
     return best;
 }
 
+}  // namespace
+
+// elementwise.hip: split-K combine + residual add + RMSNorm (compiled there, without FMA contraction, next to the
+// kernels it must reproduce bit for bit)
+int md_internal_launch_reduce_add_rmsnorm(const float* partial, int S, int M, int N, const void* bias, const void* scales,
+                                          const void* x, int64_t ldx, const void* w, void* h_out, void* y, float eps,
+                                          hipStream_t st);
+
+namespace {
+
 template <int MT, int EPI, bool W8>
 int launch(const GemmParams& p, int n_blocks, hipStream_t st) {
     constexpr int RD = 8;
@@ -302,7 +313,7 @@ int launch(const GemmParams& p, int n_blocks, hipStream_t st) {
         }
     }
     hipLaunchKernelGGL(k, dim3(n_blocks, p.S), dim3(256), lds, st, p);
-    if (p.S > 1) {
+    if (p.S > 1 && !p.skip_reduce) {
         const int64_t threads = (int64_t)p.M * (p.Nout / 4);
         hipLaunchKernelGGL((skinny_reduce_kernel<EPI, W8>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, p);
     }
@@ -360,6 +371,7 @@ extern "C" int md_linear(const void* x, int64_t ldx, const void* w, int w_dtype,
     p.K = K;
     p.Nout = epilogue == EPI_SWIGLU ? N / 2 : N;
     p.packed = w_packed ? 1 : 0;
+    p.skip_reduce = 0;
     const int cols_per_block = epilogue == EPI_SWIGLU ? 64 : 128;      // output columns per workgroup
     const int n_blocks = (p.Nout + cols_per_block - 1) / cols_per_block;
     p.S = pick_splits(n_blocks, K);
@@ -378,5 +390,55 @@ extern "C" int md_linear(const void* x, int64_t ldx, const void* w, int w_dtype,
         rc = w8 ? launch_mt<EPI_NONE, true>(p, n_blocks, st) : launch_mt<EPI_NONE, false>(p, n_blocks, st);
     if (rc != MD_OK) return rc;
     MD_CHECK_LAUNCH("md_linear");
+    return MD_OK;
+}
+
+extern "C" int md_linear_add_rmsnorm_supported(int M, int N, int K) {
+    if (!md_linear_supported(M, N, K, EPI_NONE) || N % 8 || N > 8192) return 0;
+    return pick_splits((N + 127) / 128, K) > 1 ? 1 : 0;      // needs the split-K combine launch to fuse into
+}
+
+extern "C" int md_linear_add_rmsnorm(const void* x, int64_t ldx, const void* w, int w_dtype, int w_packed,
+                                     const void* scales, const void* bias, const void* resid, int64_t ldr,
+                                     const void* norm_weight, float eps, void* h_out, void* y_out, int M, int N, int K,
+                                     void* workspace, size_t workspace_bytes, md_stream_t stream) {
+    MD_CHECK_ARG(x && w && resid && norm_weight && h_out && y_out, "md_linear_add_rmsnorm: null pointer argument");
+    MD_CHECK_ARG(md_linear_add_rmsnorm_supported(M, N, K),
+                 "md_linear_add_rmsnorm: unsupported shape M=%d N=%d K=%d (md_linear shape with a split K, N %% 8 == 0, "
+                 "N <= 8192)", M, N, K);
+    MD_CHECK_ARG(w_dtype == MD_W_BF16 || (w_dtype == MD_W_INT8 && scales), "md_linear_add_rmsnorm: w_dtype must be "
+                 "MD_W_BF16 or MD_W_INT8 (with per-channel scales)");
+    MD_CHECK_ARG((((uintptr_t)x | (uintptr_t)w | (uintptr_t)resid | (uintptr_t)norm_weight | (uintptr_t)h_out |
+                   (uintptr_t)y_out) & 15) == 0 && ldx % 8 == 0 && ldr % 8 == 0,
+                 "md_linear_add_rmsnorm: pointers must be 16-byte aligned, ldx %% 8 == 0, ldr %% 8 == 0");
+    GemmParams p;
+    p.x = (const bf16_t*)x;
+    p.w = w;
+    p.bias = nullptr;
+    p.scales = nullptr;
+    p.out = nullptr;
+    p.ldx = ldx;
+    p.ldo = N;
+    p.M = M;
+    p.N = N;
+    p.K = K;
+    p.Nout = N;
+    p.packed = w_packed ? 1 : 0;
+    p.skip_reduce = 1;
+    const int n_blocks = (N + 127) / 128;
+    p.S = pick_splits(n_blocks, K);
+    p.kblk = K / p.S;
+    p.partial = (float*)workspace;
+    MD_CHECK_ARG(workspace && workspace_bytes >= (size_t)p.S * M * N * 4 && (((uintptr_t)workspace) & 15) == 0,
+                 "md_linear_add_rmsnorm: workspace too small (need %zu bytes) or not 16-byte aligned",
+                 (size_t)p.S * M * N * 4);
+    hipStream_t st = (hipStream_t)stream;
+    const bool w8 = w_dtype == MD_W_INT8;
+    int rc = w8 ? launch_mt<EPI_NONE, true>(p, n_blocks, st) : launch_mt<EPI_NONE, false>(p, n_blocks, st);
+    if (rc != MD_OK) return rc;
+    rc = md_internal_launch_reduce_add_rmsnorm(p.partial, p.S, M, N, bias, w8 ? scales : nullptr, resid, ldr,
+                                               norm_weight, h_out, y_out, eps, st);
+    if (rc != MD_OK) return rc;
+    MD_CHECK_LAUNCH("md_linear_add_rmsnorm");
     return MD_OK;
 }

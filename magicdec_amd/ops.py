@@ -351,6 +351,42 @@ def linear(x, weight, bias=None, scales=None, swiglu=False, workspace: "AttnWork
     return out
 
 
+def linear_add_rmsnorm_supported(M, N, K):
+    """True when md_linear_add_rmsnorm takes this shape (an md_linear shape whose K is split, N <= 8192)."""
+    return bool(_lib.load().md_linear_add_rmsnorm_supported(int(M), int(N), int(K)))
+
+
+def linear_add_rmsnorm(x, weight, resid, norm_weight, eps, bias=None, scales=None, workspace: "AttnWorkspace" = None):
+    """(h, y) = (resid + F.linear(x, W, bias), rmsnorm(h) * norm_weight) on md_linear with the residual add and the norm
+    fused into its split-K combine launch -- bit-identical to linear() followed by add_rmsnorm()."""
+    packed = isinstance(weight, PackedWeight)
+    wt = weight.data if packed else weight
+    _gpu(x, wt, bias, scales, resid, norm_weight)
+    if x.dim() != 2 or x.stride(1) != 1 or resid.dim() != 2 or resid.stride(1) != 1:
+        raise ValueError("linear_add_rmsnorm expects 2-D x / resid with unit inner stride")
+    M, K = x.shape
+    N = weight.N if packed else weight.shape[0]
+    if packed and weight.swiglu:
+        raise ValueError("linear_add_rmsnorm: the weight was packed for the SwiGLU epilogue")
+    if resid.shape != (M, N) or norm_weight.numel() != N:
+        raise ValueError("linear_add_rmsnorm: resid must be [M, N], norm_weight [N]")
+    wd = MD_W_INT8 if wt.dtype == torch.int8 else MD_W_BF16
+    if wd == MD_W_INT8 and scales is None:
+        raise ValueError("int8 weights need per-row scales")
+    lib = _lib.load()
+    nbytes = lib.md_linear_workspace_bytes(M, N, K, EPI_NONE)
+    if workspace is None or not nbytes:
+        raise ValueError("linear_add_rmsnorm: needs a workspace and a shape whose K is split")
+    ws = workspace.get(nbytes + 256)
+    off = (-ws.data_ptr()) % 256
+    h = torch.empty((M, N), dtype=x.dtype, device=x.device)
+    y = torch.empty((M, N), dtype=x.dtype, device=x.device)
+    check(lib.md_linear_add_rmsnorm(_p(x), x.stride(0), _p(wt), wd, 1 if packed else 0, _p(scales), _p(bias), _p(resid),
+                                    resid.stride(0), _p(norm_weight), float(eps), _p(h), _p(y), M, N, K,
+                                    ctypes.c_void_p(ws.data_ptr() + off), nbytes, _stream()), "md_linear_add_rmsnorm")
+    return h, y
+
+
 # ----------------------------------------------------------------------------- K8b
 FL_NONE, FL_SWIGLU, FL_RESID, FL_ROPE_APPEND = 0, 1, 2, 3
 

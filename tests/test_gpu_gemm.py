@@ -188,3 +188,32 @@ def test_linear_rejects_bad_arguments(ops):
         ops.linear(x, w)
     with pytest.raises(ValueError):
         ops.linear(torch.zeros(4, 128, dtype=BF, device=DEV), torch.zeros(64, 128, dtype=torch.int8, device=DEV))
+
+
+@pytest.mark.parametrize("M,N,K,int8", [(64, 2048, 8192, False), (256, 4096, 14336, False), (32, 1024, 2048, False),
+                                        (100, 512, 1024, False), (64, 1024, 2048, True)])
+@pytest.mark.parametrize("packed", [False, True], ids=["rowmajor", "packed"])
+def test_linear_add_rmsnorm_equals_linear_then_add_rmsnorm(ops, M, N, K, int8, packed):
+    """md_linear_add_rmsnorm (the split-K combine launch also adds the residual and normalises) must reproduce
+    md_linear -> md_add_rmsnorm bit for bit: h and y."""
+    g = torch.Generator().manual_seed(M + N + K)
+    x = torch.randn(M, K, generator=g).to(BF)
+    r = torch.randn(M, N, generator=g).to(BF)
+    nw = (1 + 0.1 * torch.randn(N, generator=g)).to(BF)
+    ws = ops.AttnWorkspace(DEV)
+    if int8:
+        w = torch.randint(-127, 128, (N, K), generator=g, dtype=torch.int8)
+        sc = (torch.rand(N, generator=g) * 0.01 + 0.001).to(BF)
+        wd, scales = w.to(DEV), sc.to(DEV)
+        if packed:
+            wd = ops.PackedWeight(wd)
+    else:
+        w = (torch.randn(N, K, generator=g) * 0.05).to(BF)
+        wd, scales = (ops.PackedWeight(w.to(DEV)) if packed else w.to(DEV)), None
+    if not ops.linear_add_rmsnorm_supported(M, N, K):
+        pytest.skip("K is not split for this shape: nothing to fuse into")
+    o = ops.linear(x.to(DEV), wd, scales=scales, workspace=ws)
+    h_want, y_want = ops.add_rmsnorm(r.to(DEV), o, nw.to(DEV), 1e-5)
+    h, y = ops.linear_add_rmsnorm(x.to(DEV), wd, r.to(DEV), nw.to(DEV), 1e-5, scales=scales, workspace=ws)
+    assert torch.equal(h.view(torch.int16), h_want.view(torch.int16))
+    assert torch.equal(y.view(torch.int16), y_want.view(torch.int16))

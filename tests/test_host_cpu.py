@@ -96,7 +96,8 @@ def test_every_entry_point_rejects_null_arguments():
     assert lib.md_linear_supported(0, 0, 0, 0) == 0 and lib.md_linear_supported(64, 128, 256, 0) == 1
     assert lib.md_linear_fused_supported(0, 0, 0, 0) == 0 and lib.md_linear_fused_supported(64, 768, 2048, 3) == 1
     assert lib.md_linear_fused_supported(64, 770, 2048, 0) == 0 and lib.md_linear_fused_supported(300, 768, 2048, 0) == 0
-    skip |= {"md_linear_supported", "md_linear_fused_supported"}
+    assert lib.md_linear_add_rmsnorm_supported(0, 0, 0) == 0 and lib.md_linear_add_rmsnorm_supported(256, 4096, 14336) == 1
+    skip |= {"md_linear_supported", "md_linear_fused_supported", "md_linear_add_rmsnorm_supported"}
     # md_linear_fused takes a struct: NULL struct, then a zeroed struct (null tensors), then tensors but a bad shape
     assert lib.md_linear_fused(None, None) < 0 and "md_linear_fused" in lib.md_last_error_string().decode()
     fa = _lib.FusedLinearArgs()
