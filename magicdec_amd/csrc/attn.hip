@@ -575,6 +575,7 @@ __global__ __launch_bounds__(256) void attn_merge_kernel(const AttnParams p, int
 // the MFMA work per key is unchanged (the round-2 kernel spent ~190 VALU per 32 MFMAs: VALU-bound).
 template <int D, int QT, bool FP8, int NW, int KT>
 __global__ __launch_bounds__(64 * NW, 2) void prefill_attn_kernel(const AttnParams p) {
+    constexpr bool TMASK = D == 128;       // causal mask as a compile-time property of the tile body (see `compute`)
     constexpr int KG = KT / 32;            // 32-key groups per tile (V sub-tile images, PV MFMA k-groups)
     constexpr int KBN = KT / 16;           // 16-key MFMA blocks per tile
     constexpr int EB = FP8 ? 1 : 2;
@@ -731,8 +732,15 @@ __global__ __launch_bounds__(64 * NW, 2) void prefill_attn_kernel(const AttnPara
     };
     // MASK is a compile-time property of the call: only the last few tiles of a causal chunk reach past the smallest
     // limit of the wave's rows; every tile before them runs a body without a single compare / select
+    // At D = 128 the two bodies cost nothing (one workgroup per CU either way); at D = 64 the duplicated body pushes the
+    // kernel from 117 to 167 VGPRs = from two workgroups per CU to one (measured: 1.62 -> 2.38 ms at 16K keys), so
+    // there the mask stays a run-time, wave-uniform branch (TMASK = false).
     auto compute = [&](int t, const unsigned char* img, auto mask_c) {
-        constexpr bool need_mask = decltype(mask_c)::value;
+        bool need_mask;
+        if constexpr (std::is_same_v<decltype(mask_c), bool>)
+            need_mask = mask_c;
+        else
+            need_mask = decltype(mask_c)::value;
         f32x4 s[QT][KBN];
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt)
@@ -755,7 +763,7 @@ __global__ __launch_bounds__(64 * NW, 2) void prefill_attn_kernel(const AttnPara
             for (int kb = 0; kb < KBN; ++kb)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) v[kb * 4 + j] = s[qt][kb][j];
-            if constexpr (need_mask) {
+            if (need_mask) {
 #pragma unroll
                 for (int kb = 0; kb < KBN; ++kb)
 #pragma unroll
@@ -817,10 +825,15 @@ __global__ __launch_bounds__(64 * NW, 2) void prefill_attn_kernel(const AttnPara
         if (t + 1 < ntiles_wg) issue(t + 1);
         __syncthreads();
         if (t < my_ntiles) {
-            if ((t * KT + KT - 1) > lo)
-                compute(t, img, std::true_type{});
-            else
-                compute(t, img, std::false_type{});
+            const bool masked = (t * KT + KT - 1) > lo;
+            if constexpr (TMASK) {
+                if (masked)
+                    compute(t, img, std::true_type{});
+                else
+                    compute(t, img, std::false_type{});
+            } else {
+                compute(t, img, masked);
+            }
         }
     }
 
@@ -959,10 +972,11 @@ int launch_prefill_kt(const AttnParams& p, int grid, hipStream_t st) {
 template <int D, int QT, bool FP8>
 int launch_prefill(const AttnParams& p, int grid, int nw, hipStream_t st) {
     if constexpr (!FP8 && D == 64) {
-        // 64-key shared tiles where the registers allow it: D = 64, bf16 pages -- 580 vs 450 TFLOP/s at the 1B draft
-        // model's prefill shape (profiles/r03_prefill_ab.txt).  At D = 128 the 64-key body needs 256 VGPRs + 43 spilled
-        // (o 64 + q 32 + s 32 + p 16 ...) and LOSES (587 vs 663 TFLOP/s); the fp8 staging path (two conversions per
-        // load) was not generalised.  md_debug_set_prefill_kt(64, .) still forces it at D = 128 for experiments.
+        // 64-key shared tiles where the registers allow it: D = 64, bf16 pages, run-time mask (124 VGPRs: two workgroups
+        // per CU) -- 714 vs 663 TFLOP/s at the 1B draft model's prefill shape, +6..15 % at shorter contexts
+        // (profiles/r03_prefill_ab.txt).  At D = 128 the 64-key body needs 256 VGPRs + 43 spilled (o 64 + q 32 + s 32 +
+        // p 16 ...) and LOSES (587 vs 663 TFLOP/s); the fp8 staging path (two conversions per load) was not
+        // generalised.  md_debug_set_prefill_kt(128, .) still forces 64-key tiles at D = 128 for experiments.
         if (g_prefill_kt == 64)
             return nw == 8 ? launch_prefill_kt<D, QT, FP8, 8, 64>(p, grid, st)
                            : launch_prefill_kt<D, QT, FP8, 4, 64>(p, grid, st);
