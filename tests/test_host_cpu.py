@@ -1185,3 +1185,33 @@ def test_command_line_flags_and_defaults_equal_the_reference_scripts():
                 assert a.default is None, (script, flag, a.default)
         allowed = extras | ({"--dataset", "--benchmark"} if "baseline" in script else set())
         assert set(acts) - {r["flags"][0] for r in ref_args} <= allowed, (script, set(acts) - {r["flags"][0] for r in ref_args})
+
+
+def test_gemm_policy_encodes_the_measured_ab_table():
+    """Engine/gemm_policy.choose is a pure function of the shape: pin the decisions that profiles/r03_fused_ab.txt and
+    profiles/r02_gemm_ab.txt measured (which kernel serves which linear of the BASELINE models), so that a threshold
+    edit cannot silently move a production shape to a slower kernel."""
+    from magicdec_amd.Engine import gemm_policy as g
+    if g.mode() != "auto" or g.fused_mode() != "auto":
+        pytest.skip("MAGICDEC_GEMM / MAGICDEC_FUSED override the policy in this environment")
+    c = lambda M, N, K, kind, norm=False: g.choose(M, N, K, kind == "swiglu", False, True, kind, norm)
+    # 1B draft model at TP1 (M = 64; two-token step M = 128)
+    assert c(64, 3072, 2048, "qkv") == "fused" and c(64, 2048, 2048, "resid") == "fused"
+    assert c(64, 16384, 2048, "swiglu") == "skinny" and c(64, 16384, 2048, "swiglu", True) == "fused"
+    assert c(64, 2048, 8192, "resid") == "lib" and c(128, 3072, 2048, "qkv") == "fused"
+    assert c(64, 128256, 2048, "plain") == "skinny"
+    # its TP4 shards and the 8B model's TP8 shards at M = 64: everything fused
+    for N, K, kind in [(768, 2048, "qkv"), (2048, 512, "plain"), (4096, 2048, "swiglu"), (2048, 2048, "plain"),
+                       (768, 4096, "qkv"), (4096, 512, "plain"), (3584, 4096, "swiglu"), (4096, 1792, "plain")]:
+        assert c(64, N, K, kind) == "fused", (N, K, kind)
+    # verify pass (M = 256): only the sharded qkv projection goes to the fused kernel; the 8B model's w2 streams
+    assert c(256, 768, 4096, "qkv") == "fused" and c(256, 1536, 4096, "qkv") == "fused"
+    assert c(256, 6144, 4096, "qkv") == "lib" and c(256, 4096, 512, "plain") == "lib"
+    assert c(256, 28672, 4096, "swiglu") == "lib" and c(256, 4096, 14336, "resid") == "skinny"
+    # autoregressive 8B steps (M = 64)
+    assert c(64, 6144, 4096, "qkv") == "lib" and c(64, 4096, 4096, "resid") == "fused"
+    assert c(64, 28672, 4096, "swiglu") == "skinny" and c(64, 4096, 14336, "resid") == "skinny"
+    # never without a packed copy, never for int8 rows, never for shapes the kernel does not take
+    assert g.choose(64, 3072, 2048, False, False, False, "qkv") == "lib"
+    assert g.choose(64, 3072, 2048, False, True, True, "qkv") == "skinny"
+    assert c(64, 3080, 2048, "plain") == "lib" and c(300, 768, 2048, "qkv") == "lib"
