@@ -10,10 +10,14 @@ token ids [B, n].  What differs from the reference is everything underneath:
 * no flashinfer, no torch.library ops, no torch.compile: the attention, RoPE,
   KV append, SnapKV select, StreamingLLM eviction, norms, SiLU*mul and argmax
   are hand-written gfx950 kernels reached through the C ABI (magicdec_amd.ops);
-* per layer and step: 4 GEMMs (hipBLASLt via F.linear; w1|w3 fused into one) and
-  5 kernel launches (add+rmsnorm, rope+append, attention, add+rmsnorm, silu*mul);
-  RoPE and the paged append are one launch, the residual add is fused into the
-  following norm;
+* per layer and step: 4 linears (w1|w3 fused into one) -- each on the kernel the
+  measured policy of Engine/gemm_policy.py picks: md_linear_fused (launch-bound small
+  products: the product AND its consumer -- rope+append, residual add, SiLU*mul, the
+  RMSNorm in front -- in one launch: a 1B draft layer is 5-7 launches), md_linear (long
+  weight streams; its split-K combine also adds the residual and normalises) or
+  hipBLASLt via F.linear (prefill-sized M, the M = 256 verify GEMMs) -- plus the
+  attention and whatever the chosen linears did not absorb (rope+append, add+rmsnorm,
+  silu*mul kernels);
 * the page table is read on the device by the attention kernel -- there is no
   host-side plan() and no host<->device sync anywhere in a step, so a step can be
   captured into a hipGraph (Engine/graph.py);

@@ -18,9 +18,10 @@
 //   * a workgroup (8 wavefronts) owns one 32-row x 32-column output tile and the WHOLE K range: no split-K across
 //     workgroups, no partial sums in HBM, no combine launch; grid = (M/32) x (N/32) tiles, block id -> tile mapping
 //     keeps the M-tiles of one weight tile on one XCD (they share its L2 lines);
-//   * the K range is split over the 8 wavefronts (K/8 each); every wavefront is an independent pipeline with NO
-//     barrier in its loop: W fragments stream global -> registers (one contiguous KiB per instruction, 8-deep rolling
-//     ring, non-temporal), its private slice of the activations goes global -> registers -> wave-private LDS image ->
+//   * the K range is split over the workgroup's 8 wavefronts (16 when the grid is too small to give every CU two
+//     workgroups); every wavefront is an independent pipeline with NO barrier in its loop: W fragments stream global ->
+//     registers (one contiguous KiB per instruction, 8-deep rolling ring; non-temporal when there is one M tile, kept in
+//     L2 for the sibling M tiles otherwise), its private slice of the activations goes global -> registers -> wave-private LDS image ->
 //     MFMA A fragments (full 256-B row segments per 16 lanes from L2 instead of fragment-shaped 32-B pieces -- the
 //     latter is what made round 2's "short-stream" attempt 1.4-3x slower) with the next 128-deep chunk's loads in flight
 //     under the current chunk's MFMAs;
@@ -42,6 +43,11 @@
 // md_rmsnorm does, and applies y = bf16(bf16(h * rstd) * w) -- the reference's rounding points
 // (Engine/SnapKV/model.py:464-469) -- to its activation slice on the way from registers to the LDS image.  Only the
 // order of the fp32 sum of squares differs from the stand-alone kernel's.
+//
+// Where it wins and where it does not (profiles/r03_fused_ab.txt, Engine/gemm_policy.py): per-workgroup time is
+// ~2.5 us + 128 B x K / (45-50 GB/s per CU): the 32-row activation slab (M x K, one hot MB) is re-read by every column
+// tile through the same L2 channels.  K <= 4096 with few M tiles: 6-13 us against 10-16 for the library + the small
+// kernel behind it; K = 8192 or M = 256 with many column tiles: slower than the library -- those shapes stay there.
 #include "md_common.h"
 
 unsigned int* md_page_overflow_counter_device();   // kvops.hip: rows dropped beyond a request's mapped pages
