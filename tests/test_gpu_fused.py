@@ -37,7 +37,7 @@ def d(t):
 # ragged M (last M tile partly empty), one- and many-tile grids
 SHAPES = [(1, 32, 128), (7, 96, 256), (32, 2048, 1024), (33, 160, 384), (64, 768, 2048), (64, 3072, 2048),
           (64, 2048, 512), (100, 1024, 512), (128, 768, 4096), (256, 768, 4096), (256, 4096, 512), (200, 4096, 1792),
-          (64, 2048, 8192)]
+          (64, 2048, 8192), (64, 4096, 1792), (96, 3584, 3584)]    # 16-wave path with a 7-step tail; 224-deep slices
 
 
 @pytest.mark.parametrize("M,N,K", SHAPES, ids=[f"M{m}-N{n}-K{k}" for m, n, k in SHAPES])
