@@ -409,6 +409,10 @@ extern "C" int md_linear_fused(const md_fused_linear_args* a, md_stream_t stream
     MD_CHECK_ARG(aligned16(a->x) && aligned16(a->w_packed) && aligned16(a->out) && a->ldx % 8 == 0 && a->ldo % 2 == 0,
                  "md_linear_fused: x / w / out must be 16-byte aligned, ldx %% 8 == 0, ldo %% 2 == 0");
     MD_CHECK_ARG(!(a->epilogue == FL_SWIGLU && a->bias), "md_linear_fused: the SwiGLU epilogue takes no bias");
+    // the kernel addresses x with 32-bit byte offsets from a scalar base
+    MD_CHECK_ARG(a->ldx > 0 && ((int64_t)(a->M - 1) * a->ldx + a->K) * 2 < ((int64_t)1 << 32),
+                 "md_linear_fused: x spans more than 4 GiB (M=%d, ldx=%lld): pass a compact activation tensor", a->M,
+                 (long long)a->ldx);
     TileParams p = {};
     p.x = (const bf16_t*)a->x;
     p.w = (const bf16_t*)a->w_packed;

@@ -33,6 +33,8 @@ python3 bench.py --emulate-tp 8 --steps 20 --warmup 5 --no-cpu-baseline --no-pmc
 MAGICDEC_ONESHOT_AR=1 python3 bench.py --emulate-tp 8 --steps 20 --warmup 5 --no-cpu-baseline --no-pmc > $OUT/${TAG}_emulated_tp8_fused_ar.log 2>&1
 python3 bench.py --workload cfg2 --steps 20 --warmup 5 --no-cpu-baseline --no-pmc > $OUT/${TAG}_bench_cfg2.log 2>&1
 for f in emulated_tp8 emulated_tp8_fused_ar bench_cfg2; do grep '^{"metric"' $OUT/${TAG}_$f.log > $OUT/${TAG}_$f.json; done
+python3 -c "import __graft_entry__ as g; g.smoke()" > $OUT/${TAG}_smoke.log 2>&1
+echo "smoke rc=$?"; tail -2 $OUT/${TAG}_smoke.log
 timeout 900 python -m pytest tests -m gpu -q -p no:cacheprovider > $OUT/${TAG}_gpu_tests.log 2>&1
 echo "suite rc=$?"; tail -1 $OUT/${TAG}_gpu_tests.log
 cp $OUT/parity_report.txt $OUT/${TAG}_parity_report.txt 2>/dev/null
