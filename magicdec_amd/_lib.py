@@ -44,6 +44,7 @@ _SIGNATURES = {
     "md_paged_attn_workspace_bytes": (c_size_t, [I, I, I, I, I, I, I]),
     "md_debug_set_attn_target_wgs": (None, [I]),
     "md_debug_set_prefill_kt": (None, [I, I]),
+    "md_debug_set_prefill_mfma32": (None, [I]),
     "md_debug_attn_timing": (None, [I, I]),
     "md_debug_attn_timing_read": (c_int, [P, I]),
     "md_paged_attn": (c_int, [P, L, P, P, P, P, P, P, I, I, I, I, I, I, I, c_float, I, I, P, P, P, c_size_t, P]),
@@ -108,6 +109,9 @@ def load():
     except (OSError, AttributeError) as e:  # missing symbol / loader failure
         _err = f"cannot load {LIB_PATH}: {e}"
         raise MagicDecHipError(_err) from e
+    v = os.environ.get("MAGICDEC_PREFILL_MFMA32")          # development A/B switch of the prefill attention kernel
+    if v is not None:
+        lib.md_debug_set_prefill_mfma32(int(v))
     _lib = lib
     return _lib
 

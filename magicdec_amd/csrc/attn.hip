@@ -40,6 +40,8 @@
 
 namespace {
 
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
 struct AttnParams {
     const bf16_t* q;
     const void* cache;     // bf16 or OCP e4m3fn bytes (MD_KV_FP8_E4M3)
@@ -859,6 +861,227 @@ __global__ __launch_bounds__(64 * NW, 2) void prefill_attn_kernel(const AttnPara
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// K3, round 3: the same shared-tile prefill structure on v_mfma_f32_32x32x16_bf16 (bf16 pages).  A wave owns ONE 32-row
+// query tile instead of two 16-row tiles; per 32 keys it issues 16 MFMAs of 32 cycles instead of 32 of 16 -- the same
+// matrix time -- but every K and V fragment read from LDS now feeds twice the flops (8 + 8 KiB of fragment reads per 32
+// keys instead of 16 + 16), the softmax statistics of a query live in TWO lanes (lane, lane ^ 32) instead of four, and
+// the per-tile bookkeeping (max reduction, rescale test) is paid once per wave, not once per M tile.
+//   S^T = K Q^T   A = K fragment (lane (j, kh): key row j, d = 16 ks + 8 kh ..), B = Q fragment (q row j, same d): the
+//                 accumulator register r of lane (j, kh) is S[key (r&3) + 8 (r>>2) + 4 kh][query j];
+//   O^T = V^T P^T A = V^T fragment via ds_read_b64_tr_b16 from the same [d/16][32 keys][16] sub-tile images (a 16-lane
+//                 group reads a [4 keys][16 d] block: keys 16 s + 4 kh + {0..3} and + 8), B = P^T: registers
+//                 8 s .. 8 s + 7 of the S accumulator ARE the k-slots of 16-key step s -- no cross-lane movement.
+// Staging, double buffering, the one barrier per tile and the causal bookkeeping are those of prefill_attn_kernel.
+template <int D, int NW, int KT>
+__global__ __launch_bounds__(64 * NW, 2) void prefill32_attn_kernel(const AttnParams p) {
+    constexpr int KG = KT / 32;            // 32-key blocks per tile
+    constexpr int CH = D * 2 / 16;
+    constexpr int RPI = 64 / CH;
+    constexpr int NL = KT / RPI;
+    constexpr int NLW = (NL + NW - 1) / NW;
+    constexpr int KS = D / 16;             // 16-deep k-steps of QK^T
+    constexpr int NB = D / 16;             // 16-d V sub-tiles
+    constexpr int DB = D / 32;             // 32-d output blocks
+    constexpr int KROW = D * 2 + 16;
+    constexpr int K_BYTES = KT * KROW;
+    constexpr int VG = NB * kVSub;
+    constexpr int STAGE = prefill_stage_bytes<D, KT>();
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // 2 x STAGE, then int[NW]
+    int* s_end = reinterpret_cast<int*>(smem + 2 * STAGE);
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    const int j = lane & 31, kh = lane >> 5;
+
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7;
+    const int r0 = bid >> 3;
+    const int qg = r0 % p.n_qgroups;
+    const int pair = (r0 / p.n_qgroups) * 8 + xcd;
+    if (pair >= p.B * p.KH) return;
+    const int b = pair / p.KH, kvh = pair % p.KH;
+    const int g = p.g;
+    const int q0 = p.qo_indptr[b];
+    const int n_b = p.qo_indptr[b + 1] - q0;
+    const int pg0 = p.page_indptr[b];
+    const int npages = p.page_indptr[b + 1] - pg0;
+    const int kv_len = npages > 0 ? min((npages - 1) * p.page_size + p.last_page_len[b], npages * p.page_size) : 0;
+    const int nrows = n_b * g;
+    const int R = (qg * NW + wave) * 32 + j;           // this lane's query row (both kh halves hold the same query)
+    const bool valid = R < nrows;
+    const int qi = R / g, qr = R - qi * g;
+    const int lim = valid ? (p.causal ? kv_len - n_b + qi : kv_len - 1) : -1;
+    int hi = lim, lo = valid ? lim : 0x7fffffff;
+#pragma unroll
+    for (int o = 1; o < 32; o <<= 1) {
+        hi = max(hi, __shfl_xor(hi, o));
+        lo = min(lo, __shfl_xor(lo, o));
+    }
+    hi = __builtin_amdgcn_readfirstlane(hi);
+    lo = __builtin_amdgcn_readfirstlane(lo);
+    const int kv_end = min(hi + 1, kv_len);
+    if (lane == 0) s_end[wave] = kv_end;
+    __syncthreads();
+    int kv_end_wg = 0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) kv_end_wg = max(kv_end_wg, s_end[w]);
+    const int ntiles_wg = kv_end_wg > 0 ? (kv_end_wg + KT - 1) / KT : 0;
+    const int my_ntiles = kv_end > 0 ? (kv_end + KT - 1) / KT : 0;
+
+    bf16x8 qf[KS];
+    {
+        const bf16_t* qp = p.q + (int64_t)(q0 + qi) * p.q_row_stride + (kvh * g + qr) * D;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+            qf[ks] = valid ? *reinterpret_cast<const bf16x8*>(qp + ks * 16 + kh * 8) : z;
+        }
+    }
+    const float sl2 = p.scale_log2;
+    f32x16 o[DB];
+#pragma unroll
+    for (int db = 0; db < DB; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[db][r] = 0.f;
+    float m = -1e30f, l = 0.f;
+
+    // staging (identical to prefill_attn_kernel, bf16)
+    const int wrow = lane / CH, wch = lane % CH;
+    int kw[NLW], vw[NLW];
+#pragma unroll
+    for (int s = 0; s < NLW; ++s) {
+        const int row = wrow + (wave + NW * s) * RPI;
+        kw[s] = row * KROW + (wch << 4);
+        vw[s] = K_BYTES + (row >> 5) * VG + (row & 31) * 32 + (wch >> 1) * kVSub + (wch & 1) * 16;
+    }
+    const unsigned goff = (unsigned)((wrow * p.slot_stride + kvh * p.head_stride) * 2 + wch * 16);
+    u32x4 kreg[NLW], vreg[NLW];
+    auto issue = [&](int tt) {
+        const int pos0 = tt * KT;
+        const int page = pos0 / p.page_size;
+        const int slot0 = pos0 - page * p.page_size;
+        const int pid = __builtin_amdgcn_readfirstlane(p.page_indices[pg0 + page]);
+        const unsigned char* kb_ = reinterpret_cast<const unsigned char*>(p.cache) +
+                                   ((int64_t)pid * p.page_stride + (int64_t)slot0 * p.slot_stride) * 2;
+        const unsigned char* vb_ = kb_ + p.kv_half * 2;
+        const int64_t jstep = (int64_t)RPI * p.slot_stride * 2;
+#pragma unroll
+        for (int s = 0; s < NLW; ++s)
+            if (wave + NW * s < NL) {
+                kreg[s] = *reinterpret_cast<const u32x4*>(kb_ + (wave + NW * s) * jstep + goff);
+                vreg[s] = *reinterpret_cast<const u32x4*>(vb_ + (wave + NW * s) * jstep + goff);
+            }
+    };
+    auto stage = [&](int t, unsigned char* img) {
+#pragma unroll
+        for (int s = 0; s < NLW; ++s)
+            if (wave + NW * s < NL) {
+                if (t * KT + wrow + (wave + NW * s) * RPI >= kv_len) vreg[s] = u32x4{0u, 0u, 0u, 0u};
+                *reinterpret_cast<u32x4*>(img + kw[s]) = kreg[s];
+                *reinterpret_cast<u32x4*>(img + vw[s]) = vreg[s];
+            }
+    };
+    // fragment addresses: K (lane (j, kh)): row j, 16-B piece 2 ks + kh; V tr-read (16-lane group = (kh, j >> 4)):
+    // sub-tile ((lane >> 4) & 1) of the 32-d block, key row 4 kh + (lq >> 2) (+ 16 s, + 8), d group lq & 3
+    const int kra0 = j * KROW + (kh << 4);
+    const int lq = lane & 15;
+    const int vra0 = K_BYTES + ((lane >> 4) & 1) * kVSub + (kh * 4 + (lq >> 2)) * 32 + (lq & 3) * 8;
+
+    auto compute = [&](int t, const unsigned char* img, bool need_mask) {
+        f32x16 sc[KG];
+#pragma unroll
+        for (int kg = 0; kg < KG; ++kg) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sc[kg][r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const bf16x8 kf = lds_read_b128(img + kra0 + kg * 32 * KROW + ks * 32);
+                sc[kg] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], sc[kg], 0, 0, 0);
+            }
+        }
+        if (need_mask) {
+#pragma unroll
+            for (int kg = 0; kg < KG; ++kg)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int pos = t * KT + kg * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                    if (pos > lim) sc[kg][r] = -INFINITY;
+                }
+        }
+        float mx = sc[0][0];
+#pragma unroll
+        for (int kg = 0; kg < KG; ++kg)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sc[kg][r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        mx *= sl2;
+        if (__builtin_amdgcn_ballot_w64(mx > m) != 0) {       // lazy rescale, wave-uniform
+            const float mnew = fmaxf(m, mx);
+            const float alpha = __builtin_amdgcn_exp2f(m - mnew);
+            m = mnew;
+            l *= alpha;
+#pragma unroll
+            for (int db = 0; db < DB; ++db)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
+        }
+        const float mneg = -m;
+        float ps = 0.f;
+        bf16x8 pf[KG][2];
+#pragma unroll
+        for (int kg = 0; kg < KG; ++kg)
+#pragma unroll
+            for (int s16 = 0; s16 < 2; ++s16) {
+                f32x8 pv;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float pe = __builtin_amdgcn_exp2f(fmaf(sc[kg][s16 * 8 + e], sl2, mneg));
+                    pv[e] = pe;
+                    ps += pe;
+                }
+                pf[kg][s16] = __builtin_convertvector(pv, bf16x8);
+            }
+        l += ps;
+#pragma unroll
+        for (int db = 0; db < DB; ++db)
+#pragma unroll
+            for (int kg = 0; kg < KG; ++kg)
+#pragma unroll
+                for (int s16 = 0; s16 < 2; ++s16) {
+                    const unsigned char* vb = img + kg * VG + (2 * db) * kVSub + vra0 + s16 * 16 * 32;
+                    const bf16x4 v0 = lds_read_tr(vb);
+                    const bf16x4 v1 = lds_read_tr(vb + 8 * 32);
+                    const bf16x8 vf = __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7);
+                    o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[kg][s16], o[db], 0, 0, 0);
+                }
+    };
+
+    if (ntiles_wg > 0) issue(0);
+    for (int t = 0; t < ntiles_wg; ++t) {
+        unsigned char* img = smem + (t & 1) * STAGE;
+        stage(t, img);
+        if (t + 1 < ntiles_wg) issue(t + 1);
+        __syncthreads();
+        if (t < my_ntiles) compute(t, img, (t * KT + KT - 1) > lo);
+    }
+
+    l += __shfl_xor(l, 32);
+    if (valid) {
+        const float inv = l > 0.f ? 1.0f / l : 0.f;
+        bf16_t* op = p.out + ((int64_t)(q0 + qi) * p.H + kvh * g + qr) * D;
+#pragma unroll
+        for (int db = 0; db < DB; ++db)
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                const f32x4 ov = {o[db][rg * 4] * inv, o[db][rg * 4 + 1] * inv, o[db][rg * 4 + 2] * inv,
+                                  o[db][rg * 4 + 3] * inv};
+                *reinterpret_cast<bf16x4*>(op + db * 32 + rg * 8 + kh * 4) = __builtin_convertvector(ov, bf16x4);
+            }
+    }
+}
+
 struct AttnPlan {
     bool splitq;
     int nw;   // prefill: waves per workgroup sharing each K/V tile (4 or 8)
@@ -969,8 +1192,40 @@ int launch_prefill_kt(const AttnParams& p, int grid, hipStream_t st) {
     return MD_OK;
 }
 
+// keys per tile (32 | 64) of the 32x32x16-MFMA kernel that serves the two-M-tile bf16 prefill shapes, 0 = the 16x16x32
+// kernel above (dev knob md_debug_set_prefill_mfma32 / MAGICDEC_PREFILL_MFMA32).  Measured (profiles/r03_prefill_mfma32_ab.txt,
+// B = 64, 128 tokens x 32 heads): D = 128, 16K keys: 668 (16x16, 32 keys) -> 778 (32 keys) -> 833 TFLOP/s (64 keys: 194
+// VGPRs, no spills); 4K keys: 546 -> 667; D = 64: 712 -> 729, 588 -> 619.
+int g_prefill_mfma32 = 64;
+
+template <int D, int NW, int KT>
+int launch_prefill32_kt(const AttnParams& p, int grid, hipStream_t st) {
+    constexpr int lds = 2 * prefill_stage_bytes<D, KT>() + 32;
+    auto k = prefill32_attn_kernel<D, NW, KT>;
+    if (lds > 64 * 1024) {
+        static MdPerDeviceOnce once;
+        if (once.first()) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds) !=
+                hipSuccess) {
+                once.undo();
+                md_set_error("md_paged_attn(prefill32): hipFuncSetAttribute(%d B LDS) failed", lds);
+                return MD_ERR_LAUNCH;
+            }
+        }
+    }
+    hipLaunchKernelGGL(k, dim3(grid), dim3(64 * NW), lds, st, p);
+    MD_CHECK_LAUNCH("md_paged_attn(prefill32)");
+    return MD_OK;
+}
+
 template <int D, int QT, bool FP8>
 int launch_prefill(const AttnParams& p, int grid, int nw, hipStream_t st) {
+    if constexpr (!FP8 && QT == 2) {
+        if (g_prefill_mfma32 == 64)
+            return nw == 8 ? launch_prefill32_kt<D, 8, 64>(p, grid, st) : launch_prefill32_kt<D, 4, 64>(p, grid, st);
+        if (g_prefill_mfma32 == 32)
+            return nw == 8 ? launch_prefill32_kt<D, 8, 32>(p, grid, st) : launch_prefill32_kt<D, 4, 32>(p, grid, st);
+    }
     if constexpr (!FP8 && D == 64) {
         // 64-key shared tiles where the registers allow it: D = 64, bf16 pages, run-time mask (124 VGPRs: two workgroups
         // per CU) -- 714 vs 663 TFLOP/s at the 1B draft model's prefill shape, +6..15 % at shorter contexts
@@ -992,6 +1247,8 @@ int launch_prefill(const AttnParams& p, int grid, int nw, hipStream_t st) {
 }  // namespace
 
 extern "C" void md_debug_set_attn_target_wgs(int n) { g_target_wgs = n > 0 ? n : 256; }
+extern "C" void md_debug_set_prefill_mfma32(int kt) { g_prefill_mfma32 = (kt == 32 || kt == 64) ? kt : 0; }   // 0: off
+
 extern "C" void md_debug_set_prefill_kt(int kt, int nw) {
     g_prefill_kt = kt == 32 ? 32 : 64;
     g_prefill_kt_force128 = kt == 128;          // kt = 128: 64-key tiles at D = 128 too

@@ -92,7 +92,7 @@ def test_every_entry_point_rejects_null_arguments():
     from magicdec_amd import _lib
     lib = _lib.load()
     skip = {"md_abi_version", "md_last_error_string", "md_debug_set_attn_target_wgs", "md_ar_destroy",
-            "md_debug_set_gemm_target_blocks", "md_debug_attn_timing", "md_debug_attn_timing_read", "md_debug_set_prefill_kt", "md_debug_set_fused_nw"}
+            "md_debug_set_gemm_target_blocks", "md_debug_attn_timing", "md_debug_attn_timing_read", "md_debug_set_prefill_kt", "md_debug_set_fused_nw", "md_debug_set_prefill_mfma32"}
     assert lib.md_linear_supported(0, 0, 0, 0) == 0 and lib.md_linear_supported(64, 128, 256, 0) == 1
     assert lib.md_linear_fused_supported(0, 0, 0, 0) == 0 and lib.md_linear_fused_supported(64, 768, 2048, 3) == 1
     assert lib.md_linear_fused_supported(64, 770, 2048, 0) == 0 and lib.md_linear_fused_supported(300, 768, 2048, 0) == 0

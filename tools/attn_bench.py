@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from magicdec_amd import ops
 
 ap = argparse.ArgumentParser()
-for k, v in dict(B=64, S=16036, KH=8, H=32, D=128, n=4, iters=20, layers=2, wgs=0, fp8=0, hnd=0, kt=0, nw=0).items():
+for k, v in dict(B=64, S=16036, KH=8, H=32, D=128, n=4, iters=20, layers=2, wgs=0, fp8=0, hnd=0, kt=0, nw=0, mfma32=0).items():
     ap.add_argument(f"--{k}", type=int, default=v)
 a = ap.parse_args()
 if a.wgs:
@@ -17,6 +17,10 @@ if a.kt or a.nw:                               # prefill kernel: keys per shared
     import ctypes
     from magicdec_amd import _lib
     _lib.load().md_debug_set_prefill_kt(ctypes.c_int(a.kt or 64), ctypes.c_int(a.nw))
+if a.mfma32:                                   # 32x32x16-MFMA prefill kernel, keys per tile
+    import ctypes
+    from magicdec_amd import _lib
+    _lib.load().md_debug_set_prefill_mfma32(ctypes.c_int(a.mfma32))
 dev = "cuda"
 mp = (a.S + 127) // 128
 g = torch.Generator(device=dev).manual_seed(0)
@@ -50,7 +54,7 @@ ms = e0.elapsed_time(e1) / a.iters
 nbytes = a.B * a.S * a.KH * a.D * 2 * (1 if a.fp8 else 2) + 2 * a.B * a.n * a.H * a.D * 2
 flops = 4.0 * a.B * a.n * a.H * a.D * (a.S - a.n / 2.0)          # causal: row i of the chunk sees S - n + i + 1 keys
 if a.n >= 32:
-    print(f"  prefill view (kt={a.kt or 64} nw={a.nw or 'auto'}): {flops / ms / 1e9:.1f} TFLOP/s = {flops / ms / 1e9 / 25:.2f}% of 2.5 PFLOP/s "
+    print(f"  prefill view (kt={a.kt or 64} nw={a.nw or 'auto'} mfma32={a.mfma32}): {flops / ms / 1e9:.1f} TFLOP/s = {flops / ms / 1e9 / 25:.2f}% of 2.5 PFLOP/s "
           f"dense bf16")
 print(f"md_paged_attn B={a.B} S={a.S} KH={a.KH} H={a.H} D={a.D} n={a.n}: {ms:.4f} ms  {nbytes / ms / 1e6:.1f} GB/s  "
       f"{nbytes / ms / 1e6 / 80:.2f}% of 8 TB/s  (alg bytes {nbytes}) wgs={a.wgs} fp8={a.fp8} layout={layout} map={os.environ.get('MD_ATTN_MAP', '0')}")
