@@ -873,6 +873,9 @@ __global__ __launch_bounds__(64 * NW, 2) void prefill_attn_kernel(const AttnPara
 //                 group reads a [4 keys][16 d] block: keys 16 s + 4 kh + {0..3} and + 8), B = P^T: registers
 //                 8 s .. 8 s + 7 of the S accumulator ARE the k-slots of 16-key step s -- no cross-lane movement.
 // Staging, double buffering, the one barrier per tile and the causal bookkeeping are those of prefill_attn_kernel.
+// Measured and NOT kept (same box, profiles/r03_prefill_mfma32_ab.txt): s_setprio(1) around the MFMA clusters (808 vs 820
+// TFLOP/s), the causal mask as a compile-time property of the tile body (two bodies: 480 -- the register file again), the
+// MFMAs of one accumulator issued back to back instead of alternating accumulators (795 vs 817).
 template <int D, int NW, int KT>
 __global__ __launch_bounds__(64 * NW, 2) void prefill32_attn_kernel(const AttnParams p) {
     constexpr int KG = KT / 32;            // 32-key blocks per tile
@@ -992,22 +995,29 @@ __global__ __launch_bounds__(64 * NW, 2) void prefill32_attn_kernel(const AttnPa
     auto compute = [&](int t, const unsigned char* img, bool need_mask) {
         f32x16 sc[KG];
 #pragma unroll
-        for (int kg = 0; kg < KG; ++kg) {
+        for (int kg = 0; kg < KG; ++kg)
 #pragma unroll
             for (int r = 0; r < 16; ++r) sc[kg][r] = 0.f;
+        // ks outer, key block inner: consecutive MFMAs accumulate into different registers
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int kg = 0; kg < KG; ++kg) {
                 const bf16x8 kf = lds_read_b128(img + kra0 + kg * 32 * KROW + ks * 32);
                 sc[kg] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], sc[kg], 0, 0, 0);
             }
-        }
         if (need_mask) {
+            // a real (wave-uniform) branch: only the last tiles of a causal chunk take it; the empty volatile asm keeps
+            // the compiler from if-converting it into 32 compare/select pairs executed on every tile
 #pragma unroll
             for (int kg = 0; kg < KG; ++kg)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int pos = t * KT + kg * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-                    if (pos > lim) sc[kg][r] = -INFINITY;
+                    float v = sc[kg][r];
+                    if (pos > lim) v = -INFINITY;
+                    asm volatile("" : "+v"(v));          // volatile: cannot be hoisted out of the branch
+                    sc[kg][r] = v;
                 }
         }
         float mx = sc[0][0];
@@ -1044,18 +1054,20 @@ __global__ __launch_bounds__(64 * NW, 2) void prefill32_attn_kernel(const AttnPa
                 pf[kg][s16] = __builtin_convertvector(pv, bf16x8);
             }
         l += ps;
+        auto pv = [&](int db, int kg, int s16) {
+            const unsigned char* vb = img + kg * VG + (2 * db) * kVSub + vra0 + s16 * 16 * 32;
+            const bf16x4 v0 = lds_read_tr(vb);
+            const bf16x4 v1 = lds_read_tr(vb + 8 * 32);
+            const bf16x8 vf = __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7);
+            o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[kg][s16], o[db], 0, 0, 0);
+        };
+        // 16-key step outer, d block inner: consecutive MFMAs accumulate into different O blocks
 #pragma unroll
-        for (int db = 0; db < DB; ++db)
+        for (int kg = 0; kg < KG; ++kg)
 #pragma unroll
-            for (int kg = 0; kg < KG; ++kg)
+            for (int s16 = 0; s16 < 2; ++s16)
 #pragma unroll
-                for (int s16 = 0; s16 < 2; ++s16) {
-                    const unsigned char* vb = img + kg * VG + (2 * db) * kVSub + vra0 + s16 * 16 * 32;
-                    const bf16x4 v0 = lds_read_tr(vb);
-                    const bf16x4 v1 = lds_read_tr(vb + 8 * 32);
-                    const bf16x8 vf = __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7);
-                    o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[kg][s16], o[db], 0, 0, 0);
-                }
+                for (int db = 0; db < DB; ++db) pv(db, kg, s16);
     };
 
     if (ntiles_wg > 0) issue(0);
@@ -1247,7 +1259,9 @@ int launch_prefill(const AttnParams& p, int grid, int nw, hipStream_t st) {
 }  // namespace
 
 extern "C" void md_debug_set_attn_target_wgs(int n) { g_target_wgs = n > 0 ? n : 256; }
-extern "C" void md_debug_set_prefill_mfma32(int kt) { g_prefill_mfma32 = (kt == 32 || kt == 64) ? kt : 0; }   // 0: off
+extern "C" void md_debug_set_prefill_mfma32(int kt) {
+    g_prefill_mfma32 = (kt == 32 || kt == 64) ? kt : 0;   // 0: off
+}
 
 extern "C" void md_debug_set_prefill_kt(int kt, int nw) {
     g_prefill_kt = kt == 32 ? 32 : 64;
