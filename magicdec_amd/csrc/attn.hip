@@ -1204,11 +1204,12 @@ int launch_prefill_kt(const AttnParams& p, int grid, hipStream_t st) {
     return MD_OK;
 }
 
-// keys per tile (32 | 64) of the 32x32x16-MFMA kernel that serves the two-M-tile bf16 prefill shapes, 0 = the 16x16x32
-// kernel above (dev knob md_debug_set_prefill_mfma32 / MAGICDEC_PREFILL_MFMA32).  Measured (profiles/r03_prefill_mfma32_ab.txt,
-// B = 64, 128 tokens x 32 heads): D = 128, 16K keys: 668 (16x16, 32 keys) -> 778 (32 keys) -> 833 TFLOP/s (64 keys: 194
-// VGPRs, no spills); 4K keys: 546 -> 667; D = 64: 712 -> 729, 588 -> 619.
-int g_prefill_mfma32 = 64;
+// The 32x32x16-MFMA kernel serves the two-M-tile bf16 prefill shapes.  Keys per shared tile: 128 at D = 128 (242 VGPRs, no
+// spills, 137 KB LDS), 64 at D = 64 (118 VGPRs: two workgroups per CU; 128 keys would cost the second one) -- measured,
+// same box (profiles/r03_prefill_mfma32_ab.txt; B = 64, 128 tokens x 32 heads vs 16 K keys, TFLOP/s): D = 128: 668 (16x16
+// kernel, 32 keys) -> 778 (32) -> 805 (64) -> 874 (128); D = 64: 712 -> 729 (64), 667 (128).
+// Dev knob (md_debug_set_prefill_mfma32 / MAGICDEC_PREFILL_MFMA32): -1 = this rule, 0 = the 16x16x32 kernel, 32 | 64 | 128 forced.
+int g_prefill_mfma32 = -1;
 
 template <int D, int NW, int KT>
 int launch_prefill32_kt(const AttnParams& p, int grid, hipStream_t st) {
@@ -1233,9 +1234,12 @@ int launch_prefill32_kt(const AttnParams& p, int grid, hipStream_t st) {
 template <int D, int QT, bool FP8>
 int launch_prefill(const AttnParams& p, int grid, int nw, hipStream_t st) {
     if constexpr (!FP8 && QT == 2) {
-        if (g_prefill_mfma32 == 64)
+        const int kt32 = g_prefill_mfma32 < 0 ? (D == 128 ? 128 : 64) : g_prefill_mfma32;
+        if (kt32 == 128)
+            return nw == 8 ? launch_prefill32_kt<D, 8, 128>(p, grid, st) : launch_prefill32_kt<D, 4, 128>(p, grid, st);
+        if (kt32 == 64)
             return nw == 8 ? launch_prefill32_kt<D, 8, 64>(p, grid, st) : launch_prefill32_kt<D, 4, 64>(p, grid, st);
-        if (g_prefill_mfma32 == 32)
+        if (kt32 == 32)
             return nw == 8 ? launch_prefill32_kt<D, 8, 32>(p, grid, st) : launch_prefill32_kt<D, 4, 32>(p, grid, st);
     }
     if constexpr (!FP8 && D == 64) {
@@ -1260,7 +1264,7 @@ int launch_prefill(const AttnParams& p, int grid, int nw, hipStream_t st) {
 
 extern "C" void md_debug_set_attn_target_wgs(int n) { g_target_wgs = n > 0 ? n : 256; }
 extern "C" void md_debug_set_prefill_mfma32(int kt) {
-    g_prefill_mfma32 = (kt == 32 || kt == 64) ? kt : 0;   // 0: off
+    g_prefill_mfma32 = (kt == 32 || kt == 64 || kt == 128 || kt < 0) ? kt : 0;   // < 0: the rule, 0: off
 }
 
 extern "C" void md_debug_set_prefill_kt(int kt, int nw) {
