@@ -128,6 +128,68 @@ def test_paged_attention_ragged_query_counts(ops, name, H, KH, D, ns, lens, fp8)
     check_attention(name, out[:tot], oracle, ref64, bnd)
 
 
+PREFILL_VARIANT_SHAPES = [
+    # name, H, KH, D, rows per request, context lengths, page size
+    ("d128-ring-laps", 8, 2, 128, [128, 128], [2100, 1500], 128),          # 33 tiles of 64 keys: 8 laps of the ring
+    ("d128-g1-uneven-waves", 4, 4, 128, [300, 270], [700, 300], 128),      # waves of a workgroup end 4 tiles apart; idle waves
+    ("d128-short", 8, 2, 128, [128, 64], [128, 70], 128),                  # 2 tiles / 1 tile + prologue-only paths
+    ("d64-ring-laps", 32, 8, 64, [128, 100], [1300, 900], 128),
+    ("d128-page64", 8, 2, 128, [128, 128], [1000, 640], 64),
+]
+PREFILL_VARIANTS = [0, 32, 64, 128, 1064, 2064, 1128, 2128]   # md_debug_set_prefill_mfma32: 16x16 | 32x32 keys | ping-pong
+
+
+@pytest.mark.parametrize("knob", PREFILL_VARIANTS)
+@pytest.mark.parametrize("name,H,KH,D,ns,lens,page_size", PREFILL_VARIANT_SHAPES, ids=[c[0] for c in PREFILL_VARIANT_SHAPES])
+def test_prefill_kernel_variants_vs_oracle(ops, name, H, KH, D, ns, lens, page_size, knob):
+    """Every prefill kernel the dispatcher can pick (16x16x32 shared-tile, 32x32x16 at 32 / 64 / 128 keys per tile, and
+    the two-group ping-pong form of the latter, without and with s_setprio) on shapes that walk the tile ring several
+    times, end the waves of one workgroup on different tiles and leave whole waves without rows -- same bound as
+    test_paged_attention_vs_oracle.  A variant the shape does not admit (keys per tile not dividing the page, D) falls
+    back inside the library; the result must still be right."""
+    B = len(ns)
+    cache, indices, indptr, last, max_pages = make_paged(B, lens, KH, D, seed=case_seed(name), page_size=page_size,
+                                                         scatter=True)
+    g = torch.Generator().manual_seed(3)
+    tot = sum(ns)
+    q = torch.randn(tot, H, D, generator=g).to(BF)
+    qo = torch.tensor([0] + list(np.cumsum(ns)), dtype=torch.int32)
+    oracle = fr.batch_prefill_paged(q, cache, qo, indices, indptr, last, H, KH, D, causal=True)
+    ref64, bnd = dense_attention_f64(q, cache, qo, indices, indptr, last, H, KH, D, causal=True)
+    ws = ops.AttnWorkspace(DEV)
+    lib = ops._lib.load()
+    out = torch.full((tot + 2, H, D), 7.0, dtype=BF, device=DEV)
+    lib.md_debug_set_prefill_mfma32(knob)
+    try:
+        ops.paged_attention(q.to(DEV), cache.to(DEV), qo.to(DEV), indices.to(DEV), indptr.to(DEV), last.to(DEV),
+                            max(ns), max_pages, ws, causal=True, out=out[:tot])
+        torch.cuda.synchronize()
+    finally:
+        lib.md_debug_set_prefill_mfma32(-1)
+    assert (out[tot:].float() == 7.0).all(), "wrote past the last query row"
+    check_attention(f"{name}-knob{knob}", out[:tot], oracle, ref64, bnd)
+
+
+@pytest.mark.parametrize("page_size", [32, 64, 96])
+@pytest.mark.parametrize("D,n", [(128, 128), (64, 128), (128, 4)])
+def test_paged_attention_page_sizes(ops, page_size, D, n):
+    """The C ABI admits any page size that is a multiple of 32 (the reference runs 128): a shared K/V tile of the prefill
+    kernels must never cross a page, whatever tile size the dispatcher prefers."""
+    H, KH, B = 8, 2, 2
+    lens = [5 * page_size + 17, 3 * page_size]
+    cache, indices, indptr, last, max_pages = make_paged(B, lens, KH, D, seed=page_size + D + n, page_size=page_size,
+                                                         scatter=True)
+    g = torch.Generator().manual_seed(4)
+    q = torch.randn(B * n, H, D, generator=g).to(BF)
+    qo = torch.arange(B + 1, dtype=torch.int32) * n
+    oracle = fr.batch_prefill_paged(q, cache, qo, indices, indptr, last, H, KH, D, causal=True)
+    ref64, bnd = dense_attention_f64(q, cache, qo, indices, indptr, last, H, KH, D, causal=True)
+    ws = ops.AttnWorkspace(DEV)
+    out = ops.paged_attention(q.to(DEV), cache.to(DEV), qo.to(DEV), indices.to(DEV), indptr.to(DEV), last.to(DEV), n,
+                              max_pages, ws, causal=True)
+    check_attention(f"page{page_size}-d{D}-n{n}", out, oracle, ref64, bnd)
+
+
 def test_paged_attention_ignores_garbage_beyond_length(ops):
     """Rows past a request's length may hold NaN/Inf (stale pages): they must not leak into the output."""
     B, n, H, KH, D = 2, 4, 8, 2, 128
