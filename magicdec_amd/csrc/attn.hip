@@ -876,7 +876,7 @@ __global__ __launch_bounds__(64 * NW, 2) void prefill_attn_kernel(const AttnPara
 // Measured and NOT kept (same box, profiles/r03_prefill_mfma32_ab.txt): s_setprio(1) around the MFMA clusters (808 vs 820
 // TFLOP/s), the causal mask as a compile-time property of the tile body (two bodies: 480 -- the register file again), the
 // MFMAs of one accumulator issued back to back instead of alternating accumulators (795 vs 817).
-template <int D, int NW, int KT>
+template <int D, int NW, int KT, bool VP = true>
 __global__ __launch_bounds__(64 * NW, 2) void prefill32_attn_kernel(const AttnParams p) {
     constexpr int KG = KT / 32;            // 32-key blocks per tile
     constexpr int CH = D * 2 / 16;
@@ -990,7 +990,13 @@ __global__ __launch_bounds__(64 * NW, 2) void prefill32_attn_kernel(const AttnPa
     // sub-tile ((lane >> 4) & 1) of the 32-d block, key row 4 kh + (lq >> 2) (+ 16 s, + 8), d group lq & 3
     const int kra0 = j * KROW + (kh << 4);
     const int lq = lane & 15;
-    const int vra0 = K_BYTES + ((lane >> 4) & 1) * kVSub + (kh * 4 + (lq >> 2)) * 32 + (lq & 3) * 8;
+    // the two 16-d sub-tiles one tr-read pairs (lanes 0-15 | 16-31 of a 32-lane group): sub-tiles db and db + NB/2, whose
+    // images lie 4 x 1056 B = 128 B (mod 256) apart at D = 128 -- disjoint halves of the 64 LDS banks.  Adjacent sub-tiles
+    // (32 B mod 256 apart: VP = false, the first version) overlap on 24 banks: every ds_read_b64_tr_b16 took 4 LDS cycles
+    // instead of 2 (SQ_LDS_BANK_CONFLICT = 2 per MFMA, 28 % of SQ_LDS_IDX_ACTIVE; profiles/r03_prefill_pmc_call22.txt)
+    constexpr int VPS = VP ? NB / 2 : 1;        // sub-tile distance inside a pair
+    constexpr int VDS = VP ? 1 : 2;             // sub-tile distance between output blocks
+    const int vra0 = K_BYTES + ((lane >> 4) & 1) * VPS * kVSub + (kh * 4 + (lq >> 2)) * 32 + (lq & 3) * 8;
 
     auto compute = [&](int t, const unsigned char* img, bool need_mask) {
         f32x16 sc[KG];
@@ -1055,7 +1061,7 @@ __global__ __launch_bounds__(64 * NW, 2) void prefill32_attn_kernel(const AttnPa
             }
         l += ps;
         auto pv = [&](int db, int kg, int s16) {
-            const unsigned char* vb = img + kg * VG + (2 * db) * kVSub + vra0 + s16 * 16 * 32;
+            const unsigned char* vb = img + kg * VG + (VDS * db) * kVSub + vra0 + s16 * 16 * 32;
             const bf16x4 v0 = lds_read_tr(vb);
             const bf16x4 v1 = lds_read_tr(vb + 8 * 32);
             const bf16x8 vf = __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7);
@@ -1089,7 +1095,8 @@ __global__ __launch_bounds__(64 * NW, 2) void prefill32_attn_kernel(const AttnPa
             for (int rg = 0; rg < 4; ++rg) {
                 const f32x4 ov = {o[db][rg * 4] * inv, o[db][rg * 4 + 1] * inv, o[db][rg * 4 + 2] * inv,
                                   o[db][rg * 4 + 3] * inv};
-                *reinterpret_cast<bf16x4*>(op + db * 32 + rg * 8 + kh * 4) = __builtin_convertvector(ov, bf16x4);
+                const int dd = VP ? (db + (rg >> 1) * (NB / 2)) * 16 + (rg & 1) * 8 : db * 32 + rg * 8;
+                *reinterpret_cast<bf16x4*>(op + dd + kh * 4) = __builtin_convertvector(ov, bf16x4);
             }
     }
 }
@@ -1226,23 +1233,35 @@ __global__ __launch_bounds__(512, 2) void prefill32p_attn_kernel(const AttnParam
     auto slot = [&](int t) -> unsigned char* { return smem + (t & (RING - 1)) * STAGE; };
     const int kra0 = j * KROW + (kh << 4);
     const int lq = lane & 15;
-    const int vra0 = K_BYTES + ((lane >> 4) & 1) * kVSub + (kh * 4 + (lq >> 2)) * 32 + (lq & 3) * 8;
+    // a tr-read pairs the 16-d sub-tiles db and db + NB/2 (bank-conflict free at D = 128, see prefill32_attn_kernel)
+    const int vra0 = K_BYTES + ((lane >> 4) & 1) * (NB / 2) * kVSub + (kh * 4 + (lq >> 2)) * 32 + (lq & 3) * 8;
 
     f32x16 sc[KG];         // S(t + 1), written in P_a(t), consumed in P_b(t + 1)
     bf16x8 pf[KG][2];      // P(t) as MFMA B fragments, written in P_b(t), consumed in P_a(t)
 
-    auto qk_step = [&](const unsigned char* imgk, int i) {
+    // fragment reads run LEAD MFMA pairs ahead of their use: while waves 0..3 are in the matrix phase their SIMD partners
+    // issue no LDS reads, so nothing else hides the ~64-128 cycles between a ds_read and the MFMA that consumes it (the
+    // compiler's own order, read -> wait -> MFMA one or two MFMAs later, left the phase latency-bound: call 22)
+    constexpr int LEAD = (VAR & 2) ? 2 : 3;
+    bf16x8 kfr[LEAD + 1], vfr[LEAD + 1];
+    auto load_k = [&](const unsigned char* imgk, int i) {
         const int ks = i / KG, kg = i % KG;
-        const bf16x8 kf = lds_read_b128(imgk + kra0 + kg * 32 * KROW + ks * 32);
-        sc[kg] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], sc[kg], 0, 0, 0);
+        kfr[i % (LEAD + 1)] = lds_read_b128(imgk + kra0 + kg * 32 * KROW + ks * 32);
     };
-    auto pv_step = [&](const unsigned char* imgv, int i) {
+    auto load_v = [&](const unsigned char* imgv, int i) {
         const int kg = i / (2 * DB), s16 = (i / DB) & 1, db = i % DB;
-        const unsigned char* vb = imgv + kg * VG + (2 * db) * kVSub + vra0 + s16 * 16 * 32;
+        const unsigned char* vb = imgv + kg * VG + db * kVSub + vra0 + s16 * 16 * 32;
         const bf16x4 v0 = lds_read_tr(vb);
         const bf16x4 v1 = lds_read_tr(vb + 8 * 32);
-        const bf16x8 vf = __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7);
-        o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[kg][s16], o[db], 0, 0, 0);
+        vfr[i % (LEAD + 1)] = __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7);
+    };
+    auto mfma_k = [&](int i) {
+        const int ks = i / KG, kg = i % KG;
+        sc[kg] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[i % (LEAD + 1)], qf[ks], sc[kg], 0, 0, 0);
+    };
+    auto mfma_v = [&](int i) {
+        const int kg = i / (2 * DB), s16 = (i / DB) & 1, db = i % DB;
+        o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfr[i % (LEAD + 1)], pf[kg][s16], o[db], 0, 0, 0);
     };
     auto zero_s = [&]() {
 #pragma unroll
@@ -1318,7 +1337,10 @@ __global__ __launch_bounds__(512, 2) void prefill32p_attn_kernel(const AttnParam
     zero_s();
     if (my_ntiles > 0) {
 #pragma unroll
-        for (int i = 0; i < NM; ++i) qk_step(slot(0), i);
+        for (int i = 0; i < NM; ++i) {
+            load_k(slot(0), i);
+            mfma_k(i);
+        }
     }
     if (wave >= NW / 2) __syncthreads();        // the stagger: waves 4..7 run one phase behind waves 0..3
 
@@ -1336,29 +1358,47 @@ __global__ __launch_bounds__(512, 2) void prefill32p_attn_kernel(const AttnParam
     // last tile (no Q.K^T of a next one), and the tiles only later waves of the workgroup need (staging only).
     int t = 0;
     for (; t + 1 < my_ntiles; ++t) {
+        const unsigned char* imgk = slot(t + 1);
+        const unsigned char* imgv = slot(t);
         stage_next(t);                                   // ---- P_b(t): vector phase
         softmax(t, (t * KT + KT - 1) > lo);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < LEAD; ++i) {                 // first fragments of the matrix phase: both tiles are complete
+            load_k(imgk, i);                             // in LDS since the previous barrier
+            load_v(imgv, i);
+        }
         phase_barrier();
-        const unsigned char* imgk = slot(t + 1);          // ---- P_a(t): matrix phase
-        const unsigned char* imgv = slot(t);
-        zero_s();
+        zero_s();                                        // ---- P_a(t): matrix phase
         if constexpr (PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int i = 0; i < NM; ++i) {
-            qk_step(imgk, i);
-            pv_step(imgv, i);
+            if (i + LEAD < NM) {
+                load_k(imgk, i + LEAD);
+                load_v(imgv, i + LEAD);
+            }
+            mfma_k(i);
+            mfma_v(i);
+            __builtin_amdgcn_sched_barrier(0);
         }
         if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
         phase_barrier();
     }
     if (t < my_ntiles) {
+        const unsigned char* imgv = slot(t);
         stage_next(t);
         softmax(t, (t * KT + KT - 1) > lo);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < LEAD; ++i) load_v(imgv, i);
         phase_barrier();
-        const unsigned char* imgv = slot(t);
         if constexpr (PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-        for (int i = 0; i < NM; ++i) pv_step(imgv, i);
+        for (int i = 0; i < NM; ++i) {
+            if (i + LEAD < NM) load_v(imgv, i + LEAD);
+            mfma_v(i);
+            __builtin_amdgcn_sched_barrier(0);
+        }
         if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
         phase_barrier();
         ++t;
@@ -1380,7 +1420,8 @@ __global__ __launch_bounds__(512, 2) void prefill32p_attn_kernel(const AttnParam
             for (int rg = 0; rg < 4; ++rg) {
                 const f32x4 ov = {o[db][rg * 4] * inv, o[db][rg * 4 + 1] * inv, o[db][rg * 4 + 2] * inv,
                                   o[db][rg * 4 + 3] * inv};
-                *reinterpret_cast<bf16x4*>(op + db * 32 + rg * 8 + kh * 4) = __builtin_convertvector(ov, bf16x4);
+                const int dd = (db + (rg >> 1) * (NB / 2)) * 16 + (rg & 1) * 8;
+                *reinterpret_cast<bf16x4*>(op + dd + kh * 4) = __builtin_convertvector(ov, bf16x4);
             }
     }
 }
@@ -1502,10 +1543,10 @@ int launch_prefill_kt(const AttnParams& p, int grid, hipStream_t st) {
 // Dev knob (md_debug_set_prefill_mfma32 / MAGICDEC_PREFILL_MFMA32): -1 = this rule, 0 = the 16x16x32 kernel, 32 | 64 | 128 forced.
 int g_prefill_mfma32 = -1;
 
-template <int D, int NW, int KT>
+template <int D, int NW, int KT, bool VP = true>
 int launch_prefill32_kt(const AttnParams& p, int grid, hipStream_t st) {
     constexpr int lds = 2 * prefill_stage_bytes<D, KT>() + 32;
-    auto k = prefill32_attn_kernel<D, NW, KT>;
+    auto k = prefill32_attn_kernel<D, NW, KT, VP>;
     if (lds > 64 * 1024) {
         static MdPerDeviceOnce once;
         if (once.first()) {
@@ -1548,11 +1589,16 @@ int launch_prefill(const AttnParams& p, int grid, int nw, hipStream_t st) {
         if (g_prefill_mfma32 >= 1000 && nw == 8) {           // ping-pong variants (dev knob): 1000 * (1 + VAR) + keys
             const int kt = g_prefill_mfma32 % 1000, var = g_prefill_mfma32 / 1000 - 1;
             if (kt == 64 && fits(64))
-                return var == 1 ? launch_prefill32p<D, 64, 1>(p, grid, st) : launch_prefill32p<D, 64, 0>(p, grid, st);
+                return var == 1 ? launch_prefill32p<D, 64, 1>(p, grid, st)
+                     : var == 2 ? launch_prefill32p<D, 64, 2>(p, grid, st)
+                     : var == 3 ? launch_prefill32p<D, 64, 3>(p, grid, st) : launch_prefill32p<D, 64, 0>(p, grid, st);
             if constexpr (D == 64)
                 if (kt == 128 && fits(128))
                     return var == 1 ? launch_prefill32p<D, 128, 1>(p, grid, st) : launch_prefill32p<D, 128, 0>(p, grid, st);
         }
+        if constexpr (D == 128)
+            if (g_prefill_mfma32 == 129 && nw == 8 && fits(128))     // dev: 128 keys, first version's V sub-tile pairing
+                return launch_prefill32_kt<D, 8, 128, false>(p, grid, st);
         int kt32 = g_prefill_mfma32 < 0 ? (D == 128 ? 128 : 64) : g_prefill_mfma32;
         if (kt32 >= 1000) kt32 = D == 128 ? 128 : 64;
         while (kt32 > 32 && !fits(kt32)) kt32 >>= 1;
@@ -1586,7 +1632,7 @@ int launch_prefill(const AttnParams& p, int grid, int nw, hipStream_t st) {
 extern "C" void md_debug_set_attn_target_wgs(int n) { g_target_wgs = n > 0 ? n : 256; }
 extern "C" void md_debug_set_prefill_mfma32(int kt) {
     const int base = kt >= 1000 ? kt % 1000 : kt;                     // >= 1000: ping-pong variants, see launch_prefill
-    g_prefill_mfma32 = (base == 32 || base == 64 || base == 128 || kt < 0) ? kt : 0;   // < 0: the rule, 0: off
+    g_prefill_mfma32 = (base == 32 || base == 64 || base == 128 || kt == 129 || kt < 0) ? kt : 0;   // < 0: the rule, 0: off
 }
 
 extern "C" void md_debug_set_prefill_kt(int kt, int nw) {

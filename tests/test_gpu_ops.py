@@ -136,7 +136,7 @@ PREFILL_VARIANT_SHAPES = [
     ("d64-ring-laps", 32, 8, 64, [128, 100], [1300, 900], 128),
     ("d128-page64", 8, 2, 128, [128, 128], [1000, 640], 64),
 ]
-PREFILL_VARIANTS = [0, 32, 64, 128, 1064, 2064, 1128, 2128]   # md_debug_set_prefill_mfma32: 16x16 | 32x32 keys | ping-pong
+PREFILL_VARIANTS = [0, 32, 64, 128, 129, 1064, 2064, 3064, 4064, 1128, 2128]   # md_debug_set_prefill_mfma32: 16x16 | 32x32 keys | ping-pong
 
 
 @pytest.mark.parametrize("knob", PREFILL_VARIANTS)
