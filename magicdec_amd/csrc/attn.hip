@@ -876,7 +876,7 @@ __global__ __launch_bounds__(64 * NW, 2) void prefill_attn_kernel(const AttnPara
 // Measured and NOT kept (same box, profiles/r03_prefill_mfma32_ab.txt): s_setprio(1) around the MFMA clusters (808 vs 820
 // TFLOP/s), the causal mask as a compile-time property of the tile body (two bodies: 480 -- the register file again), the
 // MFMAs of one accumulator issued back to back instead of alternating accumulators (795 vs 817).
-template <int D, int NW, int KT, bool VP = true>
+template <int D, int NW, int KT, bool VP = true, int AB = 0>   // AB: timing ablations (wrong results): 1 = no softmax, 2 = no P.V
 __global__ __launch_bounds__(64 * NW, 2) void prefill32_attn_kernel(const AttnParams p) {
     constexpr int KG = KT / 32;            // 32-key blocks per tile
     constexpr int CH = D * 2 / 16;
@@ -1012,6 +1012,19 @@ __global__ __launch_bounds__(64 * NW, 2) void prefill32_attn_kernel(const AttnPa
                 const bf16x8 kf = lds_read_b128(img + kra0 + kg * 32 * KROW + ks * 32);
                 sc[kg] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], sc[kg], 0, 0, 0);
             }
+        bf16x8 pf[KG][2];
+        if constexpr (AB == 1) {
+#pragma unroll
+            for (int kg = 0; kg < KG; ++kg)
+#pragma unroll
+                for (int s16 = 0; s16 < 2; ++s16) {
+                    f32x8 pv;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) pv[e] = sc[kg][s16 * 8 + e];
+                    pf[kg][s16] = __builtin_convertvector(pv, bf16x8);
+                }
+            l = 1.f;
+        } else {
         if (need_mask) {
             // a real (wave-uniform) branch: only the last tiles of a causal chunk take it; the empty volatile asm keeps
             // the compiler from if-converting it into 32 compare/select pairs executed on every tile
@@ -1045,7 +1058,6 @@ __global__ __launch_bounds__(64 * NW, 2) void prefill32_attn_kernel(const AttnPa
         }
         const float mneg = -m;
         float ps = 0.f;
-        bf16x8 pf[KG][2];
 #pragma unroll
         for (int kg = 0; kg < KG; ++kg)
 #pragma unroll
@@ -1060,6 +1072,7 @@ __global__ __launch_bounds__(64 * NW, 2) void prefill32_attn_kernel(const AttnPa
                 pf[kg][s16] = __builtin_convertvector(pv, bf16x8);
             }
         l += ps;
+        }
         auto pv = [&](int db, int kg, int s16) {
             const unsigned char* vb = img + kg * VG + (VDS * db) * kVSub + vra0 + s16 * 16 * 32;
             const bf16x4 v0 = lds_read_tr(vb);
@@ -1073,7 +1086,12 @@ __global__ __launch_bounds__(64 * NW, 2) void prefill32_attn_kernel(const AttnPa
 #pragma unroll
             for (int s16 = 0; s16 < 2; ++s16)
 #pragma unroll
-                for (int db = 0; db < DB; ++db) pv(db, kg, s16);
+                for (int db = 0; db < DB; ++db) {
+                    if constexpr (AB == 2)
+                        asm volatile("" ::"v"(pf[kg][s16]));
+                    else
+                        pv(db, kg, s16);
+                }
     };
 
     if (ntiles_wg > 0) issue(0);
@@ -1270,6 +1288,19 @@ __global__ __launch_bounds__(512, 2) void prefill32p_attn_kernel(const AttnParam
             for (int r = 0; r < 16; ++r) sc[kg][r] = 0.f;
     };
     auto softmax = [&](int t, bool need_mask) {
+        if constexpr ((VAR & 4) != 0) {      // timing ablation (wrong results): P = bf16(S)
+#pragma unroll
+            for (int kg = 0; kg < KG; ++kg)
+#pragma unroll
+                for (int s16 = 0; s16 < 2; ++s16) {
+                    f32x8 pv;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) pv[e] = sc[kg][s16 * 8 + e];
+                    pf[kg][s16] = __builtin_convertvector(pv, bf16x8);
+                }
+            l = 1.f;
+            return;
+        }
         if (need_mask) {
             // a real (wave-uniform) branch, as in prefill32_attn_kernel
 #pragma unroll
@@ -1543,10 +1574,10 @@ int launch_prefill_kt(const AttnParams& p, int grid, hipStream_t st) {
 // Dev knob (md_debug_set_prefill_mfma32 / MAGICDEC_PREFILL_MFMA32): -1 = this rule, 0 = the 16x16x32 kernel, 32 | 64 | 128 forced.
 int g_prefill_mfma32 = -1;
 
-template <int D, int NW, int KT, bool VP = true>
+template <int D, int NW, int KT, bool VP = true, int AB = 0>
 int launch_prefill32_kt(const AttnParams& p, int grid, hipStream_t st) {
     constexpr int lds = 2 * prefill_stage_bytes<D, KT>() + 32;
-    auto k = prefill32_attn_kernel<D, NW, KT, VP>;
+    auto k = prefill32_attn_kernel<D, NW, KT, VP, AB>;
     if (lds > 64 * 1024) {
         static MdPerDeviceOnce once;
         if (once.first()) {
@@ -1591,7 +1622,8 @@ int launch_prefill(const AttnParams& p, int grid, int nw, hipStream_t st) {
             if (kt == 64 && fits(64))
                 return var == 1 ? launch_prefill32p<D, 64, 1>(p, grid, st)
                      : var == 2 ? launch_prefill32p<D, 64, 2>(p, grid, st)
-                     : var == 3 ? launch_prefill32p<D, 64, 3>(p, grid, st) : launch_prefill32p<D, 64, 0>(p, grid, st);
+                     : var == 3 ? launch_prefill32p<D, 64, 3>(p, grid, st)
+                     : var == 4 ? launch_prefill32p<D, 64, 4>(p, grid, st) : launch_prefill32p<D, 64, 0>(p, grid, st);
             if constexpr (D == 64)
                 if (kt == 128 && fits(128))
                     return var == 1 ? launch_prefill32p<D, 128, 1>(p, grid, st) : launch_prefill32p<D, 128, 0>(p, grid, st);
@@ -1599,6 +1631,10 @@ int launch_prefill(const AttnParams& p, int grid, int nw, hipStream_t st) {
         if constexpr (D == 128)
             if (g_prefill_mfma32 == 129 && nw == 8 && fits(128))     // dev: 128 keys, first version's V sub-tile pairing
                 return launch_prefill32_kt<D, 8, 128, false>(p, grid, st);
+        if constexpr (D == 128) {
+            if (g_prefill_mfma32 == 130 && nw == 8 && fits(128)) return launch_prefill32_kt<D, 8, 128, true, 1>(p, grid, st);
+            if (g_prefill_mfma32 == 131 && nw == 8 && fits(128)) return launch_prefill32_kt<D, 8, 128, true, 2>(p, grid, st);
+        }
         int kt32 = g_prefill_mfma32 < 0 ? (D == 128 ? 128 : 64) : g_prefill_mfma32;
         if (kt32 >= 1000) kt32 = D == 128 ? 128 : 64;
         while (kt32 > 32 && !fits(kt32)) kt32 >>= 1;
@@ -1632,7 +1668,7 @@ int launch_prefill(const AttnParams& p, int grid, int nw, hipStream_t st) {
 extern "C" void md_debug_set_attn_target_wgs(int n) { g_target_wgs = n > 0 ? n : 256; }
 extern "C" void md_debug_set_prefill_mfma32(int kt) {
     const int base = kt >= 1000 ? kt % 1000 : kt;                     // >= 1000: ping-pong variants, see launch_prefill
-    g_prefill_mfma32 = (base == 32 || base == 64 || base == 128 || kt == 129 || kt < 0) ? kt : 0;   // < 0: the rule, 0: off
+    g_prefill_mfma32 = (base == 32 || base == 64 || base == 128 || (kt >= 129 && kt <= 131) || kt < 0) ? kt : 0;   // < 0: the rule, 0: off
 }
 
 extern "C" void md_debug_set_prefill_kt(int kt, int nw) {

@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from magicdec_amd import ops
 
 ap = argparse.ArgumentParser()
-for k, v in dict(B=64, S=16036, KH=8, H=32, D=128, n=4, iters=20, layers=2, wgs=0, fp8=0, hnd=0, kt=0, nw=0, mfma32=-1, reps=1).items():
+for k, v in dict(B=64, S=16036, KH=8, H=32, D=128, n=4, iters=20, layers=2, wgs=0, fp8=0, hnd=0, kt=0, nw=0, mfma32=-1, reps=1, zero=0).items():
     ap.add_argument(f"--{k}", type=int, default=v)
 ap.add_argument("--variants", default="", help="comma list of md_debug_set_prefill_mfma32 values timed in ONE process on the "
                 "same tensors (x --reps), each checked against the first one's output")
@@ -40,6 +40,10 @@ indices = torch.arange(a.B * mp, dtype=torch.int32, device=dev)
 indptr = torch.arange(a.B + 1, dtype=torch.int32, device=dev) * mp
 last = torch.full((a.B,), a.S - (mp - 1) * 128, dtype=torch.int32, device=dev)
 qo = torch.arange(a.B + 1, dtype=torch.int32, device=dev) * a.n
+if a.zero:                                     # DVFS check: same instruction stream, no toggling data
+    for c in caches:
+        c.zero_()
+    q.zero_()
 ws = ops.AttnWorkspace(dev)
 nbytes = a.B * a.S * a.KH * a.D * 2 * (1 if a.fp8 else 2) + 2 * a.B * a.n * a.H * a.D * 2
 flops = 4.0 * a.B * a.n * a.H * a.D * (a.S - a.n / 2.0)          # causal: row i of the chunk sees S - n + i + 1 keys
