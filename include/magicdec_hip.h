@@ -142,7 +142,9 @@ size_t md_paged_attn_workspace_bytes(int B, int n_max, int H, int KH, int D,
  * n <= 0 restores the default (256 = one per CU). Host, not thread-safe. */
 void md_debug_set_attn_target_wgs(int n);
 void md_debug_set_prefill_mfma32(int kt); /* development: 32x32x16-MFMA prefill kernel: -1 = the measured rule (default), 0 = off
-                                           * (the 16x16x32 kernel), 32 | 64 | 128 = keys per shared tile */
+                                           * (the 16x16x32 kernel), 32 | 64 | 128 = keys per shared tile (halved until it
+                                           * divides the page size); 129 = 128 keys, first V sub-tile pairing; 130 / 131 =
+                                           * TIMING ABLATIONS of the 128-key kernel (no softmax / no P.V: wrong results) */
 void md_debug_set_prefill_kt(int kt, int nw); /* development: keys per shared tile of the bf16 prefill kernel (32 | 64 =
                                                * default) and waves per workgroup (4 | 8; 0 = the measured rule) */
 /* measurement (bench.py's roofline): while enabled, every decode / verify launch of md_paged_attn with n_max ==

@@ -1025,53 +1025,53 @@ __global__ __launch_bounds__(64 * NW, 2) void prefill32_attn_kernel(const AttnPa
                 }
             l = 1.f;
         } else {
-        if (need_mask) {
-            // a real (wave-uniform) branch: only the last tiles of a causal chunk take it; the empty volatile asm keeps
-            // the compiler from if-converting it into 32 compare/select pairs executed on every tile
+            if (need_mask) {
+                // a real (wave-uniform) branch: only the last tiles of a causal chunk take it; the empty volatile asm keeps
+                // the compiler from if-converting it into 32 compare/select pairs executed on every tile
+#pragma unroll
+                for (int kg = 0; kg < KG; ++kg)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int pos = t * KT + kg * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                        float v = sc[kg][r];
+                        if (pos > lim) v = -INFINITY;
+                        asm volatile("" : "+v"(v));          // volatile: cannot be hoisted out of the branch
+                        sc[kg][r] = v;
+                    }
+            }
+            float mx = sc[0][0];
 #pragma unroll
             for (int kg = 0; kg < KG; ++kg)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int pos = t * KT + kg * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-                    float v = sc[kg][r];
-                    if (pos > lim) v = -INFINITY;
-                    asm volatile("" : "+v"(v));          // volatile: cannot be hoisted out of the branch
-                    sc[kg][r] = v;
-                }
-        }
-        float mx = sc[0][0];
+                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sc[kg][r]);
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            mx *= sl2;
+            if (__builtin_amdgcn_ballot_w64(mx > m) != 0) {       // lazy rescale, wave-uniform
+                const float mnew = fmaxf(m, mx);
+                const float alpha = __builtin_amdgcn_exp2f(m - mnew);
+                m = mnew;
+                l *= alpha;
 #pragma unroll
-        for (int kg = 0; kg < KG; ++kg)
+                for (int db = 0; db < DB; ++db)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sc[kg][r]);
-        mx = fmaxf(mx, __shfl_xor(mx, 32));
-        mx *= sl2;
-        if (__builtin_amdgcn_ballot_w64(mx > m) != 0) {       // lazy rescale, wave-uniform
-            const float mnew = fmaxf(m, mx);
-            const float alpha = __builtin_amdgcn_exp2f(m - mnew);
-            m = mnew;
-            l *= alpha;
-#pragma unroll
-            for (int db = 0; db < DB; ++db)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
-        }
-        const float mneg = -m;
-        float ps = 0.f;
-#pragma unroll
-        for (int kg = 0; kg < KG; ++kg)
-#pragma unroll
-            for (int s16 = 0; s16 < 2; ++s16) {
-                f32x8 pv;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const float pe = __builtin_amdgcn_exp2f(fmaf(sc[kg][s16 * 8 + e], sl2, mneg));
-                    pv[e] = pe;
-                    ps += pe;
-                }
-                pf[kg][s16] = __builtin_convertvector(pv, bf16x8);
+                    for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
             }
-        l += ps;
+            const float mneg = -m;
+            float ps = 0.f;
+#pragma unroll
+            for (int kg = 0; kg < KG; ++kg)
+#pragma unroll
+                for (int s16 = 0; s16 < 2; ++s16) {
+                    f32x8 pv;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float pe = __builtin_amdgcn_exp2f(fmaf(sc[kg][s16 * 8 + e], sl2, mneg));
+                        pv[e] = pe;
+                        ps += pe;
+                    }
+                    pf[kg][s16] = __builtin_convertvector(pv, bf16x8);
+                }
+            l += ps;
         }
         auto pv = [&](int db, int kg, int s16) {
             const unsigned char* vb = img + kg * VG + (VDS * db) * kVSub + vra0 + s16 * 16 * 32;
@@ -1114,344 +1114,6 @@ __global__ __launch_bounds__(64 * NW, 2) void prefill32_attn_kernel(const AttnPa
                 const f32x4 ov = {o[db][rg * 4] * inv, o[db][rg * 4 + 1] * inv, o[db][rg * 4 + 2] * inv,
                                   o[db][rg * 4 + 3] * inv};
                 const int dd = VP ? (db + (rg >> 1) * (NB / 2)) * 16 + (rg & 1) * 8 : db * 32 + rg * 8;
-                *reinterpret_cast<bf16x4*>(op + dd + kh * 4) = __builtin_convertvector(ov, bf16x4);
-            }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// K3, round 3b: the 32x32x16 kernel as a two-group PING-PONG.  The body above runs the matrix work (Q.K^T, P.V) and the
-// vector work (max, exp2, sum, bf16 pack) of a tile one after the other in every wave, and the one barrier per tile
-// keeps the two waves of a SIMD (wave w and w + 4 of the 8-wave workgroup) in the SAME phase: both want the MFMA pipe,
-// then both want the VALU.  Here a wave's tile loop is software-pipelined into two phases
-//     P_b(t): softmax of S(t) (VALU only) + the LDS writes of tile t + 2 + the global loads of tile t + 3
-//     P_a(t): S(t + 1) = K(t + 1) Q^T  and  O += V(t)^T P(t)^T        (MFMA + LDS fragment reads only)
-// separated by workgroup barriers, and waves 4..7 execute ONE extra barrier before their loop: between two hardware
-// barriers waves 0..3 are in P_a while 4..7 are in P_b and vice versa, so every SIMD always has one wave feeding the
-// matrix pipe and one on the vector pipe.  K of tile t + 1 is consumed one phase before V of tile t, so the K/V tile
-// images live in a ring of FOUR (tile x is read in the hardware-barrier intervals 2x-1 .. 2x+2, written in 2x-4 and
-// 2x-3, and overwrites tile x-4 whose last read was in interval 2x-6); a ring of three would have waves 0..3 writing
-// tile x while waves 4..7 still read V of tile x-3.  Fragment layouts, staging, causal bookkeeping and the epilogue are
-// those of prefill32_attn_kernel.
-template <int D, int KT, int VAR>
-__global__ __launch_bounds__(512, 2) void prefill32p_attn_kernel(const AttnParams p) {
-    constexpr int NW = 8, RING = 4;
-    constexpr int KG = KT / 32;            // 32-key blocks per tile
-    constexpr int CH = D * 2 / 16;
-    constexpr int RPI = 64 / CH;
-    constexpr int NL = KT / RPI;
-    constexpr int NLW = (NL + NW - 1) / NW;
-    constexpr int KS = D / 16;             // 16-deep k-steps of QK^T
-    constexpr int NB = D / 16;             // 16-d V sub-tiles
-    constexpr int DB = D / 32;             // 32-d output blocks
-    constexpr int KROW = D * 2 + 16;
-    constexpr int K_BYTES = KT * KROW;
-    constexpr int VG = NB * kVSub;
-    constexpr int STAGE = prefill_stage_bytes<D, KT>();
-    constexpr int NM = KS * KG;            // MFMAs of one Q.K^T tile == MFMAs of one P.V tile
-    static_assert(NM == KG * 2 * DB, "QK^T and PV issue the same number of MFMAs per tile");
-    static_assert(RING * STAGE + 32 <= 160 * 1024, "ring of four tile images must fit the LDS");
-    constexpr bool PRIO = (VAR & 1) != 0;  // s_setprio(1) around the MFMA phase
-
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // RING x STAGE, then int[NW]
-    int* s_end = reinterpret_cast<int*>(smem + RING * STAGE);
-    const int tid = threadIdx.x;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int lane = tid & 63;
-    const int j = lane & 31, kh = lane >> 5;
-
-    const int bid = blockIdx.x;
-    const int xcd = bid & 7;
-    const int r0 = bid >> 3;
-    const int qg = r0 % p.n_qgroups;
-    const int pair = (r0 / p.n_qgroups) * 8 + xcd;
-    if (pair >= p.B * p.KH) return;
-    const int b = pair / p.KH, kvh = pair % p.KH;
-    const int g = p.g;
-    const int q0 = p.qo_indptr[b];
-    const int n_b = p.qo_indptr[b + 1] - q0;
-    const int pg0 = p.page_indptr[b];
-    const int npages = p.page_indptr[b + 1] - pg0;
-    const int kv_len = npages > 0 ? min((npages - 1) * p.page_size + p.last_page_len[b], npages * p.page_size) : 0;
-    const int nrows = n_b * g;
-    const int R = (qg * NW + wave) * 32 + j;
-    const bool valid = R < nrows;
-    const int qi = R / g, qr = R - qi * g;
-    const int lim = valid ? (p.causal ? kv_len - n_b + qi : kv_len - 1) : -1;
-    int hi = lim, lo = valid ? lim : 0x7fffffff;
-#pragma unroll
-    for (int o = 1; o < 32; o <<= 1) {
-        hi = max(hi, __shfl_xor(hi, o));
-        lo = min(lo, __shfl_xor(lo, o));
-    }
-    hi = __builtin_amdgcn_readfirstlane(hi);
-    lo = __builtin_amdgcn_readfirstlane(lo);
-    const int kv_end = min(hi + 1, kv_len);
-    if (lane == 0) s_end[wave] = kv_end;
-    __syncthreads();
-    int kv_end_wg = 0;
-#pragma unroll
-    for (int w = 0; w < NW; ++w) kv_end_wg = max(kv_end_wg, s_end[w]);
-    const int ntiles_wg = kv_end_wg > 0 ? (kv_end_wg + KT - 1) / KT : 0;
-    const int my_ntiles = kv_end > 0 ? (kv_end + KT - 1) / KT : 0;
-
-    bf16x8 qf[KS];
-    {
-        const bf16_t* qp = p.q + (int64_t)(q0 + qi) * p.q_row_stride + (kvh * g + qr) * D;
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
-            qf[ks] = valid ? *reinterpret_cast<const bf16x8*>(qp + ks * 16 + kh * 8) : z;
-        }
-    }
-    const float sl2 = p.scale_log2;
-    f32x16 o[DB];
-#pragma unroll
-    for (int db = 0; db < DB; ++db)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) o[db][r] = 0.f;
-    float m = -1e30f, l = 0.f;
-
-    // staging: as prefill32_attn_kernel
-    const int wrow = lane / CH, wch = lane % CH;
-    int kw[NLW], vw[NLW];
-#pragma unroll
-    for (int s = 0; s < NLW; ++s) {
-        const int row = wrow + (wave + NW * s) * RPI;
-        kw[s] = row * KROW + (wch << 4);
-        vw[s] = K_BYTES + (row >> 5) * VG + (row & 31) * 32 + (wch >> 1) * kVSub + (wch & 1) * 16;
-    }
-    const unsigned goff = (unsigned)((wrow * p.slot_stride + kvh * p.head_stride) * 2 + wch * 16);
-    u32x4 kreg[NLW], vreg[NLW];
-    auto issue = [&](int tt) {
-        const int pos0 = tt * KT;
-        const int page = pos0 / p.page_size;
-        const int slot0 = pos0 - page * p.page_size;
-        const int pid = __builtin_amdgcn_readfirstlane(p.page_indices[pg0 + page]);
-        const unsigned char* kb_ = reinterpret_cast<const unsigned char*>(p.cache) +
-                                   ((int64_t)pid * p.page_stride + (int64_t)slot0 * p.slot_stride) * 2;
-        const unsigned char* vb_ = kb_ + p.kv_half * 2;
-        const int64_t jstep = (int64_t)RPI * p.slot_stride * 2;
-#pragma unroll
-        for (int s = 0; s < NLW; ++s)
-            if (wave + NW * s < NL) {
-                kreg[s] = *reinterpret_cast<const u32x4*>(kb_ + (wave + NW * s) * jstep + goff);
-                vreg[s] = *reinterpret_cast<const u32x4*>(vb_ + (wave + NW * s) * jstep + goff);
-            }
-    };
-    auto stage = [&](int t, unsigned char* img) {
-#pragma unroll
-        for (int s = 0; s < NLW; ++s)
-            if (wave + NW * s < NL) {
-                if (t * KT + wrow + (wave + NW * s) * RPI >= kv_len) vreg[s] = u32x4{0u, 0u, 0u, 0u};
-                *reinterpret_cast<u32x4*>(img + kw[s]) = kreg[s];
-                *reinterpret_cast<u32x4*>(img + vw[s]) = vreg[s];
-            }
-    };
-    auto slot = [&](int t) -> unsigned char* { return smem + (t & (RING - 1)) * STAGE; };
-    const int kra0 = j * KROW + (kh << 4);
-    const int lq = lane & 15;
-    // a tr-read pairs the 16-d sub-tiles db and db + NB/2 (bank-conflict free at D = 128, see prefill32_attn_kernel)
-    const int vra0 = K_BYTES + ((lane >> 4) & 1) * (NB / 2) * kVSub + (kh * 4 + (lq >> 2)) * 32 + (lq & 3) * 8;
-
-    f32x16 sc[KG];         // S(t + 1), written in P_a(t), consumed in P_b(t + 1)
-    bf16x8 pf[KG][2];      // P(t) as MFMA B fragments, written in P_b(t), consumed in P_a(t)
-
-    // fragment reads run LEAD MFMA pairs ahead of their use: while waves 0..3 are in the matrix phase their SIMD partners
-    // issue no LDS reads, so nothing else hides the ~64-128 cycles between a ds_read and the MFMA that consumes it (the
-    // compiler's own order, read -> wait -> MFMA one or two MFMAs later, left the phase latency-bound: call 22)
-    constexpr int LEAD = (VAR & 2) ? 2 : 3;
-    bf16x8 kfr[LEAD + 1], vfr[LEAD + 1];
-    auto load_k = [&](const unsigned char* imgk, int i) {
-        const int ks = i / KG, kg = i % KG;
-        kfr[i % (LEAD + 1)] = lds_read_b128(imgk + kra0 + kg * 32 * KROW + ks * 32);
-    };
-    auto load_v = [&](const unsigned char* imgv, int i) {
-        const int kg = i / (2 * DB), s16 = (i / DB) & 1, db = i % DB;
-        const unsigned char* vb = imgv + kg * VG + db * kVSub + vra0 + s16 * 16 * 32;
-        const bf16x4 v0 = lds_read_tr(vb);
-        const bf16x4 v1 = lds_read_tr(vb + 8 * 32);
-        vfr[i % (LEAD + 1)] = __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7);
-    };
-    auto mfma_k = [&](int i) {
-        const int ks = i / KG, kg = i % KG;
-        sc[kg] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[i % (LEAD + 1)], qf[ks], sc[kg], 0, 0, 0);
-    };
-    auto mfma_v = [&](int i) {
-        const int kg = i / (2 * DB), s16 = (i / DB) & 1, db = i % DB;
-        o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfr[i % (LEAD + 1)], pf[kg][s16], o[db], 0, 0, 0);
-    };
-    auto zero_s = [&]() {
-#pragma unroll
-        for (int kg = 0; kg < KG; ++kg)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) sc[kg][r] = 0.f;
-    };
-    auto softmax = [&](int t, bool need_mask) {
-        if constexpr ((VAR & 4) != 0) {      // timing ablation (wrong results): P = bf16(S)
-#pragma unroll
-            for (int kg = 0; kg < KG; ++kg)
-#pragma unroll
-                for (int s16 = 0; s16 < 2; ++s16) {
-                    f32x8 pv;
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) pv[e] = sc[kg][s16 * 8 + e];
-                    pf[kg][s16] = __builtin_convertvector(pv, bf16x8);
-                }
-            l = 1.f;
-            return;
-        }
-        if (need_mask) {
-            // a real (wave-uniform) branch, as in prefill32_attn_kernel
-#pragma unroll
-            for (int kg = 0; kg < KG; ++kg)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int pos = t * KT + kg * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-                    float v = sc[kg][r];
-                    if (pos > lim) v = -INFINITY;
-                    asm volatile("" : "+v"(v));
-                    sc[kg][r] = v;
-                }
-        }
-        float mx = sc[0][0];
-#pragma unroll
-        for (int kg = 0; kg < KG; ++kg)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sc[kg][r]);
-        mx = fmaxf(mx, __shfl_xor(mx, 32));
-        mx *= sl2;
-        if (__builtin_amdgcn_ballot_w64(mx > m) != 0) {       // lazy rescale, wave-uniform; P.V of tile t-1 is complete
-            const float mnew = fmaxf(m, mx);
-            const float alpha = __builtin_amdgcn_exp2f(m - mnew);
-            m = mnew;
-            l *= alpha;
-#pragma unroll
-            for (int db = 0; db < DB; ++db)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
-        }
-        const float mneg = -m;
-        float ps = 0.f;
-#pragma unroll
-        for (int kg = 0; kg < KG; ++kg)
-#pragma unroll
-            for (int s16 = 0; s16 < 2; ++s16) {
-                f32x8 pv;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const float pe = __builtin_amdgcn_exp2f(fmaf(sc[kg][s16 * 8 + e], sl2, mneg));
-                    pv[e] = pe;
-                    ps += pe;
-                }
-                pf[kg][s16] = __builtin_convertvector(pv, bf16x8);
-            }
-        l += ps;
-        asm volatile("" : "+v"(l));      // the row sum is formed HERE, not sunk into the matrix phase behind the barrier
-    };
-
-    // prologue (all eight waves in step): tiles 0 and 1 into the ring, tile 2 in flight, S(0)
-    if (ntiles_wg > 0) {
-        issue(0);
-        stage(0, slot(0));
-    }
-    if (ntiles_wg > 1) {
-        issue(1);
-        stage(1, slot(1));
-    }
-    if (ntiles_wg > 2) issue(2);
-    __syncthreads();
-    // the Q fragments are waited for HERE on every path (else the loop carries a "maybe pending" state for them and
-    // the first MFMA of every matrix phase waits for ALL outstanding loads, i.e. for the tile just issued)
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) asm volatile("" ::"v"(qf[ks]));
-    zero_s();
-    if (my_ntiles > 0) {
-#pragma unroll
-        for (int i = 0; i < NM; ++i) {
-            load_k(slot(0), i);
-            mfma_k(i);
-        }
-    }
-    if (wave >= NW / 2) __syncthreads();        // the stagger: waves 4..7 run one phase behind waves 0..3
-
-    auto phase_barrier = [&]() {
-        __builtin_amdgcn_sched_barrier(0);
-        __syncthreads();
-        __builtin_amdgcn_sched_barrier(0);
-    };
-    auto stage_next = [&](int t) {
-        if (t + 2 < ntiles_wg) stage(t + 2, slot(t + 2));
-        if (t + 3 < ntiles_wg) issue(t + 3);
-    };
-    // Three loops with the same barrier pattern, so that the S / O accumulators never cross a conditional join (the
-    // compiler otherwise keeps two copies of S and moves 64 registers per tile): tiles with a successor, the wave's
-    // last tile (no Q.K^T of a next one), and the tiles only later waves of the workgroup need (staging only).
-    int t = 0;
-    for (; t + 1 < my_ntiles; ++t) {
-        const unsigned char* imgk = slot(t + 1);
-        const unsigned char* imgv = slot(t);
-        stage_next(t);                                   // ---- P_b(t): vector phase
-        softmax(t, (t * KT + KT - 1) > lo);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int i = 0; i < LEAD; ++i) {                 // first fragments of the matrix phase: both tiles are complete
-            load_k(imgk, i);                             // in LDS since the previous barrier
-            load_v(imgv, i);
-        }
-        phase_barrier();
-        zero_s();                                        // ---- P_a(t): matrix phase
-        if constexpr (PRIO) __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int i = 0; i < NM; ++i) {
-            if (i + LEAD < NM) {
-                load_k(imgk, i + LEAD);
-                load_v(imgv, i + LEAD);
-            }
-            mfma_k(i);
-            mfma_v(i);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
-        phase_barrier();
-    }
-    if (t < my_ntiles) {
-        const unsigned char* imgv = slot(t);
-        stage_next(t);
-        softmax(t, (t * KT + KT - 1) > lo);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int i = 0; i < LEAD; ++i) load_v(imgv, i);
-        phase_barrier();
-        if constexpr (PRIO) __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int i = 0; i < NM; ++i) {
-            if (i + LEAD < NM) load_v(imgv, i + LEAD);
-            mfma_v(i);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
-        phase_barrier();
-        ++t;
-    }
-    for (; t < ntiles_wg; ++t) {
-        stage_next(t);
-        phase_barrier();
-        phase_barrier();
-    }
-    if (wave < NW / 2) __syncthreads();         // every wave executes the same number of barriers
-
-    l += __shfl_xor(l, 32);
-    if (valid) {
-        const float inv = l > 0.f ? 1.0f / l : 0.f;
-        bf16_t* op = p.out + ((int64_t)(q0 + qi) * p.H + kvh * g + qr) * D;
-#pragma unroll
-        for (int db = 0; db < DB; ++db)
-#pragma unroll
-            for (int rg = 0; rg < 4; ++rg) {
-                const f32x4 ov = {o[db][rg * 4] * inv, o[db][rg * 4 + 1] * inv, o[db][rg * 4 + 2] * inv,
-                                  o[db][rg * 4 + 3] * inv};
-                const int dd = (db + (rg >> 1) * (NB / 2)) * 16 + (rg & 1) * 8;
                 *reinterpret_cast<bf16x4*>(op + dd + kh * 4) = __builtin_convertvector(ov, bf16x4);
             }
     }
@@ -1571,7 +1233,8 @@ int launch_prefill_kt(const AttnParams& p, int grid, hipStream_t st) {
 // spills, 137 KB LDS), 64 at D = 64 (118 VGPRs: two workgroups per CU; 128 keys would cost the second one) -- measured,
 // same box (profiles/r03_prefill_mfma32_ab.txt; B = 64, 128 tokens x 32 heads vs 16 K keys, TFLOP/s): D = 128: 668 (16x16
 // kernel, 32 keys) -> 778 (32) -> 805 (64) -> 874 (128); D = 64: 712 -> 729 (64), 667 (128).
-// Dev knob (md_debug_set_prefill_mfma32 / MAGICDEC_PREFILL_MFMA32): -1 = this rule, 0 = the 16x16x32 kernel, 32 | 64 | 128 forced.
+// Dev knob (md_debug_set_prefill_mfma32 / MAGICDEC_PREFILL_MFMA32): -1 = this rule, 0 = the 16x16x32 kernel, 32 | 64 | 128 forced
+// (halved until it divides the page size), 129 = first V pairing, 130 / 131 = timing ablations.
 int g_prefill_mfma32 = -1;
 
 template <int D, int NW, int KT, bool VP = true, int AB = 0>
@@ -1594,49 +1257,18 @@ int launch_prefill32_kt(const AttnParams& p, int grid, hipStream_t st) {
     return MD_OK;
 }
 
-template <int D, int KT, int VAR>
-int launch_prefill32p(const AttnParams& p, int grid, hipStream_t st) {
-    constexpr int lds = 4 * prefill_stage_bytes<D, KT>() + 32;
-    auto k = prefill32p_attn_kernel<D, KT, VAR>;
-    static MdPerDeviceOnce once;
-    if (once.first()) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds) !=
-            hipSuccess) {
-            once.undo();
-            md_set_error("md_paged_attn(prefill32p): hipFuncSetAttribute(%d B LDS) failed", lds);
-            return MD_ERR_LAUNCH;
-        }
-    }
-    hipLaunchKernelGGL(k, dim3(grid), dim3(512), lds, st, p);
-    MD_CHECK_LAUNCH("md_paged_attn(prefill32p)");
-    return MD_OK;
-}
-
 template <int D, int QT, bool FP8>
 int launch_prefill(const AttnParams& p, int grid, int nw, hipStream_t st) {
     // a shared tile never crosses a page: keys per tile must divide the page size (32 always does, md_paged_attn checks)
     const auto fits = [&](int kt) { return p.page_size % kt == 0; };
     if constexpr (!FP8 && QT == 2) {
-        if (g_prefill_mfma32 >= 1000 && nw == 8) {           // ping-pong variants (dev knob): 1000 * (1 + VAR) + keys
-            const int kt = g_prefill_mfma32 % 1000, var = g_prefill_mfma32 / 1000 - 1;
-            if (kt == 64 && fits(64))
-                return var == 1 ? launch_prefill32p<D, 64, 1>(p, grid, st)
-                     : var == 2 ? launch_prefill32p<D, 64, 2>(p, grid, st)
-                     : var == 3 ? launch_prefill32p<D, 64, 3>(p, grid, st)
-                     : var == 4 ? launch_prefill32p<D, 64, 4>(p, grid, st) : launch_prefill32p<D, 64, 0>(p, grid, st);
-            if constexpr (D == 64)
-                if (kt == 128 && fits(128))
-                    return var == 1 ? launch_prefill32p<D, 128, 1>(p, grid, st) : launch_prefill32p<D, 128, 0>(p, grid, st);
-        }
         if constexpr (D == 128)
-            if (g_prefill_mfma32 == 129 && nw == 8 && fits(128))     // dev: 128 keys, first version's V sub-tile pairing
-                return launch_prefill32_kt<D, 8, 128, false>(p, grid, st);
-        if constexpr (D == 128) {
-            if (g_prefill_mfma32 == 130 && nw == 8 && fits(128)) return launch_prefill32_kt<D, 8, 128, true, 1>(p, grid, st);
-            if (g_prefill_mfma32 == 131 && nw == 8 && fits(128)) return launch_prefill32_kt<D, 8, 128, true, 2>(p, grid, st);
-        }
+            if (nw == 8 && fits(128)) {      // dev variants of the 128-key kernel (md_debug_set_prefill_mfma32)
+                if (g_prefill_mfma32 == 129) return launch_prefill32_kt<D, 8, 128, false>(p, grid, st);    // first V pairing
+                if (g_prefill_mfma32 == 130) return launch_prefill32_kt<D, 8, 128, true, 1>(p, grid, st);  // no softmax
+                if (g_prefill_mfma32 == 131) return launch_prefill32_kt<D, 8, 128, true, 2>(p, grid, st);  // no P.V
+            }
         int kt32 = g_prefill_mfma32 < 0 ? (D == 128 ? 128 : 64) : g_prefill_mfma32;
-        if (kt32 >= 1000) kt32 = D == 128 ? 128 : 64;
         while (kt32 > 32 && !fits(kt32)) kt32 >>= 1;
         if (kt32 == 128)
             return nw == 8 ? launch_prefill32_kt<D, 8, 128>(p, grid, st) : launch_prefill32_kt<D, 4, 128>(p, grid, st);
@@ -1667,8 +1299,9 @@ int launch_prefill(const AttnParams& p, int grid, int nw, hipStream_t st) {
 
 extern "C" void md_debug_set_attn_target_wgs(int n) { g_target_wgs = n > 0 ? n : 256; }
 extern "C" void md_debug_set_prefill_mfma32(int kt) {
-    const int base = kt >= 1000 ? kt % 1000 : kt;                     // >= 1000: ping-pong variants, see launch_prefill
-    g_prefill_mfma32 = (base == 32 || base == 64 || base == 128 || (kt >= 129 && kt <= 131) || kt < 0) ? kt : 0;   // < 0: the rule, 0: off
+    // < 0: the rule, 0: the 16x16 kernel, 32 | 64 | 128: keys per tile; 129: 128 keys with the first version's V pairing;
+    // 130 / 131: TIMING ABLATIONS of the 128-key kernel (no softmax / no P.V -- results are wrong by construction)
+    g_prefill_mfma32 = (kt == 32 || kt == 64 || kt == 128 || (kt >= 129 && kt <= 131) || kt < 0) ? kt : 0;
 }
 
 extern "C" void md_debug_set_prefill_kt(int kt, int nw) {

@@ -130,22 +130,21 @@ def test_paged_attention_ragged_query_counts(ops, name, H, KH, D, ns, lens, fp8)
 
 PREFILL_VARIANT_SHAPES = [
     # name, H, KH, D, rows per request, context lengths, page size
-    ("d128-ring-laps", 8, 2, 128, [128, 128], [2100, 1500], 128),          # 33 tiles of 64 keys: 8 laps of the ring
+    ("d128-many-tiles", 8, 2, 128, [128, 128], [2100, 1500], 128),
     ("d128-g1-uneven-waves", 4, 4, 128, [300, 270], [700, 300], 128),      # waves of a workgroup end 4 tiles apart; idle waves
     ("d128-short", 8, 2, 128, [128, 64], [128, 70], 128),                  # 2 tiles / 1 tile + prologue-only paths
-    ("d64-ring-laps", 32, 8, 64, [128, 100], [1300, 900], 128),
+    ("d64-many-tiles", 32, 8, 64, [128, 100], [1300, 900], 128),
     ("d128-page64", 8, 2, 128, [128, 128], [1000, 640], 64),
 ]
-PREFILL_VARIANTS = [0, 32, 64, 128, 129, 1064, 2064, 3064, 4064, 1128, 2128]   # md_debug_set_prefill_mfma32: 16x16 | 32x32 keys | ping-pong
+PREFILL_VARIANTS = [0, 32, 64, 128, 129]   # md_debug_set_prefill_mfma32: 16x16 kernel | 32x32 kernel: keys per tile | first V pairing
 
 
 @pytest.mark.parametrize("knob", PREFILL_VARIANTS)
 @pytest.mark.parametrize("name,H,KH,D,ns,lens,page_size", PREFILL_VARIANT_SHAPES, ids=[c[0] for c in PREFILL_VARIANT_SHAPES])
 def test_prefill_kernel_variants_vs_oracle(ops, name, H, KH, D, ns, lens, page_size, knob):
-    """Every prefill kernel the dispatcher can pick (16x16x32 shared-tile, 32x32x16 at 32 / 64 / 128 keys per tile, and
-    the two-group ping-pong form of the latter, without and with s_setprio) on shapes that walk the tile ring several
-    times, end the waves of one workgroup on different tiles and leave whole waves without rows -- same bound as
-    test_paged_attention_vs_oracle.  A variant the shape does not admit (keys per tile not dividing the page, D) falls
+    """Every prefill kernel the dispatcher can pick (16x16x32 shared-tile; 32x32x16 at 32 / 64 / 128 keys per tile and
+    with either V sub-tile pairing) on shapes that run many tiles, end the waves of one workgroup on different tiles and
+    leave whole waves without rows -- same bound as test_paged_attention_vs_oracle.  A variant the shape does not admit (keys per tile not dividing the page, D) falls
     back inside the library; the result must still be right."""
     B = len(ns)
     cache, indices, indptr, last, max_pages = make_paged(B, lens, KH, D, seed=case_seed(name), page_size=page_size,
