@@ -170,10 +170,13 @@ def test_prefill_kernel_variants_vs_oracle(ops, name, H, KH, D, ns, lens, page_s
 
 
 @pytest.mark.parametrize("page_size", [32, 64, 96])
-@pytest.mark.parametrize("D,n", [(128, 128), (64, 128), (128, 4)])
-def test_paged_attention_page_sizes(ops, page_size, D, n):
+@pytest.mark.parametrize("D,n,layout,fp8", [(128, 128, "NHD", False), (64, 128, "NHD", False), (128, 4, "NHD", False),
+                                            (128, 128, "HND", False), (64, 128, "HND", False), (128, 4, "HND", False),
+                                            (128, 128, "NHD", True), (128, 4, "HND", True)])
+def test_paged_attention_page_sizes(ops, page_size, D, n, layout, fp8):
     """The C ABI admits any page size that is a multiple of 32 (the reference runs 128): a shared K/V tile of the prefill
-    kernels must never cross a page, whatever tile size the dispatcher prefers."""
+    kernels must never cross a page, whatever tile size the dispatcher prefers -- in both page layouts and for bf16 and
+    fp8 pages."""
     H, KH, B = 8, 2, 2
     lens = [5 * page_size + 17, 3 * page_size]
     cache, indices, indptr, last, max_pages = make_paged(B, lens, KH, D, seed=page_size + D + n, page_size=page_size,
@@ -181,12 +184,24 @@ def test_paged_attention_page_sizes(ops, page_size, D, n):
     g = torch.Generator().manual_seed(4)
     q = torch.randn(B * n, H, D, generator=g).to(BF)
     qo = torch.arange(B + 1, dtype=torch.int32) * n
-    oracle = fr.batch_prefill_paged(q, cache, qo, indices, indptr, last, H, KH, D, causal=True)
-    ref64, bnd = dense_attention_f64(q, cache, qo, indices, indptr, last, H, KH, D, causal=True)
+    scales = None
+    ref_cache, dev_cache = cache, cache
+    if fp8:
+        ks = 0.02 * (1 + torch.arange(KH, dtype=torch.float32))
+        vs = 0.015 * (1 + torch.arange(KH, dtype=torch.float32))
+        P = cache.shape[0]
+        c8 = torch.empty(cache.shape, dtype=torch.float8_e4m3fn)
+        c8[:, 0] = fr.quantize_fp8(cache[:, 0].reshape(-1, KH, D), ks).view(P, page_size, KH, D)
+        c8[:, 1] = fr.quantize_fp8(cache[:, 1].reshape(-1, KH, D), vs).view(P, page_size, KH, D)
+        ref_cache, dev_cache, scales = fr.dequantize_cache_fp8(c8, ks, vs), c8, (ks.to(DEV), vs.to(DEV))
+    if layout == "HND":
+        dev_cache = dev_cache.permute(0, 1, 3, 2, 4).contiguous()
+    oracle = fr.batch_prefill_paged(q, ref_cache, qo, indices, indptr, last, H, KH, D, causal=True)
+    ref64, bnd = dense_attention_f64(q, ref_cache, qo, indices, indptr, last, H, KH, D, causal=True)
     ws = ops.AttnWorkspace(DEV)
-    out = ops.paged_attention(q.to(DEV), cache.to(DEV), qo.to(DEV), indices.to(DEV), indptr.to(DEV), last.to(DEV), n,
-                              max_pages, ws, causal=True)
-    check_attention(f"page{page_size}-d{D}-n{n}", out, oracle, ref64, bnd)
+    out = ops.paged_attention(q.to(DEV), dev_cache.to(DEV), qo.to(DEV), indices.to(DEV), indptr.to(DEV), last.to(DEV), n,
+                              max_pages, ws, causal=True, kv_scales=scales, kv_layout=layout)
+    check_attention(f"page{page_size}-d{D}-n{n}-{layout}{'-fp8' if fp8 else ''}", out, oracle, ref64, bnd)
 
 
 def test_paged_attention_ignores_garbage_beyond_length(ops):
