@@ -1,0 +1,63 @@
+"""CPU emulation (torch, no GPU) of the accuracy cost of DEFERRING the running max of the online softmax in the prefill
+attention kernel (cdna_hip_programming.md T13): exponentiate a 128-key tile against the previous tiles' max unless a
+32-row group's tile max exceeds it by more than `thr` (log2 units).  P is rounded to bf16 (floating: the relative error
+does not depend on the scale), O and l accumulate in fp32 -- the kernel's rounding points.  Prints the worst
+error / forward bound ((u_P + u_O) * sum p |v|, the gate of tests/parity_util.py) against a float64 softmax, on random
+data and with keys spiked against some queries (late large maxima).
+
+    python tools/deferred_max_emulation.py
+
+Result: thr <= 8 leaves the error where it is (0.100 -> 0.109 of the bound; spiked: 0.717 unchanged),
+thr = 11.5 reaches 1.1 on the spiked data."""
+import math
+
+import torch
+
+BF = torch.bfloat16
+
+
+def run(S=4096, n=64, D=128, KT=128, thr=None, spike=False, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    q = torch.randn(n, D, generator=g).to(BF)
+    k = torch.randn(S, D, generator=g).to(BF)
+    v = torch.randn(S, D, generator=g).to(BF)
+    if spike:
+        for i in range(0, n, 8):
+            k[600 + 37 * i] = (q[i].float() * 3).to(BF)
+    sl2 = (1 / math.sqrt(D)) * 1.4426950408889634
+    s = q.float() @ k.float().T
+    p64 = torch.softmax((q.double() @ k.double().T) / math.sqrt(D), dim=-1)
+    ref = p64 @ v.double()
+    u = 2.0 ** -9
+    bnd = (u + u) * (p64 @ v.double().abs())
+    m = torch.full((n,), -1e30)
+    l = torch.zeros(n)
+    o = torch.zeros(n, D)
+    rescales = 0
+    for t in range(0, S, KT):
+        st = s[:, t:t + KT] * sl2
+        mx = st.max(dim=1).values
+        if thr is None:
+            mnew = torch.maximum(m, mx)
+        else:
+            need = (mx > m + thr).view(-1, 32).any(dim=1).repeat_interleave(32)     # wave-uniform decision
+            mnew = torch.where(need, torch.maximum(m, mx), m)
+            rescales += int(need.view(-1, 32)[:, 0].sum())
+        alpha = torch.exp2(m - mnew)
+        m = mnew
+        l = l * alpha
+        o = o * alpha[:, None]
+        p = torch.exp2(st - m[:, None])
+        l = l + p.sum(dim=1)
+        o = o + p.to(BF).float() @ v[t:t + KT].float()
+    out = (o / l[:, None]).to(BF).double()
+    err = (out - ref).abs()
+    return float((err / bnd).max()), float(err.max()), rescales
+
+
+if __name__ == "__main__":
+    for spike in (False, True):
+        for thr in (None, 0.0, 1.0, 2.0, 4.0, 8.0, 11.5):
+            r = [run(thr=thr, spike=spike, seed=sd) for sd in range(3)]
+            print(f"spiked keys={spike} thr={thr}: max err/bound {max(x[0] for x in r):.3f}  max abs err "
+                  f"{max(x[1] for x in r):.2e}  rescales {sum(x[2] for x in r)}")
