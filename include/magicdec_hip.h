@@ -24,6 +24,8 @@
  *        len_b = (indptr[b+1]-indptr[b]-1)*page_size + last_page_len[b]
  *   - safe to capture into a hipGraph: no host reads of device memory, all
  *     lengths are read on the device at execution time.
+ *   - no process-global tuning state: the development knobs (md_debug_set_*) are declared in
+ *     magicdec_hip_dev.h and exist only in a library built with -DMD_DEV_KNOBS.
  */
 #ifndef MAGICDEC_HIP_H
 #define MAGICDEC_HIP_H
@@ -138,15 +140,6 @@ int md_rope_append(const void* q, const void* k, const void* v, int64_t q_row_st
  * ---------------------------------------------------------------------- */
 size_t md_paged_attn_workspace_bytes(int B, int n_max, int H, int KH, int D,
                                      int max_pages_per_req, int page_size);
-/* development knob (kernel tuning sweeps only): target number of workgroups of the split-KV decomposition;
- * n <= 0 restores the default (256 = one per CU). Host, not thread-safe. */
-void md_debug_set_attn_target_wgs(int n);
-void md_debug_set_prefill_mfma32(int kt); /* development: 32x32x16-MFMA prefill kernel: -1 = the measured rule (default), 0 = off
-                                           * (the 16x16x32 kernel), 32 | 64 | 128 = keys per shared tile (halved until it
-                                           * divides the page size); 129 = 128 keys, first V sub-tile pairing; 130 / 131 =
-                                           * TIMING ABLATIONS of the 128-key kernel (no softmax / no P.V: wrong results) */
-void md_debug_set_prefill_kt(int kt, int nw); /* development: keys per shared tile of the bf16 prefill kernel (32 | 64 =
-                                               * default) and waves per workgroup (4 | 8; 0 = the measured rule) */
 /* measurement (bench.py's roofline): while enabled, every decode / verify launch of md_paged_attn with n_max ==
  * n_rows query rows per request is bracketed by the kernel's OWN begin / end timestamps (hipExtLaunchKernel start /
  * stop events = what a rocprofv3 kernel trace reports; stream events around a launch also see the dispatch overhead).
@@ -248,7 +241,6 @@ int md_silu_mul(const void* a, const void* b, int64_t a_row_stride, int64_t b_ro
 #define MD_EPI_SWIGLU 1
 int md_linear_supported(int M, int N, int K, int epilogue);
 size_t md_linear_workspace_bytes(int M, int N, int K, int epilogue);
-void md_debug_set_gemm_target_blocks(int n); /* development: split-K policy (workgroups to aim for) */
 int md_linear(const void* x, int64_t ldx, const void* w, int w_dtype, int w_packed, const void* scales,
               const void* bias, void* out, int64_t ldo, int M, int N, int K, int epilogue, void* workspace,
               size_t workspace_bytes, md_stream_t stream);
@@ -264,6 +256,29 @@ int md_linear_add_rmsnorm(const void* x, int64_t ldx, const void* w, int w_dtype
                           const void* bias, const void* resid, int64_t ldr, const void* norm_weight, float eps,
                           void* h_out, void* y_out, int M, int N, int K, void* workspace, size_t workspace_bytes,
                           md_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * K8c  block-tile GEMM for the 129..256-row linears of a verify step (csrc/blockgemm.hip)
+ *     reference: the same nn.Linear calls as K8 at M = B x (gamma+1) = 256 rows -- Attention.wqkv / wo,
+ *     FeedForward.w1 / w3 / w2, Transformer.output (Engine/SnapKV/model.py:288-289,446-455,175-177)
+ * out = epilogue(x[M][K] . W[N][K]^T + bias), W bf16 in the STREAMING layout of md_linear (w_packed = 1; packed for
+ * MD_EPI_SWIGLU when that is the epilogue), M <= 256, N % 128 == 0, K % 64 == 0.  One workgroup = all rows x 128 columns
+ * x a K slice, both operands global -> LDS by DMA through a three-stage ring, v_mfma_f32_32x32x16_bf16; narrow products
+ * split K over workgroups (fp32 partial tiles in `workspace`, combined in slice order by the launch that applies the
+ * epilogue: deterministic).  Epilogues and rounding points are md_linear's (MD_EPI_NONE / MD_EPI_SWIGLU);
+ * md_linear_block_add_rmsnorm is md_linear_add_rmsnorm on this kernel ((h, y) = (resid + o, rmsnorm(h) * w));
+ * md_linear_block_rope_append is md_linear_fused(MD_FL_ROPE_APPEND) on this kernel: the combine launch adds the bias,
+ * rotates q and k (interleaved RoPE, fp32 table), writes q_rot to args->out and appends k / v to the paged cache(s) --
+ * the same results as md_linear_fused(MD_FL_NONE) -> md_rope_append.
+ * workspace: md_linear_block_workspace_bytes(M, N, K, force_split) bytes, 16-B aligned (force_split = 1 for the
+ * add_rmsnorm / rope_append forms, whose epilogue always runs in the combine launch). */
+int md_linear_block_supported(int M, int N, int K, int epilogue);
+size_t md_linear_block_workspace_bytes(int M, int N, int K, int force_split);
+int md_linear_block(const void* x, int64_t ldx, const void* w_packed, const void* bias, void* out, int64_t ldo, int M,
+                    int N, int K, int epilogue, void* workspace, size_t workspace_bytes, md_stream_t stream);
+int md_linear_block_add_rmsnorm(const void* x, int64_t ldx, const void* w_packed, const void* bias, const void* resid,
+                                int64_t ldr, const void* norm_weight, float eps, void* h_out, void* y_out, int M, int N,
+                                int K, void* workspace, size_t workspace_bytes, md_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * K8b  fused small-problem linear: a linear of a decode / verify step TOGETHER with the op that consumes its output,
@@ -321,7 +336,6 @@ typedef struct md_fused_linear_args {
     int pro_tiles;
 } md_fused_linear_args;
 int md_linear_fused_supported(int M, int N, int K, int epilogue);
-void md_debug_set_fused_nw(int nw); /* development: wavefronts (K slices) per workgroup, 8 | 16; 0 = the measured rule */
 int md_linear_fused(const md_fused_linear_args* args, md_stream_t stream);
 
 /* ------------------------------------------------------------------------

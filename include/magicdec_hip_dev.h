@@ -1,0 +1,33 @@
+/*
+ * magicdec_hip_dev.h -- DEVELOPMENT knobs of libmagicdec_hip.so (kernel tuning sweeps and same-process A/Bs only).
+ *
+ * Not part of the drop-in boundary (include/magicdec_hip.h).  These functions set process-global, non-thread-safe
+ * host state that changes which kernel variant / decomposition the next calls use; they exist only in a library built
+ * with -DMD_DEV_KNOBS (the in-tree Makefile's default, DEV=1, because tools/ and the variant-parity tests use them;
+ * `make DEV=0` builds the library without them).  No knob selects a kernel that returns wrong results.
+ */
+#ifndef MAGICDEC_HIP_DEV_H
+#define MAGICDEC_HIP_DEV_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* md_paged_attn: target number of workgroups of the split-KV decomposition; n <= 0 restores the default (256) */
+void md_debug_set_attn_target_wgs(int n);
+/* md_paged_attn, prefill: 32x32x16-MFMA kernel: -1 = the measured rule (default), 0 = off (the 16x16x32 kernel),
+ * 32 | 64 | 128 = keys per shared tile (halved until it divides the page size); 129 = 128 keys, first V sub-tile pairing */
+void md_debug_set_prefill_mfma32(int kt);
+/* md_paged_attn, prefill: keys per shared tile of the 16x16 kernel (32 | 64 = default), waves per workgroup (4 | 8; 0 = rule) */
+void md_debug_set_prefill_kt(int kt, int nw);
+/* md_linear: split-K policy (workgroups to aim for) */
+void md_debug_set_gemm_target_blocks(int n);
+/* md_linear_fused: wavefronts (K slices) per workgroup, 8 | 16; 0 = the measured rule */
+void md_debug_set_fused_nw(int nw);
+/* md_linear_block: workgroups to aim for when K is split (0 = default 256); non-temporal weight DMA (1 = default) */
+void md_debug_set_block_gemm(int target_blocks, int weights_nontemporal);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

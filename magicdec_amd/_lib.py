@@ -11,7 +11,7 @@ from ctypes import c_char_p, c_double, c_float, c_int, c_int64, c_size_t, c_void
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmagicdec_hip.so")
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 _lib = None
 _err = None
@@ -42,9 +42,6 @@ _SIGNATURES = {
     "md_rope_fill_table_host": (c_int, [P, I, I, c_double, c_double, c_double, c_double, c_double]),
     "md_rope_append": (c_int, [P, P, P, L, L, L, P, P, P, I, I, I, I, I, P, I, P, P, P, P, P, P, P, P, I, I, P, P, P]),
     "md_paged_attn_workspace_bytes": (c_size_t, [I, I, I, I, I, I, I]),
-    "md_debug_set_attn_target_wgs": (None, [I]),
-    "md_debug_set_prefill_kt": (None, [I, I]),
-    "md_debug_set_prefill_mfma32": (None, [I]),
     "md_debug_attn_timing": (None, [I, I]),
     "md_debug_attn_timing_read": (c_int, [P, I]),
     "md_paged_attn": (c_int, [P, L, P, P, P, P, P, P, I, I, I, I, I, I, I, c_float, I, I, P, P, P, c_size_t, P]),
@@ -64,12 +61,14 @@ _SIGNATURES = {
     "md_streaming_rotate": (c_int, [P, P, I, I, I, I, I, I, P, I, P]),
     "md_linear_supported": (c_int, [I, I, I, I]),
     "md_linear_workspace_bytes": (c_size_t, [I, I, I, I]),
-    "md_debug_set_gemm_target_blocks": (None, [I]),
     "md_linear": (c_int, [P, L, P, I, I, P, P, P, L, I, I, I, I, P, c_size_t, P]),
     "md_linear_add_rmsnorm_supported": (c_int, [I, I, I]),
     "md_linear_add_rmsnorm": (c_int, [P, L, P, I, I, P, P, P, L, P, c_float, P, P, I, I, I, P, c_size_t, P]),
+    "md_linear_block_supported": (c_int, [I, I, I, I]),
+    "md_linear_block_workspace_bytes": (c_size_t, [I, I, I, I]),
+    "md_linear_block": (c_int, [P, L, P, P, P, L, I, I, I, I, P, c_size_t, P]),
+    "md_linear_block_add_rmsnorm": (c_int, [P, L, P, P, P, L, P, c_float, P, P, I, I, I, P, c_size_t, P]),
     "md_linear_fused_supported": (c_int, [I, I, I, I]),
-    "md_debug_set_fused_nw": (None, [I]),
     "md_linear_fused": (c_int, [ctypes.POINTER(FusedLinearArgs), P]),
     "md_rmsnorm": (c_int, [P, P, P, I, I, c_float, P]),
     "md_add_rmsnorm": (c_int, [P, P, P, P, P, I, I, c_float, P]),
@@ -80,6 +79,18 @@ _SIGNATURES = {
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+# include/magicdec_hip_dev.h: tuning knobs, present only in a -DMD_DEV_KNOBS build (bound when the library has them;
+# nothing under magicdec_amd/ needs them)
+_DEV_SIGNATURES = {
+    "md_debug_set_attn_target_wgs": (None, [I]),
+    "md_debug_set_prefill_kt": (None, [I, I]),
+    "md_debug_set_prefill_mfma32": (None, [I]),
+    "md_debug_set_gemm_target_blocks": (None, [I]),
+    "md_debug_set_fused_nw": (None, [I]),
+    "md_debug_set_block_gemm": (None, [I, I]),
+}
+DEV_SYMBOLS = tuple(_DEV_SIGNATURES)
 
 
 class MagicDecHipError(RuntimeError):
@@ -104,13 +115,18 @@ def load():
             fn = getattr(lib, name)
             fn.restype = res
             fn.argtypes = args
+        for name, (res, args) in _DEV_SIGNATURES.items():
+            fn = getattr(lib, name, None)
+            if fn is not None:
+                fn.restype = res
+                fn.argtypes = args
         if lib.md_abi_version() != ABI_VERSION:
             raise OSError(f"ABI version {lib.md_abi_version()} != expected {ABI_VERSION}")
     except (OSError, AttributeError) as e:  # missing symbol / loader failure
         _err = f"cannot load {LIB_PATH}: {e}"
         raise MagicDecHipError(_err) from e
     v = os.environ.get("MAGICDEC_PREFILL_MFMA32")          # development A/B switch of the prefill attention kernel
-    if v is not None:
+    if v is not None and hasattr(lib, "md_debug_set_prefill_mfma32"):
         lib.md_debug_set_prefill_mfma32(int(v))
     _lib = lib
     return _lib

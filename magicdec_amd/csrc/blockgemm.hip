@@ -1,0 +1,426 @@
+// Block-tile GEMM for the 129..256-row linears of a verify step (gfx950):  out = epilogue(x[M][K] . W[N][K]^T + bias)
+//
+// replaces: the nn.Linear calls of the (gamma+1)-token verify pass at B x (gamma+1) = 256 rows
+//           (Engine/SnapKV/model.py:288-289 wqkv / wo, :446-455 w1 / w3 / w2, :175-177 output), which rounds 1-3 left
+//           to hipBLASLt -- 5.1 ms of a 31 ms iteration at 20-43 % of HBM / <= 35 % of the MFMA peak
+//           (profiles/r03_bench_cfg3_iter_breakdown.csv).
+//
+// Why a third GEMM kernel.  At M = 256 the products sit on the MFMA / HBM ridge (256 flop per weight byte): md_linear
+// (gemm.hip: one wave = 32 columns x all rows, W straight into registers, x re-read from LDS per 32 columns) pays
+// 1 + 1/8 LDS fragment reads per MFMA and is LDS-bound there; md_linear_fused (tilegemm.hip: 32 x 32 tiles) re-reads
+// the weights 8 times through L2.  This kernel is the classic block-tile form, built around what bounds it on CDNA4
+// -- LDS bytes per flop and the per-CU load path:
+//   * one workgroup = 256 rows (all of M) x 128 columns x a K range; 4 wavefronts as 2 (M) x 2 (N), ONE per SIMD, each
+//     owning a 128 x 64 output tile = 4 x 2 accumulators of v_mfma_f32_32x32x16_bf16 (128 accumulator registers):
+//     6 fragment reads per 8 MFMAs, half of md_linear's LDS traffic per flop;
+//   * both operands go global -> LDS by DMA (buffer_load ... lds, 16 B per lane, no VGPR round trip), three 48-KB
+//     stages of 64 k (144 of the 160 KB), the loads of stage s+2 issued right after the one barrier of stage s and
+//     retired with a COUNTED vmcnt two stages later -- loads stay in flight across the barrier;
+//   * W is read in the streaming layout of md_linear ([N/32][K/16][64 lanes][8]: the MFMA B fragment of 32 columns x
+//     16 k is one contiguous KiB): one DMA instruction = one fragment, the LDS image is lane-linear, fragment reads are
+//     conflict-free ds_read_b128, and no second packed copy of the weights is needed;
+//   * x (row-major, L2-resident, re-read by every column tile) is fetched in full 128-B lines; the LDS image is
+//     [row][8 chunks of 16 B] with chunk' = chunk ^ ((row >> 1) & 7): the DMA writes LDS linearly, so the permutation
+//     is applied to the per-lane SOURCE address and again on the fragment read -- every 16-lane group of a
+//     ds_read_b128 then covers all 64 banks once;
+//   * narrow products (N = 4096..6144: 32-48 column tiles) split K over workgroups so that ~240-256 of them exist;
+//     fp32 partial tiles go to the workspace and the combine launch applies the epilogue in a fixed slice order
+//     (deterministic) -- the SAME combine kernels as md_linear (bias / SwiGLU / residual add + RMSNorm), plus one for the
+//     qkv projection (bias + RoPE + paged append);
+//   * the un-split product (w1|w3: 224 tiles) finishes in the kernel: accumulators -> LDS (fp32, the ring is free by
+//     then) -> 16-byte row-contiguous stores, SwiGLU with the reference's rounding points.
+#include "md_common.h"
+
+// gemm.hip / elementwise.hip: the split-K combine launches shared with md_linear
+int md_internal_launch_skinny_reduce(const float* partial, int S, int M, int N, int epilogue, const void* bias, void* out,
+                                     int64_t ldo, hipStream_t st);
+int md_internal_launch_reduce_add_rmsnorm(const float* partial, int S, int M, int N, const void* bias, const void* scales,
+                                          const void* x, int64_t ldx, const void* w, void* h_out, void* y, float eps,
+                                          hipStream_t st);
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __attribute__((address_space(3))) void lds_ptr_t;
+
+constexpr int BM = 256, BN = 128, BK = 64;
+constexpr int kStageA = BM * BK * 2;            // 32 KiB: [256 rows][8 chunks x 16 B], chunk-swizzled
+constexpr int kStageB = BN * BK * 2;            // 16 KiB: [4 column tiles][4 k-steps][64 lanes x 16 B]
+constexpr int kStage = kStageA + kStageB;       // 48 KiB
+constexpr int kStages = 3;
+constexpr int kLds = kStage * kStages;          // 144 KiB
+constexpr int kEpiPitch = BN + 4;               // fp32 epilogue tile [256][132]: 135 168 B inside the ring
+static_assert(BM * kEpiPitch * 4 <= kLds, "epilogue tile must fit the ring");
+
+enum { BE_NONE = 0, BE_SWIGLU = 1 };
+
+struct BlockParams {
+    const bf16_t* x;
+    const bf16_t* w;        // streaming layout [N/32][K/16][64][8]
+    const bf16_t* bias;     // [N] or null (un-split BE_NONE only; split products get it in the combine launch)
+    bf16_t* out;            // un-split: [M][N] (BE_NONE) or [M][N/2] (BE_SWIGLU), row stride ldo
+    float* partial;         // split: [S][M][N] fp32, GEMM-column order ([w1; w3] for BE_SWIGLU)
+    int64_t ldx, ldo;
+    int M, N, K, S, nsteps;     // nsteps = K / 64
+    unsigned int x_bytes;       // bytes of x a row index may address: rows >= M read zeros through the buffer bound
+};
+
+__device__ __forceinline__ float silu_bf16(float h1) {
+    return bf16_to_f32(f32_to_bf16(h1 / (1.0f + expf(-h1))));     // same expression as md_silu_mul / md_linear
+}
+
+// LLVM SchedGroupMask bits for __builtin_amdgcn_sched_group_barrier
+#define SG_MFMA 0x8
+#define SG_VMEM 0x10
+#define SG_DSR 0x100
+
+// WNT: weights with the non-temporal cache policy (the tile owns all 256 rows: a weight byte is read by one workgroup)
+template <int EPI, bool SPLIT, bool WNT>
+__global__ __launch_bounds__(256, 1) void block_gemm_kernel(const BlockParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];     // the ONLY LDS object (cdna guide 5.4(a))
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int j = lane & 31, kh = lane >> 5;
+    // block id -> (column tile, K slice); with S = 8 a slice (= the x columns it reads) stays on one XCD's L2
+    const int slice = blockIdx.x % p.S, tn = blockIdx.x / p.S;
+    const int s0 = (int)((int64_t)slice * p.nsteps / p.S), s1 = (int)((int64_t)(slice + 1) * p.nsteps / p.S);
+    const int n = s1 - s0;
+
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.x), 0, p.x_bytes, 0x00020000);
+    const int64_t wtile = (int64_t)(p.K >> 4) * 512;                       // elements of one 32-column tile
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<bf16_t*>(p.w + (int64_t)tn * 4 * wtile), 0, (unsigned int)(4 * wtile * 2), 0x00020000);
+
+    // ---- DMA addresses.  x: piece q of this wave covers rows (wave*8+q)*8 .. +7, 8 lanes per 128-B line; rows >= M lie
+    // beyond the descriptor's bound and read as zeros
+    unsigned int avo[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int r = (wave * 8 + q) * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ ((r >> 1) & 7);
+        avo[q] = (unsigned int)r * (unsigned int)p.ldx * 2u + (unsigned int)c * 16u;
+    }
+    // W: this wave stages column tile `wave` (4 k-steps = 4 KiB contiguous per stage)
+    const unsigned int bvo = (unsigned int)wave * (unsigned int)(wtile * 2) + (unsigned int)lane * 16u;
+
+    // One stage = 12 DMA pieces per wave (8 of x, 4 of W), issued in four groups of three so that they sit in the MFMA
+    // shadows of four k-steps.  A stage past the end of the slice is issued all the same with its offsets pushed beyond
+    // the descriptors' bounds (bit 31): zero fill, no memory traffic -- the loop stays branch-free and every vmcnt is
+    // the same count.  (The instruction's immediate offset would move the LDS address too: not used.)
+    auto issue_group = [&](int it, int buf_off, int g) {
+        const unsigned int oob = it < n ? 0u : 0x80000000u;
+        const int so_a = (s0 + it) * (BK * 2);            // byte offset of the stage's k range in a row of x
+        const int so_b = (s0 + it) * 4096 + g * 1024;     // ... in a column tile of W (4 fragments per stage)
+#pragma unroll
+        for (int q = 2 * g; q < 2 * g + 2; ++q)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr_t*)(lds + buf_off + (wave * 8 + q) * 1024), 16,
+                                                     avo[q] | oob, so_a, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr_t*)(lds + buf_off + kStageA + (wave * 4 + g) * 1024), 16,
+                                                 bvo | oob, so_b, 0, WNT ? 2 : 0);
+    };
+
+    // ---- fragment read addresses
+    const int f = (j >> 1) & 7;
+    const unsigned char* a_lane = lds + (wm * 128 + j) * 128;
+    int axo[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) axo[ks] = ((2 * ks + kh) ^ f) * 16;
+    const unsigned char* b_lane = lds + kStageA + wn * 8192 + lane * 16;
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+
+    bf16x8 fa[2][4], fb[2][2];                             // fragment double buffer (compile-time indices only)
+    auto read_frags = [&](int set, int buf_off, int ks) {
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+            fa[set][mt] = *reinterpret_cast<const bf16x8*>(a_lane + buf_off + axo[ks] + mt * 4096);
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+            fb[set][nt] = *reinterpret_cast<const bf16x8*>(b_lane + buf_off + (nt * 4 + ks) * 1024);
+    };
+    auto mfmas = [&](int set) {
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[set][mt], fb[set][nt], acc[mt][nt], 0, 0, 0);
+    };
+    // the issue order of one k-step: 8 MFMAs (fragments read one k-step ago) with the 6 fragment reads of the NEXT k-step
+    // and 3 DMA pieces in their shadows (one wave per SIMD: nothing else hides an LDS round trip or a DMA issue)
+    auto interleave = [&]() {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            __builtin_amdgcn_sched_group_barrier(SG_MFMA, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(SG_DSR, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(SG_MFMA, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(SG_DSR, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(SG_VMEM, 1, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(SG_MFMA, 2, 0);
+    };
+
+    // iteration `it` computes stage it from buffer CUR; NXT holds stage it+1 (landing), PRV (read last iteration) takes
+    // groups 1..3 of stage it+2 during k-steps 0..2; in k-step 3 every wave has issued its last read of CUR: wait for
+    // them, wait for MY pieces of stage it+1 (counted: the 12 of stage it+2 stay in flight), meet the other waves, then
+    // CUR is free for group 0 of stage it+3 and NXT is readable
+    auto iteration = [&](int it, int cur, int nxt, int prv) {
+        issue_group(it + 2, prv, 1);
+        read_frags(1, cur, 1);
+        mfmas(0);
+        interleave();
+        __builtin_amdgcn_sched_barrier(0);
+        issue_group(it + 2, prv, 2);
+        read_frags(0, cur, 2);
+        mfmas(1);
+        interleave();
+        __builtin_amdgcn_sched_barrier(0);
+        issue_group(it + 2, prv, 3);
+        read_frags(1, cur, 3);
+        mfmas(0);
+        interleave();
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        issue_group(it + 3, cur, 0);
+        read_frags(0, nxt, 0);
+        mfmas(1);
+        interleave();
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    issue_group(0, 0, 0);
+    issue_group(0, 0, 1);
+    issue_group(0, 0, 2);
+    issue_group(0, 0, 3);
+    issue_group(1, kStage, 0);
+    issue_group(1, kStage, 1);
+    issue_group(1, kStage, 2);
+    issue_group(1, kStage, 3);
+    issue_group(2, 2 * kStage, 0);
+    asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    read_frags(0, 0, 0);
+    for (int it = 0;;) {
+        iteration(it, 0, kStage, 2 * kStage);
+        if (++it >= n) break;
+        iteration(it, kStage, 2 * kStage, 0);
+        if (++it >= n) break;
+        iteration(it, 2 * kStage, 0, kStage);
+        if (++it >= n) break;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // zero-fill pieces of the stages past the end
+
+    // ---- epilogue: accumulators -> fp32 tile in LDS -> row-contiguous 16-byte stores
+    // acc[mt][nt][r] = D[row wm*128 + mt*32 + (r&3) + 8*(r>>2) + 4*kh][column wn*64 + nt*32 + j]
+    __syncthreads();
+    float* tile = reinterpret_cast<float*>(lds);
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = wm * 128 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                tile[row * kEpiPitch + wn * 64 + nt * 32 + j] = acc[mt][nt][r];
+            }
+    __syncthreads();
+
+    if constexpr (SPLIT) {
+        float* pp = p.partial + (int64_t)slice * p.M * p.N;
+#pragma unroll 4
+        for (int q = 0; q < 32; ++q) {
+            const int c = tid + 256 * q;
+            const int row = c >> 5, c4 = (c & 31) * 4;                        // 4 consecutive tile columns
+            if (row >= p.M) continue;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(tile + row * kEpiPitch + c4);
+            int col;
+            if constexpr (EPI == BE_SWIGLU) {                                 // packed tile: 16 rows of w1, 16 of w3
+                const int t = tn * 4 + (c4 >> 5), jj = c4 & 31;
+                col = jj < 16 ? t * 16 + jj : (p.N >> 1) + t * 16 + jj - 16;
+            } else {
+                col = tn * BN + c4;
+            }
+            *reinterpret_cast<f32x4*>(pp + (int64_t)row * p.N + col) = v;
+        }
+    } else if constexpr (EPI == BE_SWIGLU) {
+#pragma unroll 4
+        for (int q = 0; q < 8; ++q) {
+            const int c = tid + 256 * q;
+            const int row = c >> 3, t = (c >> 1) & 3, i8 = (c & 1) * 8;       // 8 outputs of packed tile t
+            if (row >= p.M) continue;
+            const float* src = tile + row * kEpiPitch + t * 32 + i8;
+            const f32x4 h1a = *reinterpret_cast<const f32x4*>(src), h1b = *reinterpret_cast<const f32x4*>(src + 4);
+            const f32x4 h3a = *reinterpret_cast<const f32x4*>(src + 16), h3b = *reinterpret_cast<const f32x4*>(src + 20);
+            bf16x8 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                o[e] = f32_to_bf16(silu_bf16(bf16_to_f32(f32_to_bf16(h1a[e]))) * bf16_to_f32(f32_to_bf16(h3a[e])));
+                o[4 + e] = f32_to_bf16(silu_bf16(bf16_to_f32(f32_to_bf16(h1b[e]))) * bf16_to_f32(f32_to_bf16(h3b[e])));
+            }
+            *reinterpret_cast<bf16x8*>(p.out + (int64_t)row * p.ldo + (tn * 4 + t) * 16 + i8) = o;
+        }
+    } else {
+        const int c8 = (tid & 15) * 8;                                        // the thread's 8 columns: the same for every q
+        f32x8 bv = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (p.bias) bv = __builtin_convertvector(*reinterpret_cast<const bf16x8*>(p.bias + tn * BN + c8), f32x8);
+#pragma unroll 4
+        for (int q = 0; q < 16; ++q) {
+            const int row = (tid + 256 * q) >> 4;
+            if (row >= p.M) continue;
+            const float* src = tile + row * kEpiPitch + c8;
+            const f32x4 va = *reinterpret_cast<const f32x4*>(src), vb = *reinterpret_cast<const f32x4*>(src + 4);
+            bf16x8 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                o[e] = f32_to_bf16(va[e] + bv[e]);
+                o[4 + e] = f32_to_bf16(vb[e] + bv[4 + e]);
+            }
+            *reinterpret_cast<bf16x8*>(p.out + (int64_t)row * p.ldo + tn * BN + c8) = o;
+        }
+    }
+}
+
+int g_target_blocks = 256;     // K is split so that about this many workgroups exist (md_debug_set_block_gemm)
+int g_wnt = 1;                 // non-temporal weight DMA
+
+int pick_splits(int n_tiles, int nsteps) {
+    if (n_tiles >= 160) return 1;                                   // >= 62 % of the CUs busy without partial sums
+    int s = g_target_blocks / n_tiles;
+    if (s < 1) s = 1;
+    if (s > 16) s = 16;
+    if (s > nsteps / 4) s = nsteps / 4 > 0 ? nsteps / 4 : 1;        // at least 4 stages (256 k) per workgroup
+    return s;
+}
+
+template <int EPI, bool SPLIT, bool WNT>
+int launch_cfg(const BlockParams& p, int grid, hipStream_t st) {
+    auto k = block_gemm_kernel<EPI, SPLIT, WNT>;
+    static MdPerDeviceOnce once;
+    if (once.first()) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, kLds) !=
+            hipSuccess) {
+            once.undo();
+            md_set_error("md_linear_block: hipFuncSetAttribute(%d B LDS) failed", kLds);
+            return MD_ERR_LAUNCH;
+        }
+    }
+    hipLaunchKernelGGL(k, dim3(grid), dim3(256), kLds, st, p);
+    return MD_OK;
+}
+
+template <int EPI>
+int launch_epi(const BlockParams& p, int grid, hipStream_t st) {
+    if (p.S > 1 || p.partial)
+        return g_wnt ? launch_cfg<EPI, true, true>(p, grid, st) : launch_cfg<EPI, true, false>(p, grid, st);
+    return g_wnt ? launch_cfg<EPI, false, true>(p, grid, st) : launch_cfg<EPI, false, false>(p, grid, st);
+}
+
+bool shape_ok(int M, int N, int K) { return M >= 1 && M <= BM && N >= BN && N % BN == 0 && K >= BK && K % BK == 0; }
+
+// fills the GEMM part of the parameters; `force_split`: partial sums even with one K slice (the combine launch applies an
+// epilogue the kernel does not have)
+int setup(BlockParams& p, const void* x, int64_t ldx, const void* w, int M, int N, int K, bool force_split,
+          void* workspace, size_t workspace_bytes, const char* who) {
+    MD_CHECK_ARG(x && w, "%s: null pointer argument", who);
+    MD_CHECK_ARG(shape_ok(M, N, K), "%s: unsupported shape M=%d N=%d K=%d (need 1 <= M <= 256, N %% 128 == 0, K %% 64 == 0)",
+                 who, M, N, K);
+    MD_CHECK_ARG((((uintptr_t)x | (uintptr_t)w) & 15) == 0 && ldx % 8 == 0 && ldx >= K,
+                 "%s: x / w must be 16-byte aligned, ldx %% 8 == 0", who);
+    const int64_t xb = ((int64_t)(M - 1) * ldx + K) * 2;
+    MD_CHECK_ARG(xb < ((int64_t)1 << 31) && (int64_t)255 * ldx * 2 + K * 2 < ((int64_t)1 << 31) && (int64_t)K * 256 < ((int64_t)1 << 31),
+                 "%s: x spans more than 2 GiB (M=%d, ldx=%lld): pass a compact activation tensor", who, M, (long long)ldx);
+    p.x = (const bf16_t*)x;
+    p.w = (const bf16_t*)w;
+    p.bias = nullptr;
+    p.out = nullptr;
+    p.ldx = ldx;
+    p.ldo = 0;
+    p.M = M;
+    p.N = N;
+    p.K = K;
+    p.nsteps = K / BK;
+    p.S = pick_splits(N / BN, p.nsteps);
+    p.x_bytes = (unsigned int)xb;
+    p.partial = nullptr;
+    if (p.S > 1 || force_split) {
+        const size_t need = (size_t)p.S * M * N * 4;
+        MD_CHECK_ARG(workspace && workspace_bytes >= need && (((uintptr_t)workspace) & 15) == 0,
+                     "%s: workspace too small (need %zu bytes) or not 16-byte aligned", who, need);
+        p.partial = (float*)workspace;
+    }
+    return MD_OK;
+}
+
+}  // namespace
+
+#ifdef MD_DEV_KNOBS
+extern "C" void md_debug_set_block_gemm(int target_blocks, int weights_nontemporal) {
+    g_target_blocks = target_blocks > 0 ? target_blocks : 256;
+    g_wnt = weights_nontemporal ? 1 : 0;
+}
+#endif
+
+extern "C" int md_linear_block_supported(int M, int N, int K, int epilogue) {
+    if (!shape_ok(M, N, K)) return 0;
+    return (epilogue == BE_NONE || epilogue == BE_SWIGLU) ? 1 : 0;
+}
+
+extern "C" size_t md_linear_block_workspace_bytes(int M, int N, int K, int force_split) {
+    if (!shape_ok(M, N, K)) return 0;
+    const int S = pick_splits(N / BN, K / BK);
+    return (S > 1 || force_split) ? (size_t)S * M * N * 4 : 0;
+}
+
+extern "C" int md_linear_block(const void* x, int64_t ldx, const void* w_packed, const void* bias, void* out, int64_t ldo,
+                               int M, int N, int K, int epilogue, void* workspace, size_t workspace_bytes,
+                               md_stream_t stream) {
+    MD_CHECK_ARG(out && (((uintptr_t)out) & 15) == 0 && ldo % 8 == 0, "md_linear_block: out must be 16-byte aligned, ldo %% 8 == 0");
+    MD_CHECK_ARG(epilogue == BE_NONE || epilogue == BE_SWIGLU, "md_linear_block: unknown epilogue %d", epilogue);
+    MD_CHECK_ARG(!(epilogue == BE_SWIGLU && bias), "md_linear_block: the SwiGLU epilogue takes no bias");
+    BlockParams p;
+    int rc = setup(p, x, ldx, w_packed, M, N, K, false, workspace, workspace_bytes, "md_linear_block");
+    if (rc != MD_OK) return rc;
+    p.out = (bf16_t*)out;
+    p.ldo = ldo;
+    p.bias = p.S > 1 ? nullptr : (const bf16_t*)bias;
+    hipStream_t st = (hipStream_t)stream;
+    const int grid = (N / BN) * p.S;
+    rc = epilogue == BE_SWIGLU ? launch_epi<BE_SWIGLU>(p, grid, st) : launch_epi<BE_NONE>(p, grid, st);
+    if (rc != MD_OK) return rc;
+    if (p.S > 1) {
+        rc = md_internal_launch_skinny_reduce(p.partial, p.S, M, N, epilogue, bias, out, ldo, st);
+        if (rc != MD_OK) return rc;
+    }
+    MD_CHECK_LAUNCH("md_linear_block");
+    return MD_OK;
+}
+
+extern "C" int md_linear_block_add_rmsnorm(const void* x, int64_t ldx, const void* w_packed, const void* bias,
+                                           const void* resid, int64_t ldr, const void* norm_weight, float eps, void* h_out,
+                                           void* y_out, int M, int N, int K, void* workspace, size_t workspace_bytes,
+                                           md_stream_t stream) {
+    MD_CHECK_ARG(resid && norm_weight && h_out && y_out, "md_linear_block_add_rmsnorm: null pointer argument");
+    MD_CHECK_ARG((((uintptr_t)resid | (uintptr_t)norm_weight | (uintptr_t)h_out | (uintptr_t)y_out) & 15) == 0 &&
+                     ldr % 8 == 0 && N % 8 == 0 && N <= 8192,
+                 "md_linear_block_add_rmsnorm: pointers must be 16-byte aligned, ldr %% 8 == 0, N %% 8 == 0, N <= 8192");
+    BlockParams p;
+    int rc = setup(p, x, ldx, w_packed, M, N, K, true, workspace, workspace_bytes, "md_linear_block_add_rmsnorm");
+    if (rc != MD_OK) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    rc = launch_epi<BE_NONE>(p, (N / BN) * p.S, st);
+    if (rc != MD_OK) return rc;
+    rc = md_internal_launch_reduce_add_rmsnorm(p.partial, p.S, M, N, bias, nullptr, resid, ldr, norm_weight, h_out, y_out,
+                                               eps, st);
+    if (rc != MD_OK) return rc;
+    MD_CHECK_LAUNCH("md_linear_block_add_rmsnorm");
+    return MD_OK;
+}

@@ -330,7 +330,30 @@ int launch_mt(const GemmParams& p, int n_blocks, hipStream_t st) {
 
 }  // namespace
 
+// blockgemm.hip: the fixed-order combine of fp32 partial slabs [S][M][N] (+ bias / SwiGLU) for md_linear_block
+int md_internal_launch_skinny_reduce(const float* partial, int S, int M, int N, int epilogue, const void* bias, void* out,
+                                     int64_t ldo, hipStream_t st) {
+    GemmParams p = {};
+    p.partial = const_cast<float*>(partial);
+    p.S = S;
+    p.M = M;
+    p.N = N;
+    p.Nout = epilogue == EPI_SWIGLU ? N / 2 : N;
+    p.bias = (const bf16_t*)bias;
+    p.out = (bf16_t*)out;
+    p.ldo = ldo;
+    const int64_t threads = (int64_t)M * (p.Nout / 4);
+    const dim3 grid((unsigned)((threads + 255) / 256));
+    if (epilogue == EPI_SWIGLU)
+        hipLaunchKernelGGL((skinny_reduce_kernel<EPI_SWIGLU, false>), grid, dim3(256), 0, st, p);
+    else
+        hipLaunchKernelGGL((skinny_reduce_kernel<EPI_NONE, false>), grid, dim3(256), 0, st, p);
+    return MD_OK;
+}
+
+#ifdef MD_DEV_KNOBS
 extern "C" void md_debug_set_gemm_target_blocks(int n) { g_target_blocks = n > 0 ? n : 256; }
+#endif
 
 extern "C" size_t md_linear_workspace_bytes(int M, int N, int K, int epilogue) {
     if (M <= 0 || N <= 0 || K <= 0 || K % kSlabK) return 0;

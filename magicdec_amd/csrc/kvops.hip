@@ -238,10 +238,17 @@ bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
 }  // namespace
 
-// device address of the dropped-row counter, for kernels of other translation units (csrc/tilegemm.hip)
+// device address of the dropped-row counter, for kernels of other translation units (csrc/tilegemm.hip, blockgemm.hip).
+// Resolved once per device: the callers sit on the launch-bound path (one call per layer per step, also inside graph
+// capture), where a runtime call per launch is avoidable host latency.
 unsigned int* md_page_overflow_counter_device() {
+    static unsigned int* cached[MD_MAX_DEVICES] = {};
+    int d = 0;
+    const bool slot = hipGetDevice(&d) == hipSuccess && d >= 0 && d < MD_MAX_DEVICES;
+    if (slot && cached[d]) return cached[d];
     void* p = nullptr;
     if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_md_page_overflow)) != hipSuccess) return nullptr;
+    if (slot) cached[d] = (unsigned int*)p;
     return (unsigned int*)p;
 }
 

@@ -6,6 +6,7 @@
 #include <stdarg.h>
 
 #include "../../include/magicdec_hip.h"
+#include "../../include/magicdec_hip_dev.h"
 
 typedef __bf16 bf16_t;
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));

@@ -394,7 +394,9 @@ bool aligned16(const void* q) { return ((uintptr_t)q & 15) == 0; }
 
 }  // namespace
 
+#ifdef MD_DEV_KNOBS
 extern "C" void md_debug_set_fused_nw(int nw) { g_force_nw = (nw == 8 || nw == 16) ? nw : 0; }
+#endif
 
 extern "C" int md_linear_fused_supported(int M, int N, int K, int epilogue) {
     if (M < 1 || M > 256 || K < 128 || K % 128 || N < 32 || N % 32) return 0;

@@ -387,6 +387,69 @@ def linear_add_rmsnorm(x, weight, resid, norm_weight, eps, bias=None, scales=Non
     return h, y
 
 
+# ----------------------------------------------------------------------------- K8c
+def linear_block_supported(M, N, K, swiglu=False):
+    """True when md_linear_block (csrc/blockgemm.hip: the block-tile GEMM of the 129..256-row verify linears) takes
+    this shape (M <= 256, N % 128 == 0, K % 64 == 0)."""
+    return bool(_lib.load().md_linear_block_supported(int(M), int(N), int(K), EPI_SWIGLU if swiglu else EPI_NONE))
+
+
+def _block_ws(lib, M, N, K, force, workspace):
+    nbytes = lib.md_linear_block_workspace_bytes(M, N, K, 1 if force else 0)
+    if not nbytes:
+        return None, 0
+    if workspace is None:
+        raise ValueError("linear_block: this shape splits K and needs a workspace")
+    ws = workspace.get(nbytes + 256)
+    return ctypes.c_void_p(ws.data_ptr() + (-ws.data_ptr()) % 256), nbytes
+
+
+def _block_args(x, weight, swiglu):
+    if not isinstance(weight, PackedWeight) or weight.dtype != torch.bfloat16:
+        raise TypeError("linear_block streams a bf16 PackedWeight")
+    _gpu(x, weight.data)
+    if x.dim() != 2 or x.stride(1) != 1 or x.dtype != torch.bfloat16:
+        raise ValueError("linear_block expects x [M, K] bf16 with unit inner stride")
+    if weight.K != x.shape[1]:
+        raise ValueError(f"linear_block: x has K={x.shape[1]}, weight has K={weight.K}")
+    if weight.swiglu != swiglu:
+        raise ValueError("PackedWeight was packed for a different epilogue")
+    return x.shape[0], weight.N, weight.K
+
+
+def linear_block(x, weight: "PackedWeight", bias=None, swiglu=False, workspace: "AttnWorkspace" = None, out=None):
+    """F.linear(x, W, bias) (or silu(x.w1^T) * (x.w3^T) for swiglu=True, weight = [w1; w3]) for 129..256 rows on the
+    block-tile GEMM md_linear_block; same contract and rounding points as linear()."""
+    M, N, K = _block_args(x, weight, swiglu)
+    _gpu(bias)
+    n_out = N // 2 if swiglu else N
+    if out is None:
+        out = torch.empty((M, n_out), dtype=x.dtype, device=x.device)
+    lib = _lib.load()
+    wsp, nbytes = _block_ws(lib, M, N, K, False, workspace)
+    check(lib.md_linear_block(_p(x), x.stride(0), _p(weight.data), _p(bias), _p(out), out.stride(0), M, N, K,
+                              EPI_SWIGLU if swiglu else EPI_NONE, wsp, nbytes, _stream()), "md_linear_block")
+    return out
+
+
+def linear_block_add_rmsnorm(x, weight: "PackedWeight", resid, norm_weight, eps, bias=None,
+                             workspace: "AttnWorkspace" = None):
+    """(h, y) = (resid + F.linear(x, W, bias), rmsnorm(h) * norm_weight): md_linear_block with the residual add and the
+    norm in its combine launch -- the combine kernel of linear_add_rmsnorm (same rounding points)."""
+    M, N, K = _block_args(x, weight, False)
+    _gpu(bias, resid, norm_weight)
+    if resid.dim() != 2 or resid.stride(1) != 1 or resid.shape != (M, N) or norm_weight.numel() != N:
+        raise ValueError("linear_block_add_rmsnorm: resid must be [M, N] with unit inner stride, norm_weight [N]")
+    lib = _lib.load()
+    wsp, nbytes = _block_ws(lib, M, N, K, True, workspace)
+    h = torch.empty((M, N), dtype=x.dtype, device=x.device)
+    y = torch.empty((M, N), dtype=x.dtype, device=x.device)
+    check(lib.md_linear_block_add_rmsnorm(_p(x), x.stride(0), _p(weight.data), _p(bias), _p(resid), resid.stride(0),
+                                          _p(norm_weight), float(eps), _p(h), _p(y), M, N, K, wsp, nbytes, _stream()),
+          "md_linear_block_add_rmsnorm")
+    return h, y
+
+
 # ----------------------------------------------------------------------------- K8b
 FL_NONE, FL_SWIGLU, FL_RESID, FL_ROPE_APPEND = 0, 1, 2, 3
 

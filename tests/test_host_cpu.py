@@ -25,6 +25,10 @@ def test_library_exports_every_declared_symbol():
     declared = set(re.findall(r"\b(md_[a-z0-9_]+)\s*\(", header))
     from magicdec_amd import _lib
     assert declared == set(_lib.EXPORTED_SYMBOLS), declared ^ set(_lib.EXPORTED_SYMBOLS)
+    # the tuning knobs live in their own header and only in a -DMD_DEV_KNOBS build (the in-tree default)
+    assert not any(n.startswith("md_debug_set") for n in declared)
+    dev = set(re.findall(r"\b(md_[a-z0-9_]+)\s*\(", (ROOT / "include" / "magicdec_hip_dev.h").read_text()))
+    assert dev == set(_lib.DEV_SYMBOLS) and all(n.startswith("md_debug_set") for n in dev)
     lib = _lib.load()
     for name in declared:
         assert hasattr(lib, name), name
@@ -91,13 +95,15 @@ def test_every_entry_point_rejects_null_arguments():
     import ctypes
     from magicdec_amd import _lib
     lib = _lib.load()
-    skip = {"md_abi_version", "md_last_error_string", "md_debug_set_attn_target_wgs", "md_ar_destroy",
-            "md_debug_set_gemm_target_blocks", "md_debug_attn_timing", "md_debug_attn_timing_read", "md_debug_set_prefill_kt", "md_debug_set_fused_nw", "md_debug_set_prefill_mfma32"}
+    skip = {"md_abi_version", "md_last_error_string", "md_ar_destroy", "md_debug_attn_timing", "md_debug_attn_timing_read"}
     assert lib.md_linear_supported(0, 0, 0, 0) == 0 and lib.md_linear_supported(64, 128, 256, 0) == 1
     assert lib.md_linear_fused_supported(0, 0, 0, 0) == 0 and lib.md_linear_fused_supported(64, 768, 2048, 3) == 1
     assert lib.md_linear_fused_supported(64, 770, 2048, 0) == 0 and lib.md_linear_fused_supported(300, 768, 2048, 0) == 0
     assert lib.md_linear_add_rmsnorm_supported(0, 0, 0) == 0 and lib.md_linear_add_rmsnorm_supported(256, 4096, 14336) == 1
-    skip |= {"md_linear_supported", "md_linear_fused_supported", "md_linear_add_rmsnorm_supported"}
+    assert lib.md_linear_block_supported(0, 0, 0, 0) == 0 and lib.md_linear_block_supported(256, 4096, 4096, 0) == 1
+    assert lib.md_linear_block_supported(256, 4100, 4096, 0) == 0 and lib.md_linear_block_supported(257, 4096, 4096, 0) == 0
+    assert lib.md_linear_block_workspace_bytes(256, 4096, 4096, 0) > 0 and lib.md_linear_block_workspace_bytes(256, 28672, 4096, 0) == 0
+    skip |= {"md_linear_supported", "md_linear_fused_supported", "md_linear_add_rmsnorm_supported", "md_linear_block_supported"}
     # md_linear_fused takes a struct: NULL struct, then a zeroed struct (null tensors), then tensors but a bad shape
     assert lib.md_linear_fused(None, None) < 0 and "md_linear_fused" in lib.md_last_error_string().decode()
     fa = _lib.FusedLinearArgs()
