@@ -15,6 +15,17 @@ every decode / verify shape of the BASELINE models timed on both, weights cycled
     narrow projections of an 8B step) go to md_linear_fused (csrc/tilegemm.hip): one launch for the product AND the op
     behind it (rope+append, residual add, SiLU*mul), no split-K combine, no partial sums in HBM.
 
+  * round 4: the 129..256-ROW products of a verify step whose column count fills the chip without splitting K, and the
+    K = 14336 down projection, go to md_linear_block (csrc/blockgemm.hip: 256 x 128 block tiles, LDS-DMA rings, loader +
+    MFMA waves) -- profiles/r04_block_ab_final.txt, same process, graph-captured, weights cycled (us; "lib" includes the
+    elementwise kernel behind it, "skinny" its combine launch):
+        8B w1|w3 + SiLU*mul  M = 256: lib 85-89 (68.8 + 6.2 inside the cfg3 trace), skinny 108-119, block 67-72
+        8B w2 + add + norm   M = 256: lib 66-68, skinny 53.5-55, block 48.6-49.9
+        8B lm head           M = 256: lib 293-297, skinny 345-350, block 274-278
+        8B w1|w3             M = 128: lib 58-65, skinny 61.6-63.8, block 52.3-57
+    and NOT the narrow projections, where splitting K over ~256 workgroups costs a partial-sum round trip the product is
+    too small to pay for (wqkv 30-32 vs lib 27 + 6.3 for rope/append: a wash; wo 34-35 vs 25; every TP8 shard slower).
+
 A weight a hand-written kernel will serve is re-packed once at setup_caches (Transformer._pack_weights); the row-major
 copy stays for the prefill-sized products.  MAGICDEC_GEMM=hip forces md_linear wherever it supports the shape,
 MAGICDEC_GEMM=lib forces the library, MAGICDEC_FUSED=0/1 switches md_linear_fused off / on everywhere (the A/B
@@ -64,14 +75,34 @@ def fused_mode() -> str:
     return _FUSED
 
 
-def want_packed(N: int, K: int) -> bool:
-    """Re-pack this weight into the streaming layout at load time?  Every linear either hand-written kernel may serve:
-    md_linear takes the long streams, md_linear_fused the small products (any bf16 weight with K % 128 == 0)."""
-    if _MODE == "lib" or K % 128:
+_PACKED = os.environ.get("MAGICDEC_PACKED_COPIES", "auto")   # "0": no streaming-layout copies at all (every linear on the
+                                                             # library / the row-major md_linear): saves their HBM
+
+
+def set_packed_copies(mode: str):
+    global _PACKED
+    assert mode in ("auto", "0")
+    _PACKED = mode
+
+
+def want_packed(N: int, K: int, swiglu: bool = False, int8: bool = False) -> bool:
+    """Re-pack this weight into the streaming layout at load time?  Only when a hand-written kernel may actually be
+    chosen for it at some row count of a decode / verify step (1..256): the copy doubles the weight's HBM footprint
+    (round 3 packed every bf16 weight with K % 128 == 0)."""
+    if _MODE == "lib" or _PACKED == "0" or K % 64:
         return False
-    if _MODE == "hip" or N * K * 2 >= MIN_STREAM_BYTES:
+    if int8:
+        return K % 128 == 0            # int8 rows are only streamed by md_linear, at every row count
+    if _MODE == "hip" or _BLOCK == "1" or _FUSED == "1":
         return True
-    return _FUSED != "0" and N % 32 == 0
+    kinds = ("swiglu",) if swiglu else ("plain", "resid", "qkv")
+    for M in (1, 32, 64, 128, 256):
+        if use_skinny(M, N, K, swiglu, False, True):
+            return True
+        for kind in kinds:
+            if use_block(M, N, K, kind) or use_fused(M, N, K, kind, absorbs_norm=True):
+                return True
+    return False
 
 
 def use_fused(M: int, N: int, K: int, kind: str = "plain", absorbs_norm: bool = False) -> bool:
@@ -102,10 +133,45 @@ def use_skinny(M: int, N: int, K: int, swiglu: bool, int8: bool, packed: bool) -
     return K >= 8192 and nbytes >= MIN_STREAM_BYTES_M128
 
 
+BLOCK_MIN_TILES = 160          # 128-column tiles that fill the chip without a K split (w1|w3: 224, lm head: 1002)
+_BLOCK = os.environ.get("MAGICDEC_BLOCK", "auto")      # "0": never md_linear_block, "1": wherever it supports the shape
+
+
+def set_block(mode: str):
+    global _BLOCK
+    assert mode in ("auto", "0", "1")
+    _BLOCK = mode
+
+
+def block_mode() -> str:
+    return _BLOCK
+
+
+def use_block(M: int, N: int, K: int, kind: str) -> bool:
+    """md_linear_block for this linear?  kind: "swiglu", "resid" (output projection + residual add + RMSNorm: the split-K
+    combine launch does both) or "plain"."""
+    if _MODE == "lib" or _BLOCK == "0" or M > 256 or N % 128 or K % 64:
+        return False
+    if _BLOCK == "1":
+        return True
+    tiles = N // 128
+    if M > 128:
+        if kind == "resid":
+            return K >= 8192 and N <= 8192 and N * K * 2 >= MIN_STREAM_BYTES_M128   # the 8B w2 (K = 14336); wo and
+                                                                                    # the TP shards stay on the library
+        return tiles >= BLOCK_MIN_TILES and kind in ("swiglu", "plain")
+    return M > 64 and kind == "swiglu" and tiles >= BLOCK_MIN_TILES      # cfg2's 128-row verify: w1|w3 only
+
+
 def choose(M: int, N: int, K: int, swiglu: bool, int8: bool, packed: bool, kind: str = None,
            absorbs_norm: bool = False) -> str:
-    """"fused" (md_linear_fused), "skinny" (md_linear) or "lib" (hipBLASLt) for one linear of a step."""
+    """"fused" (md_linear_fused), "block" (md_linear_block), "skinny" (md_linear) or "lib" (hipBLASLt) for one linear
+    of a step."""
     kind = kind or ("swiglu" if swiglu else "plain")
+    if packed and not int8 and _BLOCK == "1" and use_block(M, N, K, kind):
+        return "block"
     if packed and not int8 and use_fused(M, N, K, kind, absorbs_norm):
         return "fused"
+    if packed and not int8 and use_block(M, N, K, kind):
+        return "block"
     return "skinny" if use_skinny(M, N, K, swiglu, int8, packed) else "lib"

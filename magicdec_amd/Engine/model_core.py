@@ -325,7 +325,7 @@ class Transformer(nn.Module):
             return
 
         def pack(w, swiglu=False):
-            if want_packed(w.shape[0], w.shape[1]):
+            if w.shape[1] % 16 == 0 and want_packed(w.shape[0], w.shape[1], swiglu, w.dtype == torch.int8):
                 pw = ops.PackedWeight(w.data if isinstance(w, nn.Parameter) else w, swiglu=swiglu)
                 self._packed[id(w)] = pw
                 self.packed_bytes += pw.data.numel() * pw.data.element_size()
@@ -350,10 +350,11 @@ class Transformer(nn.Module):
         return y
 
     def _linear(self, x2d, lin, swiglu_w13=None, resid=None, want_ssq=False):
-        """One linear of a step.  Three implementations, chosen per shape by the measured rules of
+        """One linear of a step.  Four implementations, chosen per shape by the measured rules of
         Engine/gemm_policy.py: md_linear_fused (csrc/tilegemm.hip: the launch-bound small products -- draft-model
-        linears, tensor-parallel shards -- in one launch together with their epilogue), md_linear (csrc/gemm.hip: the
-        long weight streams, split-K + combine) or the library GEMM (prefill-sized M, and whatever the A/B gave it).
+        linears, tensor-parallel shards -- in one launch together with their epilogue), md_linear_block
+        (csrc/blockgemm.hip: the wide 129..256-row products of a verify step), md_linear (csrc/gemm.hip: the long weight
+        streams at <= 128 rows, split-K + combine) or the library GEMM (prefill-sized M, and whatever the A/B gave it).
         `swiglu_w13 = (w13, s13)`: the fused w1|w3 product with the SiLU*mul epilogue.
         `resid`: return bf16(resid + linear) instead (the residual add of the block; only honoured by the fused
         kernel -- callers check `_fused_here` first); with `want_ssq` also the per-row partial sums of squares of the
@@ -381,7 +382,9 @@ class Transformer(nn.Module):
         if pro is not None:
             x2d = pro.materialize()
         assert resid is None, "the residual epilogue exists on the fused kernel only"
-        if how in ("fused", "skinny") and ops.linear_supported(M, N, K, swiglu):
+        if how == "block" and ops.linear_block_supported(M, N, K, swiglu):
+            return ops.linear_block(x2d, pk, bias, swiglu, self.workspace)
+        if how in ("fused", "skinny", "block") and ops.linear_supported(M, N, K, swiglu):
             return ops.linear(x2d, pk if pk is not None else w, bias, scales, swiglu, self.workspace)
         if w.dtype == torch.int8:      # WeightOnlyInt8Linear.forward (Engine/quantize.py:84-86), dequantised on the fly
             h = F.linear(x2d, w.to(dtype=x2d.dtype)) * scales
@@ -420,7 +423,11 @@ class Transformer(nn.Module):
             w = lin.weight
             M, K = inp.shape
             pk = self._packed.get(id(w))
-            if (choose(M, w.shape[0], K, False, w.dtype == torch.int8, pk is not None, "resid") == "skinny"
+            how = choose(M, w.shape[0], K, False, w.dtype == torch.int8, pk is not None, "resid")
+            if how == "block" and ops.linear_block_supported(M, w.shape[0], K) and inp.stride(-1) == 1:
+                # 129..256 rows: the block-tile GEMM, same combine launch (residual add + RMSNorm)
+                return ops.linear_block_add_rmsnorm(inp, pk, x, norm.weight, norm.eps, lin.bias, self.workspace)
+            if (how in ("skinny", "block")
                     and ops.linear_add_rmsnorm_supported(M, w.shape[0], K)):
                 return ops.linear_add_rmsnorm(inp, pk if pk is not None else w, x, norm.weight, norm.eps, lin.bias,
                                               getattr(lin, "scales", None), self.workspace)

@@ -10,9 +10,9 @@
 // 1 + 1/8 LDS fragment reads per MFMA and is LDS-bound there; md_linear_fused (tilegemm.hip: 32 x 32 tiles) re-reads
 // the weights 8 times through L2.  This kernel is the classic block-tile form, built around what bounds it on CDNA4
 // -- LDS bytes per flop and the per-CU load path:
-//   * one workgroup = 256 rows (all of M) x 128 columns x a K range; 4 wavefronts as 2 (M) x 2 (N), ONE per SIMD, each
-//     owning a 128 x 64 output tile = 4 x 2 accumulators of v_mfma_f32_32x32x16_bf16 (128 accumulator registers):
-//     6 fragment reads per 8 MFMAs, half of md_linear's LDS traffic per flop;
+//   * one workgroup = 256 rows (all of M) x 128 columns x a K range; 4 MFMA wavefronts as 2 (M) x 2 (N), one per SIMD,
+//     each owning a 128 x 64 output tile = 4 x 2 accumulators of v_mfma_f32_32x32x16_bf16 (128 accumulator registers):
+//     6 fragment reads per 8 MFMAs, half of md_linear's LDS traffic per flop; 4 LOADER wavefronts beside them;
 //   * both operands go global -> LDS by DMA (buffer_load ... lds, 16 B per lane, no VGPR round trip), three 48-KB
 //     stages of 64 k (144 of the 160 KB), the loads of stage s+2 issued right after the one barrier of stage s and
 //     retired with a COUNTED vmcnt two stages later -- loads stay in flight across the barrier;
@@ -46,11 +46,8 @@ typedef __attribute__((address_space(3))) void lds_ptr_t;
 constexpr int BM = 256, BN = 128, BK = 64;
 constexpr int kStageA = BM * BK * 2;            // 32 KiB: [256 rows][8 chunks x 16 B], chunk-swizzled
 constexpr int kStageB = BN * BK * 2;            // 16 KiB: [4 column tiles][4 k-steps][64 lanes x 16 B]
-constexpr int kStage = kStageA + kStageB;       // 48 KiB
-constexpr int kStages = 3;
-constexpr int kLds = kStage * kStages;          // 144 KiB
-constexpr int kEpiPitch = BN + 4;               // fp32 epilogue tile [256][132]: 135 168 B inside the ring
-static_assert(BM * kEpiPitch * 4 <= kLds, "epilogue tile must fit the ring");
+constexpr int kEpiPitch = BN + 4;               // fp32 epilogue tile [256][132]: 135 168 B inside the rings
+constexpr int lds_bytes(int XS, int WS) { return XS * kStageA + WS * kStageB; }
 
 enum { BE_NONE = 0, BE_SWIGLU = 1 };
 
@@ -75,170 +72,198 @@ __device__ __forceinline__ float silu_bf16(float h1) {
 #define SG_DSR 0x100
 
 // WNT: weights with the non-temporal cache policy (the tile owns all 256 rows: a weight byte is read by one workgroup)
-template <int EPI, bool SPLIT, bool WNT>
-__global__ __launch_bounds__(256, 1) void block_gemm_kernel(const BlockParams p) {
+//
+// Eight wavefronts, two per SIMD with different jobs:
+//   waves 0-3  CONSUMERS: fragment reads + MFMAs only, software-pipelined one k-step ahead;
+//   waves 4-5  x LOADERS (16 DMA pieces per stage each), waves 6-7  W LOADERS (8 pieces per stage each).
+// What bounds it (w1|w3 at M = 256, timing experiments of GPU calls 1-9, profiles/r04_block_*; the experiment switches
+// are gone from the code): the MFMA + LDS skeleton alone runs 40.3 us (1.49 PFLOP/s), the loaders alone 59.5 us -- x only
+// (L2 hits) 30.5 = DMA-issue-bound at ~56 cycles per piece, W only (HBM) 47.1 = 5.0 TB/s, and the two TOGETHER 59.5:
+// a CU ingests ~50 GB/s once HBM misses are in the mix, whoever issues the DMA (the four MFMA waves themselves: 70.7 us;
+// dedicated loader waves: 70.5), however deep the W queue (3, 4 or 6 stages; 4 stages in the loaders' registers), and
+// wherever x comes from (one hot 32 KB every stage: 55).  Per-CU ingest for this tile is 3 MB (2 MB of it x, re-read by
+// every column tile), so ~60 us is this decomposition's floor at N = 28672 and the kernel sits at 67-72; PMC: HBM
+// fetch = 1.05 x the weight bytes, L2 hit rate of x 100 %, LDS conflicts 2 %, matrix pipe 46 % busy.
+// One s_barrier per stage joins everybody: a loader arrives when ITS pieces of stage it+1 have landed, a consumer when
+// its last fragment read of stage it has returned -- past the barrier stage it+1 is readable and the buffers of stage it
+// are free for x stage it+XS / W stage it+WS.
+template <int EPI, bool SPLIT, bool WNT, int XS, int WS>
+__global__ __launch_bounds__(512) void block_gemm_kernel(const BlockParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];     // the ONLY LDS object (cdna guide 5.4(a))
+    constexpr int kWRing = XS * kStageA;                                    // LDS offset of the W ring
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
-    const int j = lane & 31, kh = lane >> 5;
     // block id -> (column tile, K slice); with S = 8 a slice (= the x columns it reads) stays on one XCD's L2
     const int slice = blockIdx.x % p.S, tn = blockIdx.x / p.S;
     const int s0 = (int)((int64_t)slice * p.nsteps / p.S), s1 = (int)((int64_t)(slice + 1) * p.nsteps / p.S);
     const int n = s1 - s0;
+    const int wm = (wave >> 1) & 1, wn = wave & 1;          // consumers: 2 (M) x 2 (N)
+    const int j = lane & 31, kh = lane >> 5;
 
-    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.x), 0, p.x_bytes, 0x00020000);
-    const int64_t wtile = (int64_t)(p.K >> 4) * 512;                       // elements of one 32-column tile
-    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<bf16_t*>(p.w + (int64_t)tn * 4 * wtile), 0, (unsigned int)(4 * wtile * 2), 0x00020000);
+    float* tile = reinterpret_cast<float*>(lds);            // fp32 epilogue tile (the rings are free by then)
 
-    // ---- DMA addresses.  x: piece q of this wave covers rows (wave*8+q)*8 .. +7, 8 lanes per 128-B line; rows >= M lie
-    // beyond the descriptor's bound and read as zeros
-    unsigned int avo[8];
+    // A stage past the end of the slice is issued all the same with its offsets pushed beyond the descriptor's bound
+    // (bit 31): zero fill, no memory traffic, and every vmcnt is the same count.  (The instruction's immediate offset
+    // would move the LDS address too: not used.)
+    if (wave >= 6) {
+        // ------------------------------------------------------------------ W loader: column tiles 2*lw, 2*lw+1
+        const int lw = wave - 6;
+        const int64_t wtile = (int64_t)(p.K >> 4) * 512;                   // elements of one 32-column tile
+        const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<bf16_t*>(p.w + (int64_t)tn * 4 * wtile), 0, (unsigned int)(4 * wtile * 2), 0x00020000);
+        // one piece = one MFMA B fragment (32 columns x 16 k = one contiguous KiB of the streaming layout)
+        const unsigned int bvo0 = (unsigned int)(2 * lw) * (unsigned int)(wtile * 2) + (unsigned int)lane * 16u;
+        const unsigned int bvo1 = bvo0 + (unsigned int)(wtile * 2);
+        auto issue = [&](int it, int slot) {
+            const unsigned int oob = it < n ? 0u : 0x80000000u;
+            const int so = (s0 + it) * 4096;                  // byte offset of the stage's 4 fragments in a column tile
+            unsigned char* dst = lds + kWRing + slot * kStageB + lw * 8192;
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-        const int r = (wave * 8 + q) * 8 + (lane >> 3);
-        const int c = (lane & 7) ^ ((r >> 1) & 7);
-        avo[q] = (unsigned int)r * (unsigned int)p.ldx * 2u + (unsigned int)c * 16u;
-    }
-    // W: this wave stages column tile `wave` (4 k-steps = 4 KiB contiguous per stage)
-    const unsigned int bvo = (unsigned int)wave * (unsigned int)(wtile * 2) + (unsigned int)lane * 16u;
-
-    // One stage = 12 DMA pieces per wave (8 of x, 4 of W), issued in four groups of three so that they sit in the MFMA
-    // shadows of four k-steps.  A stage past the end of the slice is issued all the same with its offsets pushed beyond
-    // the descriptors' bounds (bit 31): zero fill, no memory traffic -- the loop stays branch-free and every vmcnt is
-    // the same count.  (The instruction's immediate offset would move the LDS address too: not used.)
-    auto issue_group = [&](int it, int buf_off, int g) {
-        const unsigned int oob = it < n ? 0u : 0x80000000u;
-        const int so_a = (s0 + it) * (BK * 2);            // byte offset of the stage's k range in a row of x
-        const int so_b = (s0 + it) * 4096 + g * 1024;     // ... in a column tile of W (4 fragments per stage)
+            for (int q = 0; q < 8; ++q)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr_t*)(dst + q * 1024), 16,
+                                                         ((q >> 2) ? bvo1 : bvo0) | oob, so + (q & 3) * 1024, 0,
+                                                         WNT ? 2 : 0);
+        };
 #pragma unroll
-        for (int q = 2 * g; q < 2 * g + 2; ++q)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr_t*)(lds + buf_off + (wave * 8 + q) * 1024), 16,
-                                                     avo[q] | oob, so_a, 0, 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr_t*)(lds + buf_off + kStageA + (wave * 4 + g) * 1024), 16,
-                                                 bvo | oob, so_b, 0, WNT ? 2 : 0);
-    };
-
-    // ---- fragment read addresses
-    const int f = (j >> 1) & 7;
-    const unsigned char* a_lane = lds + (wm * 128 + j) * 128;
-    int axo[4];
+        for (int i = 0; i < WS; ++i) issue(i, i);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((WS - 1) * 8) : "memory");      // stage 0 has landed
+        __builtin_amdgcn_s_barrier();
+        int slot = 0;
+        for (int it = 0; it < n; ++it) {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((WS - 2) * 8) : "memory");  // stage it+1 has landed
+            __builtin_amdgcn_s_barrier();                                         // the consumers are done with stage it
+            issue(it + WS, slot);
+            slot = slot + 1 == WS ? 0 : slot + 1;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // zero-fill pieces of the stages past the end
+        __builtin_amdgcn_s_barrier();                           // every wave is done with the rings
+    } else if (wave >= 4) {
+        // ------------------------------------------------------------------ x loader: rows lw*128 .. +127
+        const int lw = wave - 4;
+        const __amdgpu_buffer_rsrc_t rx =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.x), 0, p.x_bytes, 0x00020000);
+        // piece q covers rows (lw*16+q)*8 .. +7, 8 lanes per 128-B line; LDS image [row][8 chunks], chunk c of row r
+        // stored at chunk c ^ ((r >> 1) & 7): the DMA writes LDS linearly (base + lane * 16), so the lane FETCHES the
+        // chunk that belongs at its slot.  Rows >= M lie beyond the descriptor's bound: zeros.
+        unsigned int avo[16];
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) axo[ks] = ((2 * ks + kh) ^ f) * 16;
-    const unsigned char* b_lane = lds + kStageA + wn * 8192 + lane * 16;
-
-    f32x16 acc[4][2];
+        for (int q = 0; q < 16; ++q) {
+            const int r = (lw * 16 + q) * 8 + (lane >> 3);
+            const int c = (lane & 7) ^ ((r >> 1) & 7);
+            avo[q] = (unsigned int)r * (unsigned int)p.ldx * 2u + (unsigned int)c * 16u;
+        }
+        auto issue = [&](int it, int slot) {
+            const unsigned int oob = it < n ? 0u : 0x80000000u;
+            const int so = (s0 + it) * (BK * 2);              // byte offset of the stage's k range in a row of x
+            unsigned char* dst = lds + slot * kStageA + lw * 16384;
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt)
+            for (int q = 0; q < 16; ++q)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr_t*)(dst + q * 1024), 16, avo[q] | oob, so, 0, 0);
+        };
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
+        for (int i = 0; i < XS; ++i) issue(i, i);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((XS - 1) * 16) : "memory");
+        __builtin_amdgcn_s_barrier();
+        int slot = 0;
+        for (int it = 0; it < n; ++it) {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((XS - 2) * 16) : "memory");
+            __builtin_amdgcn_s_barrier();
+            issue(it + XS, slot);
+            slot = slot + 1 == XS ? 0 : slot + 1;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    } else {
+        // ------------------------------------------------------------------ consumer
+        const int f = (j >> 1) & 7;
+        const unsigned char* a_lane = lds + (wm * 128 + j) * 128;
+        int axo[4];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
-
-    bf16x8 fa[2][4], fb[2][2];                             // fragment double buffer (compile-time indices only)
-    auto read_frags = [&](int set, int buf_off, int ks) {
+        for (int ks = 0; ks < 4; ++ks) axo[ks] = ((2 * ks + kh) ^ f) * 16;
+        const unsigned char* b_lane = lds + kWRing + wn * 8192 + lane * 16;
+        f32x16 acc[4][2];
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt)
-            fa[set][mt] = *reinterpret_cast<const bf16x8*>(a_lane + buf_off + axo[ks] + mt * 4096);
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
-            fb[set][nt] = *reinterpret_cast<const bf16x8*>(b_lane + buf_off + (nt * 4 + ks) * 1024);
-    };
-    auto mfmas = [&](int set) {
+            for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
+                for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+
+        bf16x8 fa[2][4], fb[2][2];                             // fragment double buffer (compile-time indices only)
+        auto read_frags = [&](int set, int xoff, int woff, int ks) {
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt)
-                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[set][mt], fb[set][nt], acc[mt][nt], 0, 0, 0);
-    };
-    // the issue order of one k-step: 8 MFMAs (fragments read one k-step ago) with the 6 fragment reads of the NEXT k-step
-    // and 3 DMA pieces in their shadows (one wave per SIMD: nothing else hides an LDS round trip or a DMA issue)
-    auto interleave = [&]() {
+                fa[set][mt] = *reinterpret_cast<const bf16x8*>(a_lane + xoff + axo[ks] + mt * 4096);
 #pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            __builtin_amdgcn_sched_group_barrier(SG_MFMA, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(SG_DSR, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(SG_MFMA, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(SG_DSR, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(SG_VMEM, 1, 0);
-        }
-        __builtin_amdgcn_sched_group_barrier(SG_MFMA, 2, 0);
-    };
-
-    // iteration `it` computes stage it from buffer CUR; NXT holds stage it+1 (landing), PRV (read last iteration) takes
-    // groups 1..3 of stage it+2 during k-steps 0..2; in k-step 3 every wave has issued its last read of CUR: wait for
-    // them, wait for MY pieces of stage it+1 (counted: the 12 of stage it+2 stay in flight), meet the other waves, then
-    // CUR is free for group 0 of stage it+3 and NXT is readable
-    auto iteration = [&](int it, int cur, int nxt, int prv) {
-        issue_group(it + 2, prv, 1);
-        read_frags(1, cur, 1);
-        mfmas(0);
-        interleave();
-        __builtin_amdgcn_sched_barrier(0);
-        issue_group(it + 2, prv, 2);
-        read_frags(0, cur, 2);
-        mfmas(1);
-        interleave();
-        __builtin_amdgcn_sched_barrier(0);
-        issue_group(it + 2, prv, 3);
-        read_frags(1, cur, 3);
-        mfmas(0);
-        interleave();
-        __builtin_amdgcn_sched_barrier(0);
-        asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory");
+            for (int nt = 0; nt < 2; ++nt)
+                fb[set][nt] = *reinterpret_cast<const bf16x8*>(b_lane + woff + (nt * 4 + ks) * 1024);
+        };
+        auto mfmas = [&](int set) {
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[set][mt], fb[set][nt], acc[mt][nt], 0, 0, 0);
+        };
+        // the issue order of one k-step: 8 MFMAs (fragments read one k-step ago) with the 6 fragment reads of the NEXT
+        // k-step in the shadows of the first six
+        auto interleave = [&]() {
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                __builtin_amdgcn_sched_group_barrier(SG_MFMA, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(SG_DSR, 1, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(SG_MFMA, 2, 0);
+        };
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
-        issue_group(it + 3, cur, 0);
-        read_frags(0, nxt, 0);
-        mfmas(1);
-        interleave();
-        __builtin_amdgcn_sched_barrier(0);
-    };
-
-    issue_group(0, 0, 0);
-    issue_group(0, 0, 1);
-    issue_group(0, 0, 2);
-    issue_group(0, 0, 3);
-    issue_group(1, kStage, 0);
-    issue_group(1, kStage, 1);
-    issue_group(1, kStage, 2);
-    issue_group(1, kStage, 3);
-    issue_group(2, 2 * kStage, 0);
-    asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-    read_frags(0, 0, 0);
-    for (int it = 0;;) {
-        iteration(it, 0, kStage, 2 * kStage);
-        if (++it >= n) break;
-        iteration(it, kStage, 2 * kStage, 0);
-        if (++it >= n) break;
-        iteration(it, 2 * kStage, 0, kStage);
-        if (++it >= n) break;
+        read_frags(0, 0, 0, 0);
+        int xs = 0, ws = 0;
+        for (int it = 0; it < n; ++it) {
+            const int xoff = xs * kStageA, woff = ws * kStageB;
+            xs = xs + 1 == XS ? 0 : xs + 1;
+            ws = ws + 1 == WS ? 0 : ws + 1;
+            read_frags(1, xoff, woff, 1);
+            mfmas(0);
+            interleave();
+            __builtin_amdgcn_sched_barrier(0);
+            read_frags(0, xoff, woff, 2);
+            mfmas(1);
+            interleave();
+            __builtin_amdgcn_sched_barrier(0);
+            read_frags(1, xoff, woff, 3);
+            mfmas(0);
+            interleave();
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // my last reads of this stage have returned
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            read_frags(0, xs * kStageA, ws * kStageB, 0);
+            mfmas(1);
+            interleave();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // ---- accumulators -> fp32 tile in LDS
+        // acc[mt][nt][r] = D[row wm*128 + mt*32 + (r&3) + 8*(r>>2) + 4*kh][column wn*64 + nt*32 + j]
+        __builtin_amdgcn_s_barrier();                           // every wave is done with the rings (no DMA pending)
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = wm * 128 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                    tile[row * kEpiPitch + wn * 64 + nt * 32 + j] = acc[mt][nt][r];
+                }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // zero-fill pieces of the stages past the end
-
-    // ---- epilogue: accumulators -> fp32 tile in LDS -> row-contiguous 16-byte stores
-    // acc[mt][nt][r] = D[row wm*128 + mt*32 + (r&3) + 8*(r>>2) + 4*kh][column wn*64 + nt*32 + j]
-    __syncthreads();
-    float* tile = reinterpret_cast<float*>(lds);
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = wm * 128 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-                tile[row * kEpiPitch + wn * 64 + nt * 32 + j] = acc[mt][nt][r];
-            }
+    // ---- epilogue: row-contiguous 16-byte stores by all 512 threads
     __syncthreads();
 
     if constexpr (SPLIT) {
         float* pp = p.partial + (int64_t)slice * p.M * p.N;
 #pragma unroll 4
-        for (int q = 0; q < 32; ++q) {
-            const int c = tid + 256 * q;
+        for (int q = 0; q < 16; ++q) {
+            const int c = tid + 512 * q;
             const int row = c >> 5, c4 = (c & 31) * 4;                        // 4 consecutive tile columns
             if (row >= p.M) continue;
             const f32x4 v = *reinterpret_cast<const f32x4*>(tile + row * kEpiPitch + c4);
@@ -253,8 +278,8 @@ __global__ __launch_bounds__(256, 1) void block_gemm_kernel(const BlockParams p)
         }
     } else if constexpr (EPI == BE_SWIGLU) {
 #pragma unroll 4
-        for (int q = 0; q < 8; ++q) {
-            const int c = tid + 256 * q;
+        for (int q = 0; q < 4; ++q) {
+            const int c = tid + 512 * q;
             const int row = c >> 3, t = (c >> 1) & 3, i8 = (c & 1) * 8;       // 8 outputs of packed tile t
             if (row >= p.M) continue;
             const float* src = tile + row * kEpiPitch + t * 32 + i8;
@@ -273,8 +298,8 @@ __global__ __launch_bounds__(256, 1) void block_gemm_kernel(const BlockParams p)
         f32x8 bv = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         if (p.bias) bv = __builtin_convertvector(*reinterpret_cast<const bf16x8*>(p.bias + tn * BN + c8), f32x8);
 #pragma unroll 4
-        for (int q = 0; q < 16; ++q) {
-            const int row = (tid + 256 * q) >> 4;
+        for (int q = 0; q < 8; ++q) {
+            const int row = (tid + 512 * q) >> 4;
             if (row >= p.M) continue;
             const float* src = tile + row * kEpiPitch + c8;
             const f32x4 va = *reinterpret_cast<const f32x4*>(src), vb = *reinterpret_cast<const f32x4*>(src + 4);
@@ -301,9 +326,15 @@ int pick_splits(int n_tiles, int nsteps) {
     return s;
 }
 
+// x ring 3 x 32 KB + W ring 4 x 16 KB = the CU's 160 KB.  Measured alternatives (same process, w1|w3 at M = 256,
+// profiles/r04_block_*): W ring 3 deep: equal; x 2 + W 6: 81 vs 70.5 us (one x stage in flight is too few); the loaders'
+// register files as a 3-4 stage deep FIFO in front of a two-slot LDS image (plain loads + ds_write_b128): 76-81 us.
 template <int EPI, bool SPLIT, bool WNT>
 int launch_cfg(const BlockParams& p, int grid, hipStream_t st) {
-    auto k = block_gemm_kernel<EPI, SPLIT, WNT>;
+    constexpr int XS = 3, WS = 4;
+    constexpr int kLds = lds_bytes(XS, WS);
+    static_assert(BM * kEpiPitch * 4 <= kLds && kLds <= 160 * 1024, "rings must hold the epilogue tile and fit the CU");
+    auto k = block_gemm_kernel<EPI, SPLIT, WNT, XS, WS>;
     static MdPerDeviceOnce once;
     if (once.first()) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, kLds) !=
@@ -313,7 +344,7 @@ int launch_cfg(const BlockParams& p, int grid, hipStream_t st) {
             return MD_ERR_LAUNCH;
         }
     }
-    hipLaunchKernelGGL(k, dim3(grid), dim3(256), kLds, st, p);
+    hipLaunchKernelGGL(k, dim3(grid), dim3(512), kLds, st, p);
     return MD_OK;
 }
 

@@ -510,6 +510,30 @@ def test_lockstep_with_every_linear_on_the_skinny_gemm(ckpt_dir):
     parity_report(st.line("longspec/snapkv, all linears md_linear"))
 
 
+def test_lockstep_with_every_linear_on_the_block_gemm(ckpt_dir):
+    """MAGICDEC_BLOCK=1: every linear of the decode / verify steps of the tiny target (all N % 128 == 0, K % 64 == 0)
+    runs on md_linear_block -- plain (wqkv, lm head), SwiGLU in the kernel / in the combine launch (w1|w3) and the
+    residual add + RMSNorm combine (wo, w2) -- under the same lock-step gates as the default policy (the BASELINE shapes
+    that take this kernel by the measured rule, N >= 20480, do not occur in the tiny models)."""
+    from magicdec_amd.Engine import gemm_policy
+    cfg, sd = gc.tiny("tinytgt")
+    log = []
+    tgt = Recorder(mr.RefEngine("target", cfg, sd, gc.B, gc.MAX_LEN), "T", log)
+    drf = Recorder(mr.RefEngine("snapkv_draft", cfg, sd, gc.B, gc.MAX_LEN, gc.BUDGET), "D", log)
+    hr.longspec_batch(tgt, drf, gc.synthetic_batches()[0], gc.GAMMA, gc.MAX_LEN, gc.EOT_1, gc.EOT_2)
+    old = gemm_policy.block_mode()
+    gemm_policy.set_block("1")
+    try:
+        assert gemm_policy.choose(8, 768, 512, False, False, True, "qkv") == "block"
+        e_t, e_d = _hip("target", ckpt_dir), _hip("snapkv_draft", ckpt_dir)
+        assert len(e_t.model._packed) == 4 * cfg.n_layer + 1
+        st = replay(log, {"T": e_t, "D": e_d}, {"T": _alt("target", cfg, sd, gc.B, gc.MAX_LEN),
+                                                 "D": _alt("snapkv_draft", cfg, sd, gc.B, gc.MAX_LEN, gc.BUDGET)})
+    finally:
+        gemm_policy.set_block(old)
+    parity_report(st.line("longspec/snapkv, all linears md_linear_block"))
+
+
 def test_int8_weight_only_engine_lockstep():
     """Weight-only int8 (Engine/quantize.py, "int8" in the checkpoint path -> Engine/utils.py:201-205): the tiny
     target quantised per channel, loaded through the int8 loader, every linear streamed as int8 by md_linear with the

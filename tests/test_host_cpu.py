@@ -1198,8 +1198,8 @@ def test_gemm_policy_encodes_the_measured_ab_table():
     profiles/r02_gemm_ab.txt measured (which kernel serves which linear of the BASELINE models), so that a threshold
     edit cannot silently move a production shape to a slower kernel."""
     from magicdec_amd.Engine import gemm_policy as g
-    if g.mode() != "auto" or g.fused_mode() != "auto":
-        pytest.skip("MAGICDEC_GEMM / MAGICDEC_FUSED override the policy in this environment")
+    if g.mode() != "auto" or g.fused_mode() != "auto" or g.block_mode() != "auto":
+        pytest.skip("MAGICDEC_GEMM / MAGICDEC_FUSED / MAGICDEC_BLOCK override the policy in this environment")
     c = lambda M, N, K, kind, norm=False: g.choose(M, N, K, kind == "swiglu", False, True, kind, norm)
     # 1B draft model at TP1 (M = 64; two-token step M = 128)
     assert c(64, 3072, 2048, "qkv") == "fused" and c(64, 2048, 2048, "resid") == "fused"
@@ -1213,7 +1213,16 @@ def test_gemm_policy_encodes_the_measured_ab_table():
     # verify pass (M = 256): only the sharded qkv projection goes to the fused kernel; the 8B model's w2 streams
     assert c(256, 768, 4096, "qkv") == "fused" and c(256, 1536, 4096, "qkv") == "fused"
     assert c(256, 6144, 4096, "qkv") == "lib" and c(256, 4096, 512, "plain") == "lib"
-    assert c(256, 28672, 4096, "swiglu") == "lib" and c(256, 4096, 14336, "resid") == "skinny"
+    # round 4 (profiles/r04_block_ab_final.txt): the wide 129..256-row products and the K = 14336 down projection run
+    # on the block-tile GEMM; the narrow projections and every TP shard stay where they were
+    assert c(256, 28672, 4096, "swiglu") == "block" and c(256, 4096, 14336, "resid") == "block"
+    assert c(256, 128256, 4096, "plain") == "block" and c(128, 28672, 4096, "swiglu") == "block"
+    assert c(128, 4096, 14336, "resid") == "skinny" and c(256, 4096, 4096, "resid") == "lib"
+    assert c(256, 3584, 4096, "swiglu") == "lib" and c(256, 4096, 1792, "resid") == "lib"
+    assert c(256, 2048, 8192, "resid") == "lib"
+    # a streaming-layout copy only for weights some hand-written kernel can be chosen for
+    assert g.want_packed(28672, 4096, True) and g.want_packed(4096, 14336) and g.want_packed(3072, 2048)
+    assert not g.want_packed(1024, 16384) and not g.want_packed(4100, 4096)
     # autoregressive 8B steps (M = 64)
     assert c(64, 6144, 4096, "qkv") == "lib" and c(64, 4096, 4096, "resid") == "fused"
     assert c(64, 28672, 4096, "swiglu") == "skinny" and c(64, 4096, 14336, "resid") == "skinny"

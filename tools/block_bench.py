@@ -18,7 +18,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--only", default="")
 ap.add_argument("--iters", type=int, default=20)
 ap.add_argument("--blocks", type=int, nargs="+", default=[256])
-ap.add_argument("--wnt", type=int, nargs="+", default=[1])
+ap.add_argument("--wnt", type=int, nargs="+", default=[1], help="bit 0: nt weights; bits 4..: dev flags (16 = no x traffic, 32 = no W traffic, 64 = rotate k)")
 ap.add_argument("--check", type=int, default=1)
 a = ap.parse_args()
 print('tuned GEMM table loaded:', enable_tuned_gemms())
