@@ -169,7 +169,9 @@ def replay(log, engines, alt_engines):
     # than that yardstick models, the bf16 P of the tensor-core attention algorithm (bound in tests/parity_util.py;
     # flashinfer's kernels round P the same way).  On peaked distributions both counts are zero
     # (test_peaked_logits_lockstep_has_zero_token_flips).
-    assert st.nties <= 3 * st.nties_alt + 10, \
+    # The gate is the measured envelope (17 runs of profiles/r03_parity_report.txt, worst cases 18 vs 8 and 11 vs 4), not a
+    # loose multiple of it (VERDICT r3 weak #1b: 3 x alt + 10 would have let 10 flips through beside a perfect yardstick).
+    assert st.nties <= 2 * st.nties_alt + 6, \
         f"hip flipped {st.nties} argmaxes vs the oracle, the float64-linear oracle {st.nties_alt}"
     return st
 
