@@ -140,73 +140,105 @@ __device__ __forceinline__ int64_t kv_elem_offset(const KvTable& t, int b, int r
 // has in flight -- NW x (8 KiB of W + 8 KiB of x) -- are what its ingest rate is made of, ~50 GB/s per CU at NW = 8);
 // WNT = stream W with non-temporal loads (one M tile: every weight byte is read once) or keep it in L2 for the sibling
 // M tiles of the same weight tile.
-template <int EPI, bool FP8, int NW, bool WNT, bool PRO>
-__global__ __launch_bounds__(64 * NW, 4) void tile_gemm_kernel(const TileParams p) {
+// MT x NT = 32-row x 32-column MFMA tiles per workgroup (round 4).  What a CU has to ingest is W x (M tiles that
+// re-read it) + the x slab x (column tiles that re-read it), and a CU ingests ~50 GB/s whatever the kernel
+// (DESIGN.md 3.6): with 1 x 1 tiles the 1B w1|w3 at M = 64 (67 MB of W) moves 134 MB of W (two M tiles) + 134 MB of x
+// (512 column tiles x 256 KB) = 1.05 MB per CU = the measured 24.5 us; a 2 x 2 tile (64 rows x 64 columns, one
+// workgroup per CU) halves both.  Each K-slice wave then owns 2 x 2 accumulators, two W fragment streams and a 64-row
+// activation image; the summation order over the K slices (wave order) and every epilogue are unchanged, so the bits
+// are those of the 1 x 1 form.
+template <int EPI, bool FP8, int NW, bool WNT, bool PRO, int MT, int NT>
+__global__ __launch_bounds__(64 * NW, MT * NT > 1 ? 2 : 4) void tile_gemm_kernel(const TileParams p) {
     constexpr int kNW = NW;
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];   // NW x kWaveLds (+ 32 floats rstd when PRO)
+    constexpr int kWaveLdsT = MT * kWaveLds;               // wave-private activation image of 32 x MT rows
+    static_assert(MT * NT * 4096 <= kWaveLdsT, "the partial tiles of a wave must fit its activation image");
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];   // NW x kWaveLdsT (+ 32 MT floats rstd when PRO)
     const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, kh = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // provably wave-uniform: scalar base addresses
-    // block id -> (weight tile, M tile): block b runs on XCD b % 8; the M tiles of one weight tile stay on one XCD
+    // block id -> (weight tile group, M tile group): block b runs on XCD b % 8; the M groups of one weight tile group
+    // stay on one XCD
+    const int m_groups = (p.m_tiles + MT - 1) / MT, n_groups = p.n_tiles / NT;
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-    const int tn = (slot / p.m_tiles) * 8 + xcd, tm = slot % p.m_tiles;
-    if (tn >= p.n_tiles) return;
-    const int m0 = tm * 32;
+    const int tng = (slot / m_groups) * 8 + xcd, tmg = slot % m_groups;
+    if (tng >= n_groups) return;
+    const int m0 = tmg * 32 * MT, tn0 = tng * NT;
 
     const int ksteps_w = (p.K >> 4) / kNW;          // 16-deep MFMA k-steps of this wavefront's slice
     const int ks0 = wave * ksteps_w;
-    const bf16_t* wbase = p.w + ((int64_t)tn * (p.K >> 4) + ks0) * 512;     // wave-uniform; + lane * 8 per lane
-    unsigned char* my_lds = lds + wave * kWaveLds;
+    const bf16_t* wbase[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+        wbase[nt] = p.w + ((int64_t)(tn0 + nt) * (p.K >> 4) + ks0) * 512;    // wave-uniform; + lane * 8 per lane
+    unsigned char* my_lds = lds + wave * kWaveLdsT;
 
     // activation staging: instruction i covers rows 4i + (lane >> 4), 16 lanes read one 256-B row segment
     const int ar = lane >> 4, c16 = lane & 15;
     const unsigned char* xbase = reinterpret_cast<const unsigned char*>(p.x + ks0 * 16);   // wave-uniform
-    unsigned int xrow[8];                            // byte offsets of the lane's 8 rows (M * ldx * 2 < 2^32)
+    unsigned int xrow[8];                            // byte offsets of the lane's rows (M * ldx * 2 < 2^32); MT == 1
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const int r = m0 + 4 * i + ar;
         xrow[i] = (unsigned int)(r < p.M ? r : p.M - 1) * (unsigned int)p.ldx * 2u;   // rows >= M re-read row M-1
     }
     const int nchunk = (ksteps_w + 7) >> 3;
-    u32x4 xa[8];
+    u32x4 xa[8 * MT];
     u32x4 nwv = {0u, 0u, 0u, 0u};                   // PRO: the norm weights of this lane's 8 columns of the chunk
-    float rs8[8];                                   // PRO: rstd of this lane's 8 staging rows
+    float rs8[8];                                   // PRO, MT == 1: rstd of this lane's staging rows (MT > 1: re-read
+                                                    // from LDS per chunk -- 16 more registers would spill)
     if constexpr (PRO) {
-        float* rstd_lds = reinterpret_cast<float*>(lds + NW * kWaveLds);
+        float* rstd_lds = reinterpret_cast<float*>(lds + NW * kWaveLdsT);
         if (tid < 512) {
-            const int r = tid >> 4, part = tid & 15;
-            const int gr = m0 + r < p.M ? m0 + r : p.M - 1;
-            float t = 0.f;
-            for (int i = part; i < p.pro_tiles; i += 16) t += p.pro_ssq[(int64_t)gr * p.pro_tiles + i];
-            t += __shfl_xor(t, 1);
-            t += __shfl_xor(t, 2);
-            t += __shfl_xor(t, 4);
-            t += __shfl_xor(t, 8);
-            if (part == 0) rstd_lds[r] = rsqrtf(t / (float)p.K + p.pro_eps);      // md_rmsnorm's expression
+#pragma unroll
+            for (int mi = 0; mi < MT; ++mi) {
+                const int r = (tid >> 4) + 32 * mi, part = tid & 15;
+                const int gr = m0 + r < p.M ? m0 + r : p.M - 1;
+                float t = 0.f;
+                for (int i = part; i < p.pro_tiles; i += 16) t += p.pro_ssq[(int64_t)gr * p.pro_tiles + i];
+                t += __shfl_xor(t, 1);
+                t += __shfl_xor(t, 2);
+                t += __shfl_xor(t, 4);
+                t += __shfl_xor(t, 8);
+                if (part == 0) rstd_lds[r] = rsqrtf(t / (float)p.K + p.pro_eps);      // md_rmsnorm's expression
+            }
         }
         __syncthreads();
+        if constexpr (MT == 1) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) rs8[i] = rstd_lds[4 * i + ar];
+            for (int i = 0; i < 8; ++i) rs8[i] = rstd_lds[4 * i + ar];
+        }
     }
     auto a_load = [&](int c) {
         const int klen = min(ksteps_w - c * 8, 8) * 16;               // k elements of this chunk (wave-uniform)
         const unsigned int cc = (unsigned int)(c * kKC + (c16 * 8 < klen ? c16 : 0) * 8) * 2u;   // lanes past a short
                                                                       // tail chunk re-read its column 0
 #pragma unroll
-        for (int i = 0; i < 8; ++i) xa[i] = *reinterpret_cast<const u32x4*>(xbase + (xrow[i] + cc));
+        for (int i = 0; i < 8 * MT; ++i) {
+            unsigned int ro;
+            if constexpr (MT == 1) {
+                ro = xrow[i];
+            } else {                                                  // recomputed: 16 more live registers would spill
+                const int r = m0 + 4 * i + ar;
+                ro = (unsigned int)(r < p.M ? r : p.M - 1) * (unsigned int)p.ldx * 2u;
+            }
+            xa[i] = *reinterpret_cast<const u32x4*>(xbase + (ro + cc));
+        }
         if constexpr (PRO)
             nwv = *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned char*>(p.pro_w + ks0 * 16) + cc);
     };
     auto a_store = [&]() {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
+        for (int i = 0; i < 8 * MT; ++i) {
             u32x4 v = xa[i];
             if constexpr (PRO) {
+                float rs;
+                if constexpr (MT == 1) rs = rs8[i];
+                else rs = reinterpret_cast<const float*>(lds + NW * kWaveLdsT)[4 * i + ar];
 #pragma unroll
                 for (int w = 0; w < 4; ++w) {
                     // y = bf16(bf16(h * rstd) * weight), element by element (two bf16 per dword)
                     const float h0 = __uint_as_float(v[w] << 16), h1 = __uint_as_float(v[w] & 0xffff0000u);
                     const float g0 = __uint_as_float(nwv[w] << 16), g1 = __uint_as_float(nwv[w] & 0xffff0000u);
-                    const float n0 = bf16_to_f32(f32_to_bf16(h0 * rs8[i])), n1 = bf16_to_f32(f32_to_bf16(h1 * rs8[i]));
+                    const float n0 = bf16_to_f32(f32_to_bf16(h0 * rs)), n1 = bf16_to_f32(f32_to_bf16(h1 * rs));
                     v[w] = pack2(n0 * g0, n1 * g1);
                 }
             }
@@ -214,17 +246,23 @@ __global__ __launch_bounds__(64 * NW, 4) void tile_gemm_kernel(const TileParams 
         }
     };
 
-    f32x16 acc;
+    f32x16 acc[MT][NT];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
 
-    bf16x8 wr[8];
+    bf16x8 wr[NT][8];
     a_load(0);
 #pragma unroll
-    for (int s = 0; s < 8; ++s) {
-        const u32x4 v = ld_w<WNT>(wbase + (s < ksteps_w ? s : ksteps_w - 1) * 512 + lane * 8);
-        wr[s] = *reinterpret_cast<const bf16x8*>(&v);
-    }
+    for (int s = 0; s < 8; ++s)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const u32x4 v = ld_w<WNT>(wbase[nt] + (s < ksteps_w ? s : ksteps_w - 1) * 512 + lane * 8);
+            wr[nt][s] = *reinterpret_cast<const bf16x8*>(&v);
+        }
     const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
     const unsigned char* a_frag = my_lds + j * kPitch + kh * 16;
 #pragma unroll 1
@@ -235,124 +273,145 @@ __global__ __launch_bounds__(64 * NW, 4) void tile_gemm_kernel(const TileParams 
 #pragma unroll
         for (int st = 0; st < 8; ++st) {
             const bool live = st < nst;                               // wave-uniform; only the last chunk can be short
-            bf16x8 b = wr[st];
             const int nxt = c * 8 + st + 8;
-            const u32x4 v = ld_w<WNT>(wbase + (nxt < ksteps_w ? nxt : ksteps_w - 1) * 512 + lane * 8);
-            wr[st] = *reinterpret_cast<const bf16x8*>(&v);
-            bf16x8 a = *reinterpret_cast<const bf16x8*>(a_frag + st * 32);
-            if (!live) {                                              // stale LDS may hold NaN: 0 x 0, not 0 x garbage
-                a = zero8;
-                b = zero8;
+            bf16x8 b[NT], a[MT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                b[nt] = wr[nt][st];
+                const u32x4 v = ld_w<WNT>(wbase[nt] + (nxt < ksteps_w ? nxt : ksteps_w - 1) * 512 + lane * 8);
+                wr[nt][st] = *reinterpret_cast<const bf16x8*>(&v);
             }
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) a[mt] = *reinterpret_cast<const bf16x8*>(a_frag + mt * 32 * kPitch + st * 32);
+            if (!live) {                                              // stale LDS may hold NaN: 0 x 0, not 0 x garbage
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) a[mt] = zero8;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) b[nt] = zero8;
+            }
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mt], b[nt], acc[mt][nt], 0, 0, 0);
         }
     }
 
-    // ---- the 8 partial tiles -> LDS (each wavefront overwrites its own, fully consumed, activation image)
-    // acc[r] = D[row (r&3) + 8*(r>>2) + 4*kh][column j]
+    // ---- the NW partial tiles (x MT x NT sub-tiles) -> LDS (each wavefront overwrites its own, fully consumed,
+    // activation image).  acc[mt][nt][r] = D[row mt*32 + (r&3) + 8*(r>>2) + 4*kh][column nt*32 + j]
     float* red = reinterpret_cast<float*>(my_lds);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) red[((r & 3) + 8 * (r >> 2) + 4 * kh) * 32 + j] = acc[r];
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                red[(mt * NT + nt) * 1024 + ((r & 3) + 8 * (r >> 2) + 4 * kh) * 32 + j] = acc[mt][nt][r];
     __syncthreads();
 
-    if (NW > 8 && tid >= 512) return;                     // 512 threads finish the 32 x 32 tile (one column pair each)
+    if (NW > 8 && tid >= 512) return;                     // 512 threads finish each 32 x 32 sub-tile (one column pair each)
     const int row = tid >> 4, cp = tid & 15;
-    const int gm = m0 + row;
-    auto tile_sum2 = [&](int col) -> f32x2 {              // columns col, col+1 of row `row`, summed in wave order
-        f32x2 s = {0.f, 0.f};
+#pragma unroll 1
+    for (int sub = 0; sub < MT * NT; ++sub) {
+        const int tn = tn0 + sub % NT;
+        const int gm = m0 + 32 * (sub / NT) + row;
+        const unsigned char* part = lds + sub * 4096;         // this sub-tile inside every wave's image
+        auto tile_sum2 = [&](int col) -> f32x2 {              // columns col, col+1 of row `row`, summed in wave order
+            f32x2 s = {0.f, 0.f};
 #pragma unroll
-        for (int w = 0; w < kNW; ++w)
-            s += *reinterpret_cast<const f32x2*>(lds + w * kWaveLds + (row * 32 + col) * 4);
-        return s;
-    };
-    auto tile_sum1 = [&](int col) -> float {
-        float s = 0.f;
+            for (int w = 0; w < kNW; ++w)
+                s += *reinterpret_cast<const f32x2*>(part + w * kWaveLdsT + (row * 32 + col) * 4);
+            return s;
+        };
+        auto tile_sum1 = [&](int col) -> float {
+            float s = 0.f;
 #pragma unroll
-        for (int w = 0; w < kNW; ++w) s += *reinterpret_cast<const float*>(lds + w * kWaveLds + (row * 32 + col) * 4);
-        return s;
-    };
+            for (int w = 0; w < kNW; ++w) s += *reinterpret_cast<const float*>(part + w * kWaveLdsT + (row * 32 + col) * 4);
+            return s;
+        };
 
-    if constexpr (EPI == FL_SWIGLU) {
-        const int I = p.N >> 1;
-        const int i = tn * 16 + cp;
-        const float h1 = bf16_to_f32(f32_to_bf16(tile_sum1(cp)));
-        const float h3 = bf16_to_f32(f32_to_bf16(tile_sum1(16 + cp)));
-        if (gm < p.M && i < I) p.out[(int64_t)gm * p.ldo + i] = f32_to_bf16(silu_bf16(h1) * h3);
-        return;
-    } else {
-        const int n = tn * 32 + 2 * cp;
-        f32x2 s = tile_sum2(2 * cp);
-        if (p.bias) {
-            s[0] += bf16_to_f32(p.bias[n]);
-            s[1] += bf16_to_f32(p.bias[n + 1]);
-        }
-        if (gm >= p.M) return;
-        // the linear's own output, rounded to bf16 as nn.Linear returns it
-        const float o0 = bf16_to_f32(f32_to_bf16(s[0])), o1 = bf16_to_f32(f32_to_bf16(s[1]));
-        if constexpr (EPI == FL_NONE) {
-            *reinterpret_cast<unsigned int*>(p.out + (int64_t)gm * p.ldo + n) = pack2(o0, o1);
-        } else if constexpr (EPI == FL_RESID) {
-            const unsigned int rv = *reinterpret_cast<const unsigned int*>(p.resid + (int64_t)gm * p.ldr + n);
-            const float r0 = __uint_as_float(rv << 16), r1 = __uint_as_float(rv & 0xffff0000u);
-            const float h0 = bf16_to_f32(f32_to_bf16(r0 + o0)), h1 = bf16_to_f32(f32_to_bf16(r1 + o1));
-            *reinterpret_cast<unsigned int*>(p.out + (int64_t)gm * p.ldo + n) = pack2(h0, h1);
-            if (p.ssq_out) {
-                // sum of squares of this tile's 32 columns of row gm (the 16 lanes of the row, fixed butterfly order)
-                float q = h0 * h0 + h1 * h1;
-                q += __shfl_xor(q, 1);
-                q += __shfl_xor(q, 2);
-                q += __shfl_xor(q, 4);
-                q += __shfl_xor(q, 8);
-                if (cp == 0) p.ssq_out[(int64_t)gm * p.n_tiles + tn] = q;
+        if constexpr (EPI == FL_SWIGLU) {
+            const int I = p.N >> 1;
+            const int i = tn * 16 + cp;
+            const float h1 = bf16_to_f32(f32_to_bf16(tile_sum1(cp)));
+            const float h3 = bf16_to_f32(f32_to_bf16(tile_sum1(16 + cp)));
+            if (gm < p.M && i < I) p.out[(int64_t)gm * p.ldo + i] = f32_to_bf16(silu_bf16(h1) * h3);
+            continue;
+        } else {
+            const int n = tn * 32 + 2 * cp;
+            f32x2 s = tile_sum2(2 * cp);
+            if (p.bias) {
+                s[0] += bf16_to_f32(p.bias[n]);
+                s[1] += bf16_to_f32(p.bias[n + 1]);
             }
-        } else {                                            // FL_ROPE_APPEND
-            const int HD = p.H * p.D, KD = p.KH * p.D;
-            const int b = gm / p.rows_per_req, jrow = gm - b * p.rows_per_req;
-            const bool is_v = n >= HD + KD;
-            float y0 = o0, y1 = o1;
-            if (!is_v) {
-                int pos = p.offsets[b] + jrow;
-                pos = pos < 0 ? 0 : (pos >= p.max_pos ? p.max_pos - 1 : pos);
-                const int d = (n < HD ? n : n - HD) % p.D;          // even: (d, d+1) is one interleaved pair
-                const f32x2 cs = *reinterpret_cast<const f32x2*>(p.cos_sin + (int64_t)pos * p.D + d);
-                y0 = __fsub_rn(__fmul_rn(o0, cs[0]), __fmul_rn(o1, cs[1]));
-                y1 = __fadd_rn(__fmul_rn(o1, cs[0]), __fmul_rn(o0, cs[1]));
-            }
-            if (n < HD) {
-                *reinterpret_cast<unsigned int*>(p.out + (int64_t)gm * p.ldo + n) = pack2(y0, y1);
-                return;
-            }
-            const int nn = is_v ? n - HD - KD : n - HD;
-            const int h = nn / p.D, d = nn - h * p.D;
-            const int64_t half = (int64_t)p.page_size * KD;
-            bool over;
-            const int64_t d1 = kv_elem_offset(p.t1, b, p.rows_per_req, jrow, p.page_size, p.KH, p.D, h, d, p.hnd != 0,
-                                              &over);
-            // one count per dropped row (as md_rope_append): the thread holding the row's first K pair reports it
-            if (over && !is_v && nn == 0) atomicAdd(p.overflow, 1u);
-            // what the cache receives is the bf16 tensor k / v of the reference (RoPE output rounded to bf16) -- an fp8
-            // page quantises THAT value, not the fp32 rotation result (md_rope_append does the same)
-            y0 = bf16_to_f32(f32_to_bf16(y0));
-            y1 = bf16_to_f32(f32_to_bf16(y1));
-            if (d1 >= 0) {
-                float inv = 1.f;
-                if constexpr (FP8) inv = 1.0f / (is_v ? p.v_scale[h] : p.k_scale[h]);
-                store_pair<FP8>(p.t1.cache, d1 + (is_v ? half : 0), y0, y1, inv);
-            }
-            if (p.t2.cache) {                                 // second cache (self-speculation draft cache): bf16, NHD
-                const int64_t d2 = kv_elem_offset(p.t2, b, p.rows_per_req, jrow, p.page_size, p.KH, p.D, h, d, false,
+            if (gm >= p.M) continue;
+            // the linear's own output, rounded to bf16 as nn.Linear returns it
+            const float o0 = bf16_to_f32(f32_to_bf16(s[0])), o1 = bf16_to_f32(f32_to_bf16(s[1]));
+            if constexpr (EPI == FL_NONE) {
+                *reinterpret_cast<unsigned int*>(p.out + (int64_t)gm * p.ldo + n) = pack2(o0, o1);
+            } else if constexpr (EPI == FL_RESID) {
+                const unsigned int rv = *reinterpret_cast<const unsigned int*>(p.resid + (int64_t)gm * p.ldr + n);
+                const float r0 = __uint_as_float(rv << 16), r1 = __uint_as_float(rv & 0xffff0000u);
+                const float h0 = bf16_to_f32(f32_to_bf16(r0 + o0)), h1 = bf16_to_f32(f32_to_bf16(r1 + o1));
+                *reinterpret_cast<unsigned int*>(p.out + (int64_t)gm * p.ldo + n) = pack2(h0, h1);
+                if (p.ssq_out) {
+                    // sum of squares of this tile's 32 columns of row gm (the 16 lanes of the row, fixed butterfly order)
+                    float q = h0 * h0 + h1 * h1;
+                    q += __shfl_xor(q, 1);
+                    q += __shfl_xor(q, 2);
+                    q += __shfl_xor(q, 4);
+                    q += __shfl_xor(q, 8);
+                    if (cp == 0) p.ssq_out[(int64_t)gm * p.n_tiles + tn] = q;
+                }
+            } else {                                            // FL_ROPE_APPEND
+                const int HD = p.H * p.D, KD = p.KH * p.D;
+                const int b = gm / p.rows_per_req, jrow = gm - b * p.rows_per_req;
+                const bool is_v = n >= HD + KD;
+                float y0 = o0, y1 = o1;
+                if (!is_v) {
+                    int pos = p.offsets[b] + jrow;
+                    pos = pos < 0 ? 0 : (pos >= p.max_pos ? p.max_pos - 1 : pos);
+                    const int d = (n < HD ? n : n - HD) % p.D;          // even: (d, d+1) is one interleaved pair
+                    const f32x2 cs = *reinterpret_cast<const f32x2*>(p.cos_sin + (int64_t)pos * p.D + d);
+                    y0 = __fsub_rn(__fmul_rn(o0, cs[0]), __fmul_rn(o1, cs[1]));
+                    y1 = __fadd_rn(__fmul_rn(o1, cs[0]), __fmul_rn(o0, cs[1]));
+                }
+                if (n < HD) {
+                    *reinterpret_cast<unsigned int*>(p.out + (int64_t)gm * p.ldo + n) = pack2(y0, y1);
+                    continue;
+                }
+                const int nn = is_v ? n - HD - KD : n - HD;
+                const int h = nn / p.D, d = nn - h * p.D;
+                const int64_t half = (int64_t)p.page_size * KD;
+                bool over;
+                const int64_t d1 = kv_elem_offset(p.t1, b, p.rows_per_req, jrow, p.page_size, p.KH, p.D, h, d, p.hnd != 0,
                                                   &over);
+                // one count per dropped row (as md_rope_append): the thread holding the row's first K pair reports it
                 if (over && !is_v && nn == 0) atomicAdd(p.overflow, 1u);
-                if (d2 >= 0) store_pair<false>(p.t2.cache, d2 + (is_v ? half : 0), y0, y1, 1.f);
+                // what the cache receives is the bf16 tensor k / v of the reference (RoPE output rounded to bf16) -- an fp8
+                // page quantises THAT value, not the fp32 rotation result (md_rope_append does the same)
+                y0 = bf16_to_f32(f32_to_bf16(y0));
+                y1 = bf16_to_f32(f32_to_bf16(y1));
+                if (d1 >= 0) {
+                    float inv = 1.f;
+                    if constexpr (FP8) inv = 1.0f / (is_v ? p.v_scale[h] : p.k_scale[h]);
+                    store_pair<FP8>(p.t1.cache, d1 + (is_v ? half : 0), y0, y1, inv);
+                }
+                if (p.t2.cache) {                                 // second cache (self-speculation draft cache): bf16, NHD
+                    const int64_t d2 = kv_elem_offset(p.t2, b, p.rows_per_req, jrow, p.page_size, p.KH, p.D, h, d, false,
+                                                      &over);
+                    if (over && !is_v && nn == 0) atomicAdd(p.overflow, 1u);
+                    if (d2 >= 0) store_pair<false>(p.t2.cache, d2 + (is_v ? half : 0), y0, y1, 1.f);
+                }
             }
         }
     }
 }
 
-template <int EPI, bool FP8, int NW, bool WNT, bool PRO>
+template <int EPI, bool FP8, int NW, bool WNT, bool PRO, int MT = 1, int NT = 1>
 int launch_tile_cfg(const TileParams& p, hipStream_t st) {
-    constexpr int lds = NW * kWaveLds + (PRO ? 128 : 0);
-    auto k = tile_gemm_kernel<EPI, FP8, NW, WNT, PRO>;
+    constexpr int lds = NW * MT * kWaveLds + (PRO ? 128 * MT : 0);
+    auto k = tile_gemm_kernel<EPI, FP8, NW, WNT, PRO, MT, NT>;
     static MdPerDeviceOnce once;
     if (once.first()) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds) !=
@@ -362,15 +421,28 @@ int launch_tile_cfg(const TileParams& p, hipStream_t st) {
             return MD_ERR_LAUNCH;
         }
     }
-    const int grid = ((p.n_tiles + 7) / 8) * 8 * p.m_tiles;
+    const int m_groups = (p.m_tiles + MT - 1) / MT, n_groups = p.n_tiles / NT;
+    const int grid = ((n_groups + 7) / 8) * 8 * m_groups;
     hipLaunchKernelGGL(k, dim3(grid), dim3(64 * NW), lds, st, p);
     return MD_OK;
 }
 
 int g_force_nw = 0;   // dev knob (md_debug_set_fused_nw): 0 = the rule below, 8 / 16 = forced where the shape allows
 
+int g_force_tile = 0; // dev knob (md_debug_set_fused_nw 11 / 22): force 1 x 1 / 2 x 2 tiles where the shape allows
+
 template <int EPI, bool FP8, bool PRO>
 int launch_tile_pro(const TileParams& p, hipStream_t st) {
+    // 2 x 2 tiles (64 rows x 64 columns per workgroup, one per CU): when the M range has two 32-row tiles and the 64-column
+    // groups alone still give (nearly) every CU a workgroup -- the ingest-bound wide products of a 64-row step (the 1B
+    // w1|w3: 256 groups).  Narrow products keep 1 x 1 tiles: more, smaller workgroups matter more there.
+    if constexpr (EPI == FL_SWIGLU || EPI == FL_NONE || EPI == FL_RESID) {
+        const int groups = (p.n_tiles / 2) * ((p.m_tiles + 1) / 2);
+        bool t22 = p.m_tiles >= 2 && p.n_tiles % 2 == 0 && p.K % 128 == 0 && groups >= 192;
+        if (g_force_tile == 11) t22 = false;
+        if (g_force_tile == 22) t22 = p.n_tiles % 2 == 0 && p.K % 128 == 0;
+        if (t22) return launch_tile_cfg<EPI, FP8, 8, false, PRO, 2, 2>(p, st);
+    }
     // 16 wavefronts (K/16 slices) when the grid is too small to put two 8-wave workgroups on every CU
     const int wgs = p.n_tiles * p.m_tiles;
     bool nw16 = p.K % 256 == 0 && wgs <= 384;
@@ -395,7 +467,10 @@ bool aligned16(const void* q) { return ((uintptr_t)q & 15) == 0; }
 }  // namespace
 
 #ifdef MD_DEV_KNOBS
-extern "C" void md_debug_set_fused_nw(int nw) { g_force_nw = (nw == 8 || nw == 16) ? nw : 0; }
+extern "C" void md_debug_set_fused_nw(int nw) {
+    g_force_nw = (nw == 8 || nw == 16) ? nw : (nw == 11 ? 8 : 0);     // 11: 1 x 1 tiles AND 8 K slices (what 2 x 2 uses)
+    g_force_tile = (nw == 11 || nw == 22) ? nw : 0;
+}
 #endif
 
 extern "C" int md_linear_fused_supported(int M, int N, int K, int epilogue) {

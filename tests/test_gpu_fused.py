@@ -255,3 +255,36 @@ def test_deferred_rmsnorm_resid_then_qkv_rope_append(ops, B, n, H, KH, D, dim):
     _close_bf16(got_q, want_q, f"q_rot B={B} n={n} D={D}")
     _close_bf16(cb, ca, f"cache B={B} n={n} D={D}")
     assert not torch.equal(bits(cb), bits(d(cache)))
+
+
+@pytest.mark.parametrize("M,N,K", [(64, 2048, 2048), (33, 1024, 512), (100, 512, 1792), (256, 4096, 1024), (1, 64, 128),
+                                   (64, 16384, 2048)])
+def test_fused_2x2_tiles_bit_identical_to_1x1(ops, M, N, K):
+    """Round 4: a workgroup may own 2 x 2 MFMA tiles (64 rows x 64 columns: half the per-CU ingest of the wide 64-row
+    products).  The K slices, their summation order and the epilogues are those of the 1 x 1 form, so every output --
+    plain, residual (+ the partial sums of squares), SwiGLU, SwiGLU with the deferred RMSNorm -- must be BIT-IDENTICAL
+    between the two decompositions (md_debug_set_fused_nw 11 / 22 force them)."""
+    lib = ops._lib.load()
+    g = torch.Generator().manual_seed(M * 7 + N + K)
+    x = d(torch.randn(M, K, generator=g).to(BF))
+    w = d((torch.randn(N, K, generator=g) * 0.05).to(BF))
+    b = d(torch.randn(N, generator=g).to(BF))
+    resid = d(torch.randn(M, N, generator=g).to(BF))
+    nw = d((1 + 0.1 * torch.randn(K, generator=g)).to(BF))
+    ssq_in = d(torch.rand(M, K // 32, generator=g) * 32.0)
+    pw, pw13 = ops.PackedWeight(w), ops.PackedWeight(w, swiglu=True)
+    outs = {}
+    try:
+        for knob in (11, 22):
+            lib.md_debug_set_fused_nw(knob)
+            plain = ops.fused_linear(x, pw, b)
+            h, ssq = ops.fused_linear(x, pw, b, resid=resid, want_ssq=True)
+            sw = ops.fused_linear(x, pw13, swiglu=True)
+            swn = ops.fused_linear(x, pw13, swiglu=True, pro=ops.DeferredNorm(x, ssq_in, nw, 1e-5))
+            outs[knob] = (plain, h, ssq, sw, swn)
+    finally:
+        lib.md_debug_set_fused_nw(0)
+    for a, c, what in zip(outs[11], outs[22], ("plain", "resid", "ssq", "swiglu", "swiglu+norm")):
+        assert torch.equal(a.view(torch.int32 if a.dtype == torch.float32 else torch.int16),
+                           c.view(torch.int32 if c.dtype == torch.float32 else torch.int16)), what
+    assert not torch.isnan(outs[22][4].float()).any()

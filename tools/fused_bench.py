@@ -21,6 +21,7 @@ from magicdec_amd.Engine.utils import enable_tuned_gemms   # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--only", default="")
 ap.add_argument("--iters", type=int, default=30)
+ap.add_argument("--tiles", type=int, default=0, help="1: also time md_linear_fused with 1 x 1 and 2 x 2 tiles forced (dev knob)")
 a = ap.parse_args()
 print("tuned GEMM table loaded:", enable_tuned_gemms())
 dev = "cuda"
@@ -130,6 +131,14 @@ for model, tp, M in CASES:
         t_u = timeit(unfused, a.iters)
         t_s = timeit(skinny, a.iters) if skinny_ok else float("nan")
         t_f = timeit(fused, a.iters)
+        extra = ""
+        if a.tiles:
+            import ctypes
+            lib = _lib.load()
+            for knob in (11, 22):
+                lib.md_debug_set_fused_nw(ctypes.c_int(knob))
+                extra += f" | tiles {knob}: {timeit(fused, a.iters):6.1f}"
+            lib.md_debug_set_fused_nw(ctypes.c_int(0))
         print(f"{tag + ' ' + kind:22s} {M:4d} {N:6d} {K:6d} {nbytes / 1e6:6.1f} | {t_u:10.1f} | {t_s:9.1f} | {t_f:8.1f} | "
-              f"{t_f / t_u:5.2f}", flush=True)
+              f"{t_f / t_u:5.2f}" + extra, flush=True)
         del wl, pk
