@@ -873,6 +873,10 @@ __global__ __launch_bounds__(64 * NW, 2) void prefill_attn_kernel(const AttnPara
 //                 group reads a [4 keys][16 d] block: keys 16 s + 4 kh + {0..3} and + 8), B = P^T: registers
 //                 8 s .. 8 s + 7 of the S accumulator ARE the k-slots of 16-key step s -- no cross-lane movement.
 // Staging, double buffering, the one barrier per tile and the causal bookkeeping are those of prefill_attn_kernel.
+// Round 4, measured and NOT kept (profiles/r04_prefill_pipelined_rejected.txt): the tile loop software-pipelined inside a
+// wave -- softmax of tile t between the MFMAs of S(t+1), ring of three K/V images, sched_group_barrier-pinned: 589-605
+// TFLOP/s at 64 keys (40 registers spilled: the Q fragments come back from scratch inside the loop), 661 at 32 keys against
+// 667-685 for the un-pipelined 32-key form and 883-929 for this kernel at 128 keys.
 // Measured and NOT kept (same box, profiles/r03_prefill_mfma32_ab.txt): s_setprio(1) around the MFMA clusters (808 vs 820
 // TFLOP/s), the causal mask as a compile-time property of the tile body (two bodies: 480 -- the register file again), the
 // MFMAs of one accumulator issued back to back instead of alternating accumulators (795 vs 817).
