@@ -85,7 +85,10 @@ def parse():
                          "kv head contiguous -- same tokens, verify attention 85 %% instead of 82 %% of the HBM peak "
                          "(bf16), 81 %% instead of 71 %% (fp8), profiles/r02_layout_ab.txt; NHD = the reference's "
                          "flashinfer layout (DESIGN.md section 3.1)")
-    ap.add_argument("--draft-tp", type=int, default=4, help="size of the draft sub-group (reference README: 4 of 8)")
+    ap.add_argument("--draft-tp", type=int, default=4,
+                    help="size of the draft sub-group (reference README: 4 of 8); 0 = REPLICATED draft: every rank runs "
+                         "the whole draft model (no draft collectives, no token broadcast; greedy drafting is "
+                         "deterministic, so all ranks draft the same tokens)")
     ap.add_argument("--pmc", dest="pmc", action="store_true", default=None,
                     help="measure roofline.traffic live: two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of the "
                          "verify-attention launch at this run's shard shape in a subprocess (tools/attn_bench.py); "
@@ -208,10 +211,11 @@ def run(args, dev):
     use_tp = world > 1 or getattr(args, "force_tp", False) or emu > 1
     group = draft_group = None
     rank_group = list(range(emu if emu > 1 else world))
-    draft_ranks = list(range(min(len(rank_group), args.draft_tp)))
+    replicate_draft = args.draft_tp == 0
+    draft_ranks = list(rank_group) if replicate_draft else list(range(min(len(rank_group), args.draft_tp)))
     if use_tp:
         from magicdec_amd.Engine.tp import init_dist
-        _, group, draft_group = init_dist([0] if emu > 1 else draft_ranks)
+        _, group, draft_group = init_dist([0] if (emu > 1 or replicate_draft) else draft_ranks)
     in_draft = rank in draft_ranks
     # Collective of the per-layer partial sums: RCCL unless MAGICDEC_ONESHOT_AR=1 (Engine/oneshot.py; validated
     # against RCCL at start-up, falls back on any disagreement).  Not the default: one-shot pulls (N-1) x the message
@@ -240,7 +244,7 @@ def run(args, dev):
         engine.setup_caches(max_batch_size=B, max_seq_length=ML, kv_dtype=args.kv_dtype, kv_layout=kv_layout)
     draft = None
     if in_draft and not selfspec:
-        draft_tp = len(draft_ranks) > 1 or getattr(args, "force_tp", False)
+        draft_tp = (not replicate_draft) and (len(draft_ranks) > 1 or getattr(args, "force_tp", False))
         if streaming:
             from magicdec_amd.Engine.StreamingLLM.backend_draft import LMBackend_Draft as StreamDraft
             draft = StreamDraft(dtype=torch.bfloat16, device=dev)
@@ -313,7 +317,7 @@ def run(args, dev):
             dist.barrier()
         _sync(dev)
 
-    bcast = (draft_ranks[0], group) if (use_tp and len(draft_ranks) != len(rank_group)) else None
+    bcast = (draft_ranks[0], group) if (use_tp and len(draft_ranks) != len(rank_group)) else None   # replicated: None
 
     def iteration(next_double, forced):
         """One speculative iteration across the TP group (draft sub-group drafts, tokens broadcast, all verify)."""
@@ -466,7 +470,8 @@ def run(args, dev):
                                 f"budget {BUDGET} gamma {G}, B={B} prefix={S} max_len={ML}") if selfspec else
                                (f"{args.workload}: {tgt_name} target TP{len(rank_group)} + {drf_name} "
                                 f"{'StreamingLLM' if streaming else 'SnapKV'} draft "
-                                f"TP{len(draft_ranks)} budget {BUDGET} gamma {G}, B={B} prefix={S} max_len={ML}"),
+                                f"{'replicated on every rank' if replicate_draft and use_tp else 'TP' + str(len(draft_ranks))} "
+                                f"budget {BUDGET} gamma {G}, B={B} prefix={S} max_len={ML}"),
                    "acceptance": f"fixed replay alpha={args.alpha} (E[tokens/iter]={tok_replay / args.steps / B:.3f})",
                    "weights": "seeded random init (no checkpoints on the box)",
                    "hip_graphs": bool(engine._use_graphs),
@@ -481,7 +486,8 @@ def run(args, dev):
                    "allreduce": (None if not use_tp else
                                  "oneshot-ipc" if getattr(engine.model, "_oneshot", None) is not None else "rccl"),
                    "allreduce_timeouts": ar_timeouts,
-                   "allreduce_plan": allreduce_plan(engine, draft, B, G, len(rank_group), len(draft_ranks)) if use_tp
+                   "allreduce_plan": allreduce_plan(engine, draft, B, G, len(rank_group),
+                                                    1 if replicate_draft else len(draft_ranks)) if use_tp
                    else None},
         "speedup_vs_autoregressive": round(value / base_tps, 4),
         "alpha_sensitivity": {f"{al:.1f}": {"tokens_per_s": round(tok / dt, 1), "speedup": round(tok / dt / base_tps, 3),
@@ -539,8 +545,9 @@ def allreduce_plan(engine, draft, B, G, tp, draft_tp):
         return {"rows": rows, "bytes": nbytes, "ranks": world, "per_forward": 2 * len(model.layers), "impl": algo}
     return {"verify": one(engine.model, B * (G + 1), tp), "autoregressive": one(engine.model, B, tp),
             "draft_step": one(draft.model if draft is not None else None, B, draft_tp),
-            "argmax_merge": "2 x rccl all_reduce of [rows, ranks] per forward", "draft_tokens": "rccl broadcast per iteration"
-            if draft_tp != tp else None}
+            "argmax_merge": "2 x rccl all_reduce of [rows, ranks] per forward",
+            "draft_tokens": ("rccl broadcast per iteration" if draft_tp not in (1, tp) else
+                             ("none: the draft model is replicated on every rank" if draft_tp == 1 and tp > 1 else None))}
 
 
 def collective_microbench_isolated(shapes, iters=30, timeout_s=240, dry=False):

@@ -61,6 +61,11 @@ def longspec_parser(kind="SnapKV"):
     _common(parser, "longspec", kind)
     parser.add_argument('--target', type=Path, default=_CKPT_8B, help='target model')
     parser.add_argument('--draft_rank_group', nargs='+', type=int, help='Draft group of ranks')
+    # not in the reference: every rank of --rank_group runs the WHOLE draft model (no draft-side collectives, no
+    # per-iteration token broadcast; greedy drafting is deterministic, so all ranks draft the same tokens).  Needs
+    # --draft_rank_group to name at least two ranks only because the reference keys `use_tp` on it (kept verbatim).
+    parser.add_argument('--replicate_draft', action='store_true',
+                        help='run the whole draft model on every target rank instead of sharding it over --draft_rank_group')
     return parser
 
 
@@ -128,7 +133,8 @@ def longspec_main(kind: str, argv=None):
         DEVICE = f"cuda:{rank}" if torch.cuda.is_available() else "cpu"
     setup_seed(args.seed)
     print_(f"Using device={DEVICE}")
-    draft_target_equal = len(args.draft_rank_group) == len(args.rank_group)
+    replicate = bool(getattr(args, "replicate_draft", False)) and use_tp
+    draft_target_equal = len(args.draft_rank_group) == len(args.rank_group) or replicate
     MAX_LEN_TARGET, BATCH_SIZE, DTYPE = args.max_len, args.B, torch.bfloat16
 
     from .Engine.SnapKV.backend import LMBackend
@@ -144,12 +150,13 @@ def longspec_main(kind: str, argv=None):
                         kv_layout=args.kv_layout)
 
     draft = None
-    if (not use_tp) or rank in args.draft_rank_group:
+    if (not use_tp) or replicate or rank in args.draft_rank_group:
         if kind == "SnapKV":
             draft = LMBackend_Draft(dtype=DTYPE, device=DEVICE, draft_budget=args.draft_budget)
         else:
             draft = LMBackend_Draft(dtype=DTYPE, device=DEVICE)
-        draft.load_model(args.model, use_tp=use_tp and draft_tp, rank_group=args.draft_rank_group, group=draft_group)
+        draft.load_model(args.model, use_tp=use_tp and draft_tp and not replicate, rank_group=args.draft_rank_group,
+                         group=draft_group)
         if args.compile:
             draft.compile()
         if kind == "SnapKV":

@@ -417,7 +417,9 @@ ranks = list(range(world))
 kind = os.environ["MD_KIND"]                      # fixture name: run_longspec_snapkv_tp2 | run_selfspec_snapkv_tp2 | ...
 # each rank replays the reference's tie resolution for ITS kv heads (torch.topk's tie order is implementation-defined);
 # in the longspec layout only the draft sub-group runs the SnapKV select
-if "snapkv" in kind and (rank in draft_ranks or not kind.startswith("run_longspec")):
+if os.environ.get("MD_REPLICATE_DRAFT", "0") == "1":
+    pass                                          # no reference run to replay: torch.topk's own tie order
+elif "snapkv" in kind and (rank in draft_ranks or not kind.startswith("run_longspec")):
     name = f"{kind}.json" if rank == 0 else f"{kind}_topk_rank{rank}.json"
     cpu_ops.TOPK_REPLAY.update(table=gc.load_json(name)["snapkv_topk"], pos=0)
 log = []
@@ -427,13 +429,15 @@ if kind.startswith("run_longspec"):
     eng.load_model(ck / model / "model.pth", use_tp=True, rank_group=ranks, group=group)
     eng.setup_caches(max_batch_size=gc.B, max_seq_length=gc.MAX_LEN)
     td = None
-    if rank in draft_ranks:                       # tests/SnapKV/longspec_benchmark.py:96-103
+    replicate = os.environ.get("MD_REPLICATE_DRAFT", "0") == "1"      # --replicate_draft: the whole draft on every rank
+    if rank in draft_ranks or replicate:          # tests/SnapKV/longspec_benchmark.py:96-103
         drf = LMBackend_Draft(dtype=torch.bfloat16, device="cpu", draft_budget=gc.BUDGET)
-        drf.load_model(ck / model / "model.pth", use_tp=len(draft_ranks) > 1, rank_group=draft_ranks, group=dgroup)
+        drf.load_model(ck / model / "model.pth", use_tp=len(draft_ranks) > 1 and not replicate, rank_group=draft_ranks,
+                       group=dgroup)
         drf.setup_caches(max_batch_size=gc.B, max_seq_length=gc.MAX_LEN, draft_budget=gc.BUDGET)
         td = Tracer(drf, "SnapKV.LMBackend_Draft", log, ("encode", "inference"))
     te = Tracer(eng, "SnapKV.LMBackend", log, ("encode", "inference"))
-    bcast = (draft_ranks[0], group) if len(draft_ranks) != world else None      # longspec_benchmark.py:189
+    bcast = (draft_ranks[0], group) if (len(draft_ranks) != world and not replicate) else None   # longspec_benchmark.py:189
     for b_ids in gc.synthetic_batches():
         last, _ = harness.run_longspec_batch(te, td, b_ids, gc.GAMMA, gc.MAX_LEN, gc.EOT_1, gc.EOT_2, bcast=bcast,
                                              barrier=dist.barrier)
@@ -453,7 +457,9 @@ else:
     for b_ids in gc.synthetic_batches():
         last, _ = harness.run_selfspec_batch(te, b_ids, gc.GAMMA, gc.MAX_LEN, gc.EOT_1, gc.EOT_2, True)
 json.dump(dict(trace=log, final=dict(output=last.output.tolist(), num_nodes=last.num_nodes.tolist()),
-               local_heads=[eng.model.config.n_head, eng.model.config.n_local_heads]),
+               local_heads=[eng.model.config.n_head, eng.model.config.n_local_heads],
+               draft_heads=([drf.model.config.n_head, drf.model.config.n_local_heads]
+                            if kind.startswith("run_longspec") and td is not None else None)),
           open(os.path.join(os.environ["MD_OUT"], f"rank{rank}.json"), "w"))
 dist.barrier()
 dist.destroy_process_group()
@@ -569,6 +575,35 @@ def test_tensor_parallel_tp4_target_with_tp2_draft_subgroup_matches_reference_tr
     assert not any(r["cls"].endswith("LMBackend_Draft") for r in got[2]["trace"] + got[3]["trace"])
     for r in range(4):
         assert got[r]["final"] == j["final"]
+
+
+def test_tensor_parallel_target_with_replicated_draft(ckpt_dir):
+    """`--replicate_draft` (round 4, not in the reference): target TP2 over gloo, the WHOLE SnapKV draft model on both
+    ranks -- no draft-side collective, no per-iteration token broadcast.  Greedy drafting is deterministic, so both
+    ranks must stay in lock-step on their own: identical Engine-call traces (target and draft) and identical outputs;
+    the draft is unsharded on both; and because greedy speculative decoding returns the TARGET's greedy continuation
+    whatever the draft proposes, the final output equals the reference's TP2 run with its sharded draft
+    (tests/golden/run_longspec_snapkv_tp2.json)."""
+    import json
+    kind = "run_longspec_snapkv_tp2"
+    out = tempfile.mkdtemp(prefix="md_tp_repl_")
+    script = os.path.join(out, "worker.py")
+    Path(script).write_text(TP_SNAPKV_WORKER)
+    port = 29250 + (os.getpid() % 40)
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, LOCAL_RANK=str(r), LOCAL_WORLD_SIZE="2", RANK=str(r), WORLD_SIZE="2",
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), MD_ROOT=str(ROOT), MD_CKPT=str(ckpt_dir), MD_OUT=out,
+                   MD_KIND=kind, MD_REPLICATE_DRAFT="1", OMP_NUM_THREADS="2")
+        procs.append(subprocess.Popen([sys.executable, script], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    logs = [p.communicate(timeout=900)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(logs)
+    got = [json.load(open(os.path.join(out, f"rank{r}.json"))) for r in range(2)]
+    assert got[0]["trace"] == got[1]["trace"] and got[0]["final"] == got[1]["final"]
+    assert any(r["cls"].endswith("LMBackend_Draft") for r in got[1]["trace"])          # rank 1 drafts too
+    assert got[0]["draft_heads"] == got[1]["draft_heads"]
+    assert got[0]["draft_heads"][1] == 2 * got[0]["local_heads"][1]                     # draft: all kv heads; target: half
+    assert got[0]["final"] == gc.load_json(f"{kind}.json")["final"]
 
 
 # ------------------------------------------------------------------ checkpoint ingestion (SURVEY 8f-3)
@@ -1162,8 +1197,8 @@ def test_command_line_flags_and_defaults_equal_the_reference_scripts():
     with ast) exists in the product's parser for that script with the same type, nargs, action and DEFAULT -- the
     scripts differ (self-speculation defaults to B = 45, prefix 100000, gamma 7, budget 4097; StreamingLLM longspec to
     budget 1025; the baseline to B = 16, prefix 8065).  Deliberate differences: checkpoint paths are relative
-    ("checkpoints/...", not "/scratch/models/..."), and the product adds --kv_dtype / --kv_layout (and, for the
-    baseline, --dataset / --benchmark)."""
+    ("checkpoints/...", not "/scratch/models/..."), and the product adds --kv_dtype / --kv_layout (for the baseline
+    --dataset / --benchmark, for the two-model scripts --replicate_draft)."""
     from magicdec_amd import cli
     j = gc.load_json("cli_args.json")
     parsers = {"tests/SnapKV/longspec_benchmark.py": cli.longspec_parser("SnapKV"),
@@ -1189,7 +1224,8 @@ def test_command_line_flags_and_defaults_equal_the_reference_scripts():
                 assert repr(a.default) == ra["default"], (script, flag, a.default, ra["default"])
             else:
                 assert a.default is None, (script, flag, a.default)
-        allowed = extras | ({"--dataset", "--benchmark"} if "baseline" in script else set())
+        allowed = extras | ({"--dataset", "--benchmark"} if "baseline" in script else set()) \
+            | ({"--replicate_draft"} if "longspec" in script else set())
         assert set(acts) - {r["flags"][0] for r in ref_args} <= allowed, (script, set(acts) - {r["flags"][0] for r in ref_args})
 
 
