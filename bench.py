@@ -270,6 +270,29 @@ def run(args, dev):
     timer.n_verify = G + 1
     t_load = time.time() - t_load
 
+    # FIRST on a multi-GPU run, before the long phases (prefill ~20 s, the timed loops, the PMC passes): what one
+    # per-layer collective of this run costs, RCCL against the xGMI kernels -- these have never crossed a real link, and a
+    # short lease on an 8-GPU node should yield this report even if it yields nothing else (VERDICT r3 next #5c).  It goes
+    # to stderr and to gpurun_out/ at once, and into the JSON line at the end.
+    coll_report = None
+    if use_tp and world > 1 and on_gpu and os.environ.get("MAGICDEC_BENCH_COLLECTIVES", "1") != "0":
+        dim_t = engine.model.tok_embeddings.weight.shape[1]
+        dist.barrier()
+        _sync(dev)
+        shapes = [("verify", B * (G + 1), dim_t), ("autoregressive", B, dim_t)]
+        if drf_name is not None:          # the same list on every rank (ranks outside the draft group hold no draft model)
+            shapes.append(("draft_step", B, model_core.ModelArgs.from_name(drf_name).dim))
+        coll_report = collective_microbench_isolated(shapes)
+        if rank == 0:
+            print("[collectives_us] " + json.dumps(coll_report), file=sys.stderr, flush=True)
+            try:
+                os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+                with open(os.path.join(ROOT, "gpurun_out", f"collectives_us_n{world}.json"), "w") as f:
+                    json.dump(coll_report, f)
+            except OSError:
+                pass
+        dist.barrier()
+
     # synthetic PG-19-shaped batch: uniform token ids, BOS in column 0 (Data/data_converter.py:54), seed 123
     vocab = engine.model.tok_embeddings.weight.shape[0]
     g = torch.Generator().manual_seed(123)
@@ -513,15 +536,8 @@ def run(args, dev):
     }
     if rank == 0 and not args.no_cpu_baseline and world == 1 and not selfspec:
         line["cpu_baseline"] = cpu_baseline(tgt_name, drf_name, S, BUDGET, G, args.alpha)
-    if use_tp and world > 1 and on_gpu and os.environ.get("MAGICDEC_BENCH_COLLECTIVES", "1") != "0":
-        # after every number of the line has been taken: what one per-layer collective of this run costs, RCCL against
-        # the xGMI kernels (never run over real links before the first multi-GPU bench: this is where they get measured)
-        dim_t = engine.model.tok_embeddings.weight.shape[1]
-        dist.barrier()             # rank 0 arrives late (PMC passes): the children's time-out starts for all ranks together
-        _sync(dev)
-        coll = collective_microbench_isolated([("verify", B * (G + 1), dim_t), ("autoregressive", B, dim_t)])
-        if rank == 0:
-            line["collectives_us"] = coll
+    if coll_report is not None and rank == 0:
+        line["collectives_us"] = coll_report
     if use_tp:
         dist.barrier()
         dist.destroy_process_group()
