@@ -129,6 +129,22 @@ __device__ __forceinline__ int tab_index(float s) {
     return e < 16u ? (int)(((bits >> 15) << 11) | ((bits & 0x7fffu) - ((unsigned int)kTabE0 << 7))) : -1;
 }
 
+// Two scores at a time: `w` = two bf16 values in one dword (v_cvt_pk_bf16_f32).  Returns the two table BYTE offsets in the
+// halves of a dword and ORs into `bad` a non-zero pattern if either value lies outside the table.
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned int pack_bf16(float a, float b) {
+    const bf16x2 pk = {f32_to_bf16(a), f32_to_bf16(b)};
+    return *reinterpret_cast<const unsigned int*>(&pk);
+}
+__device__ __forceinline__ unsigned int tab_offsets2(unsigned int w, unsigned int& bad) {
+    const u16x2 base = {(unsigned short)(kTabE0 << 7), (unsigned short)(kTabE0 << 7)};
+    const u16x2 d = *reinterpret_cast<const u16x2*>(&w) - base;            // v_pk_sub_u16
+    const unsigned int u = *reinterpret_cast<const unsigned int*>(&d);
+    const unsigned int a = u & 0x7fff7fffu;                                // (exponent - E0) * 128 + mantissa per half
+    bad |= a & 0x78007800u;                                                // a half >= 2048: not one of the 16 binades
+    return (((u >> 4) & 0x08000800u) | a) << 3;                            // sign -> bit 11; x 8 bytes (no carry: < 2^15)
+}
+
 // (m, Z) <- merge of two partial softmax sums  sum exp(s - m)
 __device__ __forceinline__ void merge_mz(double& m, double& Z, double m2, double Z2) {
     const double mn = fmax(m, m2);
@@ -203,18 +219,24 @@ __global__ __launch_bounds__(64 * kSnapWaves, 4) void snapkv_stats_kernel(const 
                 for (int ks = 0; ks < D / 32; ++ks)
                     acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[ks], *reinterpret_cast<const bf16x8*>(qp + ks * 64),
                                                                   acc, 0, 0, 0);
-                // lane (lq, lc): row rt*16 + lq, columns col0 + lc*4 + j
-                float v[4];
-                int ti[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    v[j] = bf16_to_f32(f32_to_bf16(acc[j] * kscale));               // kscale = 1 for a bf16 cache
-                    ti[j] = tab_index(v[j]);
-                }
+                // lane (lq, lc): row rt*16 + lq, columns col0 + lc*4 + j; scores rounded to bf16 two per dword
+                const unsigned int w0 = pack_bf16(acc[0] * kscale, acc[1] * kscale);    // kscale = 1 for a bf16 cache
+                const unsigned int w1 = pack_bf16(acc[2] * kscale, acc[3] * kscale);
+                unsigned int bad = 0;
+                const unsigned int o0 = tab_offsets2(w0, bad), o1 = tab_offsets2(w1, bad);
+                const unsigned char* tb = reinterpret_cast<const unsigned char*>(tab);
                 // hot path, no divergence: every score of the wave's tile is in the table and no column can be masked
-                if (!tail && __builtin_amdgcn_ballot_w64((ti[0] | ti[1] | ti[2] | ti[3]) < 0) == 0) {
-                    zt[rt] += (tab[ti[0]] + tab[ti[1]]) + (tab[ti[2]] + tab[ti[3]]);
+                if (!tail && __builtin_amdgcn_ballot_w64(bad != 0) == 0) {
+                    zt[rt] += (*reinterpret_cast<const double*>(tb + (o0 & 0xffffu)) +
+                               *reinterpret_cast<const double*>(tb + (o0 >> 16))) +
+                              (*reinterpret_cast<const double*>(tb + (o1 & 0xffffu)) +
+                               *reinterpret_cast<const double*>(tb + (o1 >> 16)));
                 } else {
+                    const float v[4] = {bf16_bits_to_f32((unsigned short)(w0 & 0xffffu)), bf16_bits_to_f32((unsigned short)(w0 >> 16)),
+                                        bf16_bits_to_f32((unsigned short)(w1 & 0xffffu)), bf16_bits_to_f32((unsigned short)(w1 >> 16))};
+                    int ti[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) ti[j] = tab_index(v[j]);
                     const int rg = rt * 16 + lq;
                     double m2 = -INFINITY, z2 = 0.0;                 // this lane's out-of-table scores of the tile
 #pragma unroll
@@ -334,19 +356,28 @@ __global__ __launch_bounds__(64 * kSnapWaves, 4) void snapkv_accum_kernel(const 
                 acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(qp + ks * 64), kf[ks], acc,
                                                               0, 0, 0);
             // lane (lq, lc): rows rt*16 + lc*4 + j of column col0 + lq
-            float pj[4], v[4];
-            int ti[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                v[j] = bf16_to_f32(f32_to_bf16(acc[j] * kscale));
-                ti[j] = tab_index(v[j]);
-            }
+            float pj[4];
+            const unsigned int w0 = pack_bf16(acc[0] * kscale, acc[1] * kscale);
+            const unsigned int w1 = pack_bf16(acc[2] * kscale, acc[3] * kscale);
+            unsigned int bad = 0;
+            const unsigned int o0 = tab_offsets2(w0, bad), o1 = tab_offsets2(w1, bad);
+            const unsigned char* tb = reinterpret_cast<const unsigned char*>(tab);
             const double* rc = rowc + (rt * 16 + lc * 4) * 3;
-            if (fast_rows && !tail && __builtin_amdgcn_ballot_w64((ti[0] | ti[1] | ti[2] | ti[3]) < 0) == 0) {
+            float v[4];
+            int ti[4];
+            if (fast_rows && !tail && __builtin_amdgcn_ballot_w64(bad != 0) == 0) {
                 // hot path, no divergence: table value x the row's exp(-M) / Z
-#pragma unroll
-                for (int j = 0; j < 4; ++j) pj[j] = bf16_to_f32(f32_to_bf16((float)(tab[ti[j]] * rc[j * 3 + 2])));
+                pj[0] = bf16_to_f32(f32_to_bf16((float)(*reinterpret_cast<const double*>(tb + (o0 & 0xffffu)) * rc[2])));
+                pj[1] = bf16_to_f32(f32_to_bf16((float)(*reinterpret_cast<const double*>(tb + (o0 >> 16)) * rc[5])));
+                pj[2] = bf16_to_f32(f32_to_bf16((float)(*reinterpret_cast<const double*>(tb + (o1 & 0xffffu)) * rc[8])));
+                pj[3] = bf16_to_f32(f32_to_bf16((float)(*reinterpret_cast<const double*>(tb + (o1 >> 16)) * rc[11])));
             } else {
+                v[0] = bf16_bits_to_f32((unsigned short)(w0 & 0xffffu));
+                v[1] = bf16_bits_to_f32((unsigned short)(w0 >> 16));
+                v[2] = bf16_bits_to_f32((unsigned short)(w1 & 0xffffu));
+                v[3] = bf16_bits_to_f32((unsigned short)(w1 >> 16));
+#pragma unroll
+                for (int j = 0; j < 4; ++j) ti[j] = tab_index(v[j]);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     float pr = 0.f;
