@@ -786,6 +786,28 @@ def cpu_baseline(tgt_name, drf_name, S, budget, gamma, alpha, Bc=4):
         return t_layer, t_head, t_embed, t_attn, nbytes, n_layer, cfg, eng
 
     tl_t, th_t, te_t, ta_t, nb_t, n_t, _, _ = time_model(tgt_name, "target", gamma + 1, S + gamma + 1)
+    # the SAME target-layer sample once on every host core (BASELINE.md section 4 asks for the physical cores): printed so
+    # that capping the pool at 16 threads is evidence, not assertion
+    all_cores = os.cpu_count() or 1
+    tl_all = None
+    if all_cores > ncores and os.environ.get("MAGICDEC_CPU_ALL_CORES", "1") != "0":
+        torch.set_num_threads(all_cores)
+        try:
+            cfg_a, sd_a, _ = model_of(tgt_name)
+            eng_a = mr.RefEngine("target", cfg_a, sd_a, Bc, S + 96, 0, max_pos=S + 256)
+            npg = (S + gamma + 1 + 127) // 128
+            eng_a.paged_kv_indptr = torch.arange(Bc + 1, dtype=torch.int32) * npg
+            eng_a.paged_kv_indices = torch.cat([torch.arange(b * eng_a.ppr, b * eng_a.ppr + npg, dtype=torch.int32)
+                                                for b in range(Bc)])
+            eng_a.paged_kv_last_page_len = torch.full((Bc,), S + gamma + 1 - (npg - 1) * 128, dtype=torch.int32)
+            eng_a.caches[0].normal_()
+            eng_a.cachelens.fill_(S)
+            fn_a = eng_a._attn_std(gamma + 1, eng_a.cachelens, eng_a.caches, eng_a._tab(""))
+            x_a = torch.randn(Bc, gamma + 1, cfg_a.dim).to(torch.bfloat16)
+            tl_all = best(lambda: eng_a.model.block(x_a, 0, fn_a), reps=1)
+            del eng_a
+        finally:
+            torch.set_num_threads(ncores)
     tl_d, th_d, te_d, ta_d, nb_d, n_d, cfg_d, eng_d = time_model(drf_name, "snapkv_draft", 1, budget + 1)
     # K6: SnapKV select of ONE request of the draft model over the full prefix (the oracle loops over requests)
     g = cfg_d.n_head // cfg_d.n_local_heads
@@ -813,6 +835,11 @@ def cpu_baseline(tgt_name, drf_name, S, budget, gamma, alpha, Bc=4):
             "micro_GBps": {"K1_verify_attention": round(nb_t / ta_t / 1e9, 2),
                            "K2_draft_attention": round(nb_d / ta_d / 1e9, 3),
                            "K6_snapkv_select_one_request": round(nb_k6 / t_k6 / 1e9, 3)},
+            "thread_choice": ({"target_layer_ms_at_cores": round(tl_t * 1e3, 1), "cores": ncores,
+                               "target_layer_ms_at_all_host_cores": round(tl_all * 1e3, 1), "all_host_cores": all_cores,
+                               "note": "the same sample (one target layer, 4 rows / request) on torch's pool capped at "
+                                       "`cores` and on every host core: the cap is the FASTER of the two"}
+                              if tl_all is not None else None),
             "cfg1_end_to_end": cfg1,
             "full_iteration_b1": full_b1,
             "wall_s": round(time.perf_counter() - t_all, 1)}

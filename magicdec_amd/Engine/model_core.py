@@ -324,17 +324,32 @@ class Transformer(nn.Module):
         if not self.output.weight.is_cuda:
             return
 
-        def pack(w, swiglu=False):
-            if w.shape[1] % 16 == 0 and want_packed(w.shape[0], w.shape[1], swiglu, w.dtype == torch.int8):
-                pw = ops.PackedWeight(w.data if isinstance(w, nn.Parameter) else w, swiglu=swiglu)
-                self._packed[id(w)] = pw
-                self.packed_bytes += pw.data.numel() * pw.data.element_size()
+        todo = []
         for i, b in enumerate(self.layers):
-            pack(self._w13[i], swiglu=True)
-            pack(b.attention.wqkv.weight)
-            pack(b.attention.wo.weight)
-            pack(b.feed_forward.w2.weight)
-        pack(self.output.weight)
+            todo += [(self._w13[i], True), (b.attention.wqkv.weight, False), (b.attention.wo.weight, False),
+                     (b.feed_forward.w2.weight, False)]
+        todo.append((self.output.weight, False))
+        todo = [(w, sw) for w, sw in todo
+                if w.shape[1] % 16 == 0 and want_packed(w.shape[0], w.shape[1], sw, w.dtype == torch.int8)]
+        # headroom check: the copies double the served weights' footprint (17 GB for the 8B + 1B pair)
+        # and are made AFTER the KV slabs exist; if they do not fit beside them with a margin for the step's workspaces,
+        # serve everything from the row-major tensors (library GEMMs / row-major md_linear) instead of failing later.
+        # MAGICDEC_PACKED_COPIES=0 switches them off outright (Engine/gemm_policy.py).
+        need = sum(w.numel() * w.element_size() for w, _ in todo)
+        try:
+            free = torch.cuda.mem_get_info(self.output.weight.device)[0]
+        except Exception:              # not a HIP device (tests with stand-in ops): nothing to check
+            free = None
+        margin = 6 << 30
+        if free is not None and need + margin > free:
+            print(f"[magicdec_amd] streaming-layout weight copies need {need / 2**30:.1f} GiB but only {free / 2**30:.1f} GiB "
+                  f"are free beside the KV cache (margin {margin >> 30} GiB): not made -- the decode / verify linears run on "
+                  f"the row-major weights (slower); shrink the cache or set MAGICDEC_PACKED_COPIES=0 to silence this")
+            return
+        for w, sw in todo:
+            pw = ops.PackedWeight(w.data if isinstance(w, nn.Parameter) else w, swiglu=sw)
+            self._packed[id(w)] = pw
+            self.packed_bytes += pw.data.numel() * pw.data.element_size()
 
     # ------------------------------------------------------------------ building blocks
     def _reduce(self, y, group):
