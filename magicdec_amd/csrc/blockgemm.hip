@@ -30,6 +30,7 @@
 //   * the un-split product (w1|w3: 224 tiles) finishes in the kernel: accumulators -> LDS (fp32, the ring is free by
 //     then) -> 16-byte row-contiguous stores, SwiGLU with the reference's rounding points.
 #include "md_common.h"
+#include <type_traits>
 
 // gemm.hip / elementwise.hip: the split-K combine launches shared with md_linear
 int md_internal_launch_skinny_reduce(const float* partial, int S, int M, int N, int epilogue, const void* bias, void* out,
@@ -329,6 +330,11 @@ int pick_splits(int n_tiles, int nsteps) {
 // x ring 3 x 32 KB + W ring 4 x 16 KB = the CU's 160 KB.  Measured alternatives (same process, w1|w3 at M = 256,
 // profiles/r04_block_*): W ring 3 deep: equal; x 2 + W 6: 81 vs 70.5 us (one x stage in flight is too few); the loaders'
 // register files as a 3-4 stage deep FIFO in front of a two-slot LDS image (plain loads + ds_write_b128): 76-81 us.
+// x ring 3 x 32 KB + W ring 4 x 16 KB = the CU's 160 KB.  Measured alternatives (same process, w1|w3 at M = 256,
+// profiles/r04_block_*): W ring 3 deep: equal; x 2 + W 6: 81 vs 70.5 us (one x stage in flight is too few); the loaders'
+// register files as a 3-4 stage deep FIFO in front of a two-slot LDS image for BOTH operands (plain loads counted by
+// hipcc + ds_write_b128): 76-81 us; for the W stream only, 4-6 stages deep with inline-asm loads and a counted vmcnt
+// (96 KB of W in flight per CU instead of 48): 64.1-68.9 against 66.5 -- noise (r04_block_wreg_fifo_rejected_call28.txt).
 template <int EPI, bool SPLIT, bool WNT>
 int launch_cfg(const BlockParams& p, int grid, hipStream_t st) {
     constexpr int XS = 3, WS = 4;
