@@ -436,7 +436,9 @@ int launch_tile_pro(const TileParams& p, hipStream_t st) {
     // 2 x 2 tiles (64 rows x 64 columns per workgroup, one per CU): when the M range has two 32-row tiles and the 64-column
     // groups alone still give (nearly) every CU a workgroup -- the ingest-bound wide products of a 64-row step (the 1B
     // w1|w3: 256 groups).  Narrow products keep 1 x 1 tiles: more, smaller workgroups matter more there.
-    if constexpr (EPI == FL_SWIGLU || EPI == FL_NONE || EPI == FL_RESID) {
+    // (not with the deferred-RMSNorm prologue: that instantiation sits at the 256-register cap, re-reads rstd from LDS per
+    // chunk, and measured 25.9 us in the cfg3 iteration against 24.5 for the 1 x 1 form -- profiles/r04_bench_cfg3_iter_breakdown.csv)
+    if constexpr ((EPI == FL_SWIGLU || EPI == FL_NONE || EPI == FL_RESID) && !PRO) {
         const int groups = (p.n_tiles / 2) * ((p.m_tiles + 1) / 2);
         bool t22 = p.m_tiles >= 2 && p.n_tiles % 2 == 0 && p.K % 128 == 0 && groups >= 192;
         if (g_force_tile == 11) t22 = false;

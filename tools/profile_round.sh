@@ -9,7 +9,7 @@
 #   4. the whole -m gpu suite's parity report
 # usage: tools/profile_round.sh <tag>      outputs: gpurun_out/<tag>_*
 set -u
-TAG=${1:-r03}
+TAG=${1:-r04}
 OUT=$PWD/gpurun_out
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
