@@ -185,8 +185,10 @@ def run(args, dev):
 
     from magicdec_amd import harness, _lib
     from magicdec_amd.Engine import gemm_policy
-    gemm_mode = {"auto": "md_linear (streaming layout) for the long weight streams, hipBLASLt otherwise "
-                         "(Engine/gemm_policy.py)", "hip": "md_linear everywhere it supports the shape",
+    gemm_mode = {"auto": "md_linear (weight-streaming) for the long weight streams at <= 128 rows, md_linear_block (block-tile) "
+                         "for the wide 129..256-row products of the verify pass" +
+                         (" [off: MAGICDEC_BLOCK=0]" if gemm_policy.block_mode() == "0" else "") +
+                         ", hipBLASLt otherwise (Engine/gemm_policy.py)", "hip": "md_linear everywhere it supports the shape",
                  "lib": "hipBLASLt only"}[gemm_policy.mode()]
     from magicdec_amd.Engine import model_core
     from magicdec_amd.Engine.SnapKV.backend import LMBackend

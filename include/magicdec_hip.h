@@ -266,12 +266,11 @@ int md_linear_add_rmsnorm(const void* x, int64_t ldx, const void* w, int w_dtype
  * x a K slice, both operands global -> LDS by DMA through a three-stage ring, v_mfma_f32_32x32x16_bf16; narrow products
  * split K over workgroups (fp32 partial tiles in `workspace`, combined in slice order by the launch that applies the
  * epilogue: deterministic).  Epilogues and rounding points are md_linear's (MD_EPI_NONE / MD_EPI_SWIGLU);
- * md_linear_block_add_rmsnorm is md_linear_add_rmsnorm on this kernel ((h, y) = (resid + o, rmsnorm(h) * w));
- * md_linear_block_rope_append is md_linear_fused(MD_FL_ROPE_APPEND) on this kernel: the combine launch adds the bias,
- * rotates q and k (interleaved RoPE, fp32 table), writes q_rot to args->out and appends k / v to the paged cache(s) --
- * the same results as md_linear_fused(MD_FL_NONE) -> md_rope_append.
+ * md_linear_block_add_rmsnorm is md_linear_add_rmsnorm on this kernel ((h, y) = (resid + o, rmsnorm(h) * w): the combine
+ * launch of md_linear_add_rmsnorm, same rounding points).  The narrow projections of an M = 256 step (wqkv, wo) stay on
+ * md_linear_fused / the library: a K split over ~256 workgroups costs them more than it saves.
  * workspace: md_linear_block_workspace_bytes(M, N, K, force_split) bytes, 16-B aligned (force_split = 1 for the
- * add_rmsnorm / rope_append forms, whose epilogue always runs in the combine launch). */
+ * add_rmsnorm form, whose epilogue always runs in the combine launch). */
 int md_linear_block_supported(int M, int N, int K, int epilogue);
 size_t md_linear_block_workspace_bytes(int M, int N, int K, int force_split);
 int md_linear_block(const void* x, int64_t ldx, const void* w_packed, const void* bias, void* out, int64_t ldo, int M,
