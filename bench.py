@@ -568,7 +568,7 @@ def allreduce_plan(engine, draft, B, G, tp, draft_tp):
                              ("none: the draft model is replicated on every rank" if draft_tp == 1 and tp > 1 else None))}
 
 
-def collective_microbench_isolated(shapes, iters=30, timeout_s=240, dry=False):
+def collective_microbench_isolated(shapes, iters=30, timeout_s=120, dry=False):
     """collective_microbench in one CHILD process per rank (tools/collective_bench.py): same ranks and GPUs, a
     rendezvous port of its own, the parents waiting on the host (a GPU-side barrier would spin on the CUs the children
     are timing).  The xGMI kernels map peer memory and had never run over real links before the first multi-GPU bench;
