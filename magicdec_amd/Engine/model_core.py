@@ -532,7 +532,12 @@ class Transformer(nn.Module):
             need_calib = scales is not None and calibrate and not kvc.calibrated
             pro = y if isinstance(y, ops.DeferredNorm) else None
             yin = pro.h if pro is not None else y
-            if not need_calib and self._fused_here(yin, att.wqkv.weight, "qkv", pro is not None) and c.head_dim in (64, 128):
+            # the fused kernel derives (request, row-in-request) from the row index: every request must own exactly n
+            # consecutive rows (what every back-end passes: qo_indptr = arange * n); anything else takes rope_append, which
+            # honours qo_indptr
+            uniform_rows = yin.shape[0] == (qo_indptr.numel() - 1) * n
+            if (not need_calib and uniform_rows and self._fused_here(yin, att.wqkv.weight, "qkv", pro is not None)
+                    and c.head_dim in (64, 128)):
                 # (deferred RMSNorm +) wqkv + bias + RoPE + paged append (both caches of a self-speculation verify):
                 # ONE launch
                 q_rot = ops.fused_qkv_rope_append(

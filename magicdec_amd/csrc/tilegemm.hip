@@ -470,7 +470,8 @@ bool aligned16(const void* q) { return ((uintptr_t)q & 15) == 0; }
 
 #ifdef MD_DEV_KNOBS
 extern "C" void md_debug_set_fused_nw(int nw) {
-    g_force_nw = (nw == 8 || nw == 16) ? nw : (nw == 11 ? 8 : 0);     // 11: 1 x 1 tiles AND 8 K slices (what 2 x 2 uses)
+    // 11: 1 x 1 tiles AND 8 K slices (what 2 x 2 uses); 22 pins 8 slices too, for the forms that always stay 1 x 1
+    g_force_nw = (nw == 8 || nw == 16) ? nw : ((nw == 11 || nw == 22) ? 8 : 0);
     g_force_tile = (nw == 11 || nw == 22) ? nw : 0;
 }
 #endif
@@ -509,6 +510,8 @@ extern "C" int md_linear_fused(const md_fused_linear_args* a, md_stream_t stream
                      "md_linear_fused: the deferred-RMSNorm prologue exists for the qkv and w1|w3 linears");
         MD_CHECK_ARG(a->pro_norm_w && a->pro_tiles > 0 && aligned16(a->pro_norm_w),
                      "md_linear_fused: the deferred-RMSNorm prologue needs the norm weight (16-byte aligned) and pro_tiles");
+        MD_CHECK_ARG(a->pro_tiles * 32 == a->K, "md_linear_fused: pro_ssq must hold K / 32 = %d partial sums per row, got %d",
+                     a->K / 32, a->pro_tiles);
         p.pro_ssq = a->pro_ssq;
         p.pro_w = (const bf16_t*)a->pro_norm_w;
         p.pro_eps = a->pro_eps;

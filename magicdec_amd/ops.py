@@ -495,8 +495,10 @@ class DeferredNorm:
 def _set_pro(a, x, pro: "DeferredNorm"):
     if pro.h.data_ptr() != x.data_ptr() or pro.ssq.dtype != torch.float32 or not pro.ssq.is_contiguous():
         raise ValueError("deferred norm: x must be the un-normalised h the partial sums belong to")
-    if pro.ssq.shape[0] != x.shape[0] or pro.weight.numel() != x.shape[1] or pro.weight.dtype != torch.bfloat16:
-        raise ValueError("deferred norm: ssq [M, tiles] float32 and a bf16 norm weight [K] expected")
+    if (pro.ssq.dim() != 2 or pro.ssq.shape[0] != x.shape[0] or pro.ssq.shape[1] * 32 != x.shape[1]
+            or pro.weight.numel() != x.shape[1] or pro.weight.dtype != torch.bfloat16):
+        # ssq must hold one partial per 32-column tile of the producer (a shorter one would give a silently wrong rstd)
+        raise ValueError("deferred norm: ssq [M, K / 32] float32 and a bf16 norm weight [K] expected")
     a.pro_ssq, a.pro_tiles = pro.ssq.data_ptr(), pro.ssq.shape[1]
     a.pro_norm_w, a.pro_eps = pro.weight.data_ptr(), pro.eps
 
@@ -512,6 +514,10 @@ def fused_linear(x, weight: "PackedWeight", bias=None, swiglu=False, resid=None,
     n_out = weight.N // 2 if swiglu else weight.N
     if out is None:
         out = torch.empty((x.shape[0], n_out), dtype=x.dtype, device=x.device)
+    else:
+        _gpu(out)
+        if out.dtype != torch.bfloat16 or out.dim() != 2 or out.shape != (x.shape[0], n_out) or out.stride(1) != 1:
+            raise ValueError("fused linear: out must be bf16 [M, N_out] with unit inner stride")
     a.out, a.ldo = out.data_ptr(), out.stride(0)
     ssq = None
     if resid is not None:
