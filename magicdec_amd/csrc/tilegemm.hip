@@ -185,6 +185,9 @@ __global__ __launch_bounds__(64 * NW, MT * NT > 1 ? 2 : 4) void tile_gemm_kernel
     u32x4 nwv = {0u, 0u, 0u, 0u};                   // PRO: the norm weights of this lane's 8 columns of the chunk
     float rs8[8];                                   // PRO, MT == 1: rstd of this lane's staging rows (MT > 1: re-read
                                                     // from LDS per chunk -- 16 more registers would spill)
+    // (the row scales are formed BEFORE the first loads are issued: with the loads in flight first, the barrier below
+    // drains them -- 1B w1|w3 at 64 rows 29.2 us against 25.8, profiles/r04_fused_pro_prologue_ab.txt.  What the
+    // deferred norm costs is the VALU work of normalising the same rows in every column tile: 18.9 -> 25.8 us there.)
     if constexpr (PRO) {
         float* rstd_lds = reinterpret_cast<float*>(lds + NW * kWaveLdsT);
         if (tid < 512) {

@@ -22,6 +22,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--only", default="")
 ap.add_argument("--iters", type=int, default=30)
 ap.add_argument("--tiles", type=int, default=0, help="1: also time md_linear_fused with 1 x 1 and 2 x 2 tiles forced (dev knob)")
+ap.add_argument("--pro", type=int, default=0, help="1: also time the deferred-RMSNorm (PRO) form of the swiglu / qkv linears")
 a = ap.parse_args()
 print("tuned GEMM table loaded:", enable_tuned_gemms())
 dev = "cuda"
@@ -128,10 +129,22 @@ for model, tp, M in CASES:
             def fused(i):
                 return ops.fused_qkv_rope_append(x, pk[i % ncopy], None, h, kh, D, n_rows, offs, tab, cache, indices,
                                                  indptr, last)
+        fused_pro = None
+        if a.pro and kind in ("swiglu", "qkv"):
+            pro = ops.DeferredNorm(x, torch.rand(M, K // 32, device=dev) * 32.0, torch.ones(K, device=dev, dtype=torch.bfloat16), 1e-5)
+            if kind == "swiglu":
+                def fused_pro(i):
+                    return ops.fused_linear(x, pk[i % ncopy], swiglu=True, pro=pro)
+            else:
+                def fused_pro(i):
+                    return ops.fused_qkv_rope_append(x, pk[i % ncopy], None, h, kh, D, n_rows, offs, tab, cache, indices,
+                                                     indptr, last, pro=pro)
         t_u = timeit(unfused, a.iters)
         t_s = timeit(skinny, a.iters) if skinny_ok else float("nan")
         t_f = timeit(fused, a.iters)
         extra = ""
+        if fused_pro is not None:
+            extra += f" | pro: {timeit(fused_pro, a.iters):6.1f}"
         if a.tiles:
             import ctypes
             lib = _lib.load()
