@@ -357,12 +357,16 @@ def run(args, dev):
         nd = False
         tokens = torch.zeros((), dtype=torch.long, device=dev)
         timer.enabled = False
+        # the token counter is queued behind the accept kernel, before the iteration's host read (the host is ahead of
+        # the GPU there; after the read it would sit on the critical path of the next iteration)
+        def count(state):
+            tokens.add_(state.accept_nums.sum())
+        st.before_host_read = count
         for i in range(n_warm):
             # exactly the statements of a timed step: the first execution of any torch op in a process loads its code
             # object (the token counter's int sum + add cost 18.6 ms in the first timed iteration when the warm-up
             # loop did not run them: profiles/r02_bench_first_iteration.txt)
             term, nd = iteration(nd, forced_table[i] if forced_table is not None else None)
-            tokens += st.accept_nums.sum()
             if term:
                 restore()
                 nd = False
@@ -374,7 +378,6 @@ def run(args, dev):
         stamps = []
         for i in range(n_steps):
             term, nd = iteration(nd, forced_table[n_warm + i] if forced_table is not None else None)
-            tokens += st.accept_nums.sum()
             stamps.append((time.perf_counter(), bool(term), bool(nd)))   # the iteration ended with a host read
             if term:
                 restore()
@@ -382,6 +385,7 @@ def run(args, dev):
         barrier()
         dt = time.perf_counter() - t0
         timer.enabled = False
+        st.before_host_read = None
         if debug_iters and rank == 0:
             prev, out = t0, []
             for t, te, d2 in stamps:

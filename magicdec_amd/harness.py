@@ -13,6 +13,7 @@ Used by the CLI scripts under tests/, by bench.py and by the parity tests.
 """
 from __future__ import annotations
 
+import os
 import time
 from dataclasses import dataclass, field
 
@@ -35,6 +36,10 @@ class LoopState:
     flags_host: torch.Tensor
     iters: int = 0
     accept_trace: list = field(default_factory=list)
+    # called (with the state) after an iteration's accept kernel was queued and BEFORE the host read: device-side
+    # statistics queued here cost the host nothing on the critical path -- the GPU is still busy with the verify step
+    before_host_read: object = None
+    _flags_event: object = None
 
 
 def new_state(B, gamma, out_cols, device, input_ids=None):
@@ -54,6 +59,10 @@ def new_state(B, gamma, out_cols, device, input_ids=None):
     return st
 
 
+# MAGICDEC_HOST_READ_SPIN=0: block in hipStreamSynchronize for the iteration's host read instead of polling an event
+_SPIN_ON_HOST_READ = os.environ.get("MAGICDEC_HOST_READ_SPIN", "1") != "0"
+
+
 def _sync(t):
     if t.is_cuda:
         torch.cuda.synchronize(t.device)
@@ -66,7 +75,18 @@ def _read_flags(st: LoopState, collectives=()):
     if st.flags.is_cuda:
         st.flags_host.copy_(st.flags, non_blocking=True)
         status = [ar.status_async() for ar in collectives]
-        torch.cuda.current_stream().synchronize()
+        # the GPU idles from here until the next iteration's first launch: poll an event instead of blocking in
+        # hipStreamSynchronize (whose wake-up alone was most of a 93 us gap per iteration,
+        # profiles/r04_iteration_gaps.txt)
+        if not _SPIN_ON_HOST_READ:
+            torch.cuda.current_stream().synchronize()
+        else:
+            if st._flags_event is None:
+                st._flags_event = torch.cuda.Event()
+            ev = st._flags_event
+            ev.record()
+            while not ev.query():
+                pass
         for ar, s in zip(collectives, status):
             if int(s[0]) != 0:
                 from .Engine.oneshot import AllReduceTimeout
@@ -152,6 +172,8 @@ def _iterate(engine, draft, st: LoopState, body, forced):
     removed: profiles/r02_ab_iteration_graph.txt, profiles/r03_ab_iteration_graph_tp8.txt.)"""
     body(forced)
     st.iters += 1
+    if st.before_host_read is not None:
+        st.before_host_read(st)
     return _read_flags(st, _collectives_of(engine, draft))
 
 

@@ -10,6 +10,12 @@ import sys
 from collections import defaultdict
 
 
+def short(name):
+    """Kernel name without namespaces, template arguments and parameter lists."""
+    n = name.replace("(anonymous namespace)::", "").replace("void ", "")
+    return n.split("(")[0].split("<")[0][:48]
+
+
 def main(db_path, out_path=None):
     db = sqlite3.connect(db_path)
     cur = db.cursor()
@@ -32,6 +38,14 @@ def main(db_path, out_path=None):
             agg[n][1] += 1
             busy += en - st
     k = len(steady)
+    # where the idle time sits: gaps between consecutive kernels, by (kernel before, kernel after)
+    gaps = defaultdict(lambda: [0, 0])
+    for a, b, ln in steady:
+        for (n0, _, e0), (n1, s1, _) in zip(rows[a:b], rows[a + 1:b + 1]):
+            if s1 > e0:
+                key = (short(n0), short(n1))
+                gaps[key][0] += s1 - e0
+                gaps[key][1] += 1
     lines = [f"# {k} steady-state iterations (median {med / 1e6:.3f} ms) of {len(spans)} intervals",
              f"# per iteration: wall {wall / k / 1e6:.3f} ms, gpu busy {busy / k / 1e6:.3f} ms, "
              f"idle {(wall - busy) / k / 1e6:.3f} ms",
@@ -39,6 +53,9 @@ def main(db_path, out_path=None):
     for n, (t, c) in sorted(agg.items(), key=lambda x: -x[1][0]):
         lines.append(f"\"{n.replace(',', ';')[:150]}\",{c / k:.2f},{t / k / 1e6:.4f},{t / c / 1e3:.2f},"
                      f"{100.0 * t / wall:.2f}")
+    lines.append("# idle gaps by (kernel before -> kernel after): gaps_per_iter, us_per_iter, avg_us")
+    for (n0, n1), (t, c) in sorted(gaps.items(), key=lambda x: -x[1][0])[:25]:
+        lines.append(f"# gap,\"{n0} -> {n1}\",{c / k:.2f},{t / k / 1e3:.1f},{t / c / 1e3:.2f}")
     txt = "\n".join(lines) + "\n"
     if out_path:
         open(out_path, "w").write(txt)
