@@ -1266,3 +1266,23 @@ def test_gemm_policy_encodes_the_measured_ab_table():
     assert g.choose(64, 3072, 2048, False, False, False, "qkv") == "lib"
     assert g.choose(64, 3072, 2048, False, True, True, "qkv") == "skinny"
     assert c(64, 3080, 2048, "plain") == "lib" and c(300, 768, 2048, "qkv") == "lib"
+
+
+def test_iteration_hook_runs_after_the_body_and_before_the_host_read():
+    """LoopState.before_host_read: device-side statistics are queued behind the accept kernel and in front of the
+    iteration's one host read (bench.py counts its tokens there)."""
+    from magicdec_amd import harness
+    st = harness.new_state(2, 3, 8, "cpu")
+    order = []
+    st.before_host_read = lambda s: order.append(("hook", int(s.flags[0]), s.iters))
+
+    def body(forced):
+        st.flags[0] = 1
+        order.append(("body", forced))
+
+    term, nd = harness._iterate(None, None, st, body, None)
+    assert order == [("body", None), ("hook", 1, 1)]
+    assert term is True and nd is False and st.iters == 1
+    st.before_host_read = None
+    st.flags.zero_()
+    assert harness._iterate(None, None, st, lambda f: None, None) == (False, False)
