@@ -529,6 +529,13 @@ def run(args, dev):
                                     "tokens_per_iter_per_seq": round(tok_meas / meas_steps / B, 3),
                                     "ms_per_step": round(dt_meas / meas_steps * 1e3, 4)},
         "prefill_s": round(t_pf, 2), "load_s": round(t_load, 2),
+        # what "identical to the reference" means for this path (checked by `pytest -m gpu` and smoke(), not here)
+        "parity": {"tokens": "identity with the CPU oracle, tie-aware: argmax flips <= 2 x those of a float64-linear "
+                             "oracle + 6 per ~1000 positions (tests/test_gpu_engine.py lock-step)",
+                   "logits": "max |hip - oracle| <= 2 x the error of a correctly-rounded bf16 implementation + 2 bf16 "
+                             "ulp (measured 0.012-0.047 on logits of magnitude 1-4), NOT 1e-3 absolute: every bf16 "
+                             "linear output carries 2^-8 relative rounding",
+                   "integer_paths": "page tables, SnapKV top-k order, gather, accept/rollback: bit-exact"},
         "roofline": {"kernel": f"paged_attn_kernel<{D},{1 if (G + 1) * (H_loc // KH_loc) <= 16 else 2},"
                                f"{'true' if args.kv_dtype == 'fp8' else 'false'}> (verify attention, md_paged_attn, "
                                f"{kv_layout} pages)",
