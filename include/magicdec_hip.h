@@ -244,6 +244,15 @@ size_t md_linear_workspace_bytes(int M, int N, int K, int epilogue);
 int md_linear(const void* x, int64_t ldx, const void* w, int w_dtype, int w_packed, const void* scales,
               const void* bias, void* out, int64_t ldo, int M, int N, int K, int epilogue, void* workspace,
               size_t workspace_bytes, md_stream_t stream);
+/* md_linear_normed: md_linear over rmsnorm(h) * norm_weight WITHOUT a launch for the norm -- the consumer half of the
+ * deferred RMSNorm of md_linear_fused on the weight-streaming kernel (Engine/SnapKV/model.py:260-278,464-469: the
+ * ffn_norm in front of w1|w3, the final norm in front of the lm head).  h [M][K] is the un-normalised hidden state the
+ * residual epilogue of the producing linear wrote (MD_FL_RESID with ssq_out), ssq [M][ssq_tiles] its partial sums of
+ * squares (ssq_tiles * 32 == K); every workgroup forms rstd per row (the fixed order of md_linear_fused) and feeds
+ * y = bf16(bf16(h * rstd) * norm_weight) into the product.  bf16 weights; shapes / workspace / epilogues as md_linear. */
+int md_linear_normed(const void* h, int64_t ldh, const float* ssq, int ssq_tiles, const void* norm_weight, float eps,
+                     const void* w, int w_packed, const void* bias, void* out, int64_t ldo, int M, int N, int K,
+                     int epilogue, void* workspace, size_t workspace_bytes, md_stream_t stream);
 
 /* md_linear_add_rmsnorm: the output projection of a sub-layer on the weight-streaming kernel TOGETHER with what follows
  * it (Engine/SnapKV/model.py:260-278: h = x + wo(...), out = h + w2(...); :464-469 RMSNorm): the split-K combine launch

@@ -55,6 +55,18 @@ FUSED_QKV_M256_MAX_L2_BYTES = 110e6
 FUSED_MAX_L2_BYTES_WITH_NORM = 140e6
 
 
+# round 4: md_linear (the streaming kernel) can absorb the same deferred norm (md_linear_normed): a slab is normalised once
+# per workgroup on its way to LDS.  Free while the kernel waits for weights anyway (<= 64 rows); at 128 / 256 rows the
+# staging of a slab is as much vector work as its MFMAs and the launch it saves is cheaper (tools/fused_bench.py --pro 1:
+# 1B w1|w3 at 128 rows 35.4 vs 30.1 us with the norm as its own launch, 8B at 256 rows 179 vs 105).
+SKINNY_NORM_MAX_M = 64
+_SKINNY_NORM = os.environ.get("MAGICDEC_SKINNY_NORM", "auto")     # "0": always materialise the norm in front of md_linear
+
+
+def skinny_absorbs_norm(M: int) -> bool:
+    return _SKINNY_NORM != "0" and M <= SKINNY_NORM_MAX_M
+
+
 def set_mode(mode: str):
     global _MODE
     assert mode in ("auto", "hip", "lib")

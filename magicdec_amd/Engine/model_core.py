@@ -375,7 +375,7 @@ class Transformer(nn.Module):
         kernel -- callers check `_fused_here` first); with `want_ssq` also the per-row partial sums of squares of the
         result (the producer half of a deferred RMSNorm).  `x2d` may be an `ops.DeferredNorm`: the fused w1|w3 kernel
         applies it on the fly, every other path materialises it first."""
-        from .gemm_policy import choose
+        from .gemm_policy import choose, skinny_absorbs_norm
         if swiglu_w13 is not None:
             w, scales, bias = swiglu_w13[0], swiglu_w13[1], None
         else:
@@ -394,12 +394,18 @@ class Transformer(nn.Module):
             if pro is not None and not swiglu:
                 x2d, pro = pro.materialize(), None
             return ops.fused_linear(x2d, pk, bias, swiglu=swiglu, resid=resid, want_ssq=want_ssq, pro=pro)
+        assert resid is None, "the residual epilogue exists on the fused kernel only"
+        skinny = how in ("fused", "skinny", "block") and ops.linear_supported(M, N, K, swiglu)
+        if how == "block" and ops.linear_block_supported(M, N, K, swiglu):
+            skinny = False
+        if pro is not None and skinny and w.dtype == torch.bfloat16 and skinny_absorbs_norm(M):
+            # the weight-streaming kernel normalises its activation slabs on the way to LDS (md_linear_normed)
+            return ops.linear(x2d, pk if pk is not None else w, bias, None, swiglu, self.workspace, pro=pro)
         if pro is not None:
             x2d = pro.materialize()
-        assert resid is None, "the residual epilogue exists on the fused kernel only"
         if how == "block" and ops.linear_block_supported(M, N, K, swiglu):
             return ops.linear_block(x2d, pk, bias, swiglu, self.workspace)
-        if how in ("fused", "skinny", "block") and ops.linear_supported(M, N, K, swiglu):
+        if skinny:
             return ops.linear(x2d, pk if pk is not None else w, bias, scales, swiglu, self.workspace)
         if w.dtype == torch.int8:      # WeightOnlyInt8Linear.forward (Engine/quantize.py:84-86), dequantised on the fly
             h = F.linear(x2d, w.to(dtype=x2d.dtype)) * scales

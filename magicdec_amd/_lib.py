@@ -11,7 +11,7 @@ from ctypes import c_char_p, c_double, c_float, c_int, c_int64, c_size_t, c_void
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmagicdec_hip.so")
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 _lib = None
 _err = None
@@ -62,6 +62,7 @@ _SIGNATURES = {
     "md_linear_supported": (c_int, [I, I, I, I]),
     "md_linear_workspace_bytes": (c_size_t, [I, I, I, I]),
     "md_linear": (c_int, [P, L, P, I, I, P, P, P, L, I, I, I, I, P, c_size_t, P]),
+    "md_linear_normed": (c_int, [P, L, P, I, P, c_float, P, I, P, P, L, I, I, I, I, P, c_size_t, P]),
     "md_linear_add_rmsnorm_supported": (c_int, [I, I, I]),
     "md_linear_add_rmsnorm": (c_int, [P, L, P, I, I, P, P, P, L, P, c_float, P, P, I, I, I, P, c_size_t, P]),
     "md_linear_block_supported": (c_int, [I, I, I, I]),

@@ -49,7 +49,16 @@ struct GemmParams {
     int M, N, K, kblk, S, Nout;
     int packed;           // W is in the fragment-major streaming layout (md_pack_weight layout, see md_linear)
     int skip_reduce;      // md_linear_add_rmsnorm: the caller launches its own combine kernel
+    // deferred RMSNorm (PRO = true, md_linear_normed): x is the un-normalised h, see md_linear_fused
+    const float* pro_ssq; // [M][pro_tiles] partial sums of squares of the rows of x
+    const bf16_t* pro_w;  // RMSNorm weight [K]
+    float pro_eps;
+    int pro_tiles;
 };
+
+__device__ __forceinline__ f32x2 unpack2(unsigned int v) {          // the two bf16 of a dword as fp32 (low half first)
+    return f32x2{__uint_as_float(v << 16), __uint_as_float(v & 0xffff0000u)};
+}
 
 __device__ __forceinline__ bf16x8 ld_frag(const bf16_t* p) { return *reinterpret_cast<const bf16x8*>(p); }
 
@@ -86,10 +95,15 @@ __device__ __forceinline__ float silu_bf16(float h1) {
 }
 
 // One workgroup: 4 wavefronts x 32 GEMM columns, rows [0, M), k in [blockIdx.y*kblk, +kblk).
-template <int MT, int EPI, bool W8, int RD>
+// PRO (round 4): the deferred RMSNorm of md_linear_fused on this kernel's activation path -- x is the un-normalised h
+// the residual epilogue of the producing linear wrote together with per-row partial sums of squares; the workgroup forms
+// rstd per row (the tile kernel's sum, term for term) and normalises every slab on its way from registers to LDS:
+// y = bf16(bf16(h * rstd) * w).  A slab is normalised once per workgroup and shared by its 128 columns, so the cost is a
+// few dozen vector instructions per slab -- against a 5 us md_rmsnorm launch in front of every w1|w3 of a draft pass.
+template <int MT, int EPI, bool W8, int RD, bool PRO>
 __global__ __launch_bounds__(256) void skinny_gemm_kernel(const GemmParams p) {
     constexpr int MP = MT * 32;
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];   // 2 x [MP][kPitch]
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];   // 2 x [MP][kPitch] (+ MP floats rstd when PRO)
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 31, kh = lane >> 5;
     const int k_beg = blockIdx.y * p.kblk;
     const int nslab = p.kblk / kSlabK;
@@ -120,7 +134,11 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(const GemmParams p) {
     // ---- activation slab staging: MP rows x 16 chunks of 16 B; thread t takes chunks t, t+256, ...
     constexpr int XCH = MP * 16 / 256;   // chunks per thread (MT * 2)
     u32x4 xs[XCH];
+    u32x4 nwv = {0u, 0u, 0u, 0u};        // PRO: the norm weights of this thread's 8 columns of the slab (c16 = tid & 15)
+    const float* rstd_lds = reinterpret_cast<const float*>(lds + 2 * MP * kPitch);
     auto x_load = [&](int slab) {
+        if constexpr (PRO)
+            nwv = *reinterpret_cast<const u32x4*>(p.pro_w + k_beg + slab * kSlabK + (tid & 15) * 8);
 #pragma unroll
         for (int q = 0; q < XCH; ++q) {
             const int c = tid + 256 * q;
@@ -129,6 +147,27 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(const GemmParams p) {
             // of those rows are never stored)
             const int rr = row < p.M ? row : p.M - 1;
             xs[q] = *reinterpret_cast<const u32x4*>(p.x + (int64_t)rr * p.ldx + k_beg + slab * kSlabK + c16 * 8);
+        }
+    };
+    // PRO: normalise the staged slab in registers.  Called in the MIDDLE of the current slab's MFMA steps (the loads were
+    // issued at its top): the vector work runs under the matrix pipeline instead of between the last MFMA and the
+    // barrier, where all four waves would wait for it (+5 us on the 8B w1|w3 at 64 rows when it sat in x_store)
+    auto x_norm = [&]() {
+#pragma unroll
+        for (int q = 0; q < XCH; ++q) {
+            const int row = (tid + 256 * q) >> 4;
+            const float rs = rstd_lds[row];
+            u32x4 v = xs[q];
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {                           // the arithmetic of tile_gemm_kernel's prologue
+                const f32x2 t = unpack2(v[w]) * f32x2{rs, rs};
+                unsigned int pk;
+                asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(pk) : "v"(t[0]), "v"(t[1]));
+                const f32x2 o = unpack2(pk) * unpack2(nwv[w]);
+                const bf16x2 ob = {f32_to_bf16(o[0]), f32_to_bf16(o[1])};
+                v[w] = *reinterpret_cast<const unsigned int*>(&ob);
+            }
+            xs[q] = v;
         }
     };
     auto x_store = [&](int buf) {
@@ -152,6 +191,57 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(const GemmParams p) {
 #pragma unroll
     for (int s = 0; s < RD; ++s) wr[s] = ld_w<W8>(p.w, w_off + (int64_t)(s < nsteps ? s : nsteps - 1) * w_step);
     x_load(0);
+    if constexpr (PRO) {
+        // row scales, behind the first loads: rstd = rsqrt(sum_t ssq[row][t] / K + eps), 16 lanes per row, the partial
+        // sums added in the tile kernel's order (strided by 16, then the 16-lane butterfly)
+        float* rw = reinterpret_cast<float*>(lds + 2 * MP * kPitch);
+        constexpr int RPT = MP / 16;                               // rows per thread
+        const int part = tid & 15;
+        float t[RPT];
+        if constexpr (MT <= 2) {
+            // <= 64 rows (where the policy uses this form): the partial sums of ALL rows of a thread are requested
+            // before the first one is needed -- one L2 round trip per 128 tiles instead of one per 16 rows (a serial
+            // loop over the row groups cost the 8B w1|w3 at 64 rows +5 us)
+            const float* src[RPT];
+#pragma unroll
+            for (int it = 0; it < RPT; ++it) {
+                const int r = it * 16 + (tid >> 4);
+                src[it] = p.pro_ssq + (int64_t)(r < p.M ? r : p.M - 1) * p.pro_tiles;
+                t[it] = 0.f;
+            }
+            for (int i0 = part; i0 < p.pro_tiles; i0 += 128) {
+                float v[RPT][8];
+#pragma unroll
+                for (int it = 0; it < RPT; ++it)
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) v[it][u] = i0 + 16 * u < p.pro_tiles ? src[it][i0 + 16 * u] : 0.f;
+#pragma unroll
+                for (int it = 0; it < RPT; ++it)
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) t[it] += v[it][u];          // ascending tile index: the tile kernel's order
+            }
+        } else {
+#pragma unroll 1
+            for (int it = 0; it < RPT; ++it) {
+                const int r = it * 16 + (tid >> 4);
+                const int gr = r < p.M ? r : p.M - 1;
+                float a = 0.f;
+                for (int i = part; i < p.pro_tiles; i += 16) a += p.pro_ssq[(int64_t)gr * p.pro_tiles + i];
+                t[it] = a;
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < RPT; ++it) {
+            float a = t[it];
+            a += __shfl_xor(a, 1);
+            a += __shfl_xor(a, 2);
+            a += __shfl_xor(a, 4);
+            a += __shfl_xor(a, 8);
+            if (part == 0) rw[it * 16 + (tid >> 4)] = rsqrtf(__fadd_rn(__fdiv_rn(a, (float)p.K), p.pro_eps));
+        }
+        __syncthreads();
+        x_norm();
+    }
     x_store(0);
     __syncthreads();
 
@@ -191,6 +281,12 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(const GemmParams p) {
                     for (int mt = 0; mt < MT; ++mt)
                         acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[st & 1][mt], b, acc[mt], 0, 0, 0);
                     __builtin_amdgcn_sched_barrier(0);
+                    if constexpr (PRO) {
+                        if (st == kStepsPerSlab / 2 && more) {
+                            x_norm();
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
                 }
                 if (more) x_store(buf ^ 1);
                 __syncthreads();
@@ -297,13 +393,13 @@ int md_internal_launch_reduce_add_rmsnorm(const float* partial, int S, int M, in
 
 namespace {
 
-template <int MT, int EPI, bool W8>
+template <int MT, int EPI, bool W8, bool PRO = false>
 int launch(const GemmParams& p, int n_blocks, hipStream_t st) {
     constexpr int RD = 8;
-    const size_t lds = (size_t)2 * MT * 32 * kPitch;
-    auto k = skinny_gemm_kernel<MT, EPI, W8, RD>;
+    const size_t lds = (size_t)2 * MT * 32 * kPitch + (PRO ? MT * 32 * 4 : 0);
+    auto k = skinny_gemm_kernel<MT, EPI, W8, RD, PRO>;
     if (lds > 64 * 1024) {
-        static MdPerDeviceOnce once;   // per (MT, EPI, W8) instantiation and per device
+        static MdPerDeviceOnce once;   // per (MT, EPI, W8, PRO) instantiation and per device
         if (once.first()) {
             if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)lds) != hipSuccess) {
@@ -320,12 +416,12 @@ int launch(const GemmParams& p, int n_blocks, hipStream_t st) {
     return MD_OK;
 }
 
-template <int EPI, bool W8>
+template <int EPI, bool W8, bool PRO = false>
 int launch_mt(const GemmParams& p, int n_blocks, hipStream_t st) {
-    if (p.M <= 32) return launch<1, EPI, W8>(p, n_blocks, st);
-    if (p.M <= 64) return launch<2, EPI, W8>(p, n_blocks, st);
-    if (p.M <= 128) return launch<4, EPI, W8>(p, n_blocks, st);
-    return launch<8, EPI, W8>(p, n_blocks, st);
+    if (p.M <= 32) return launch<1, EPI, W8, PRO>(p, n_blocks, st);
+    if (p.M <= 64) return launch<2, EPI, W8, PRO>(p, n_blocks, st);
+    if (p.M <= 128) return launch<4, EPI, W8, PRO>(p, n_blocks, st);
+    return launch<8, EPI, W8, PRO>(p, n_blocks, st);
 }
 
 }  // namespace
@@ -369,9 +465,11 @@ extern "C" int md_linear_supported(int M, int N, int K, int epilogue) {
     return (N % 4 == 0) ? 1 : 0;
 }
 
-extern "C" int md_linear(const void* x, int64_t ldx, const void* w, int w_dtype, int w_packed, const void* scales,
-                         const void* bias, void* out, int64_t ldo, int M, int N, int K, int epilogue, void* workspace,
-                         size_t workspace_bytes, md_stream_t stream) {
+namespace {
+int linear_impl(const void* x, int64_t ldx, const void* w, int w_dtype, int w_packed, const void* scales,
+                const void* bias, void* out, int64_t ldo, int M, int N, int K, int epilogue, void* workspace,
+                size_t workspace_bytes, md_stream_t stream, const float* pro_ssq, int pro_tiles, const void* pro_w,
+                float pro_eps) {
     MD_CHECK_ARG(x && w && out, "md_linear: null pointer argument");
     MD_CHECK_ARG(md_linear_supported(M, N, K, epilogue), "md_linear: unsupported shape M=%d N=%d K=%d epilogue=%d "
                  "(need 1 <= M <= 256, K %% 128 == 0, N %% 4 == 0)", M, N, K, epilogue);
@@ -381,7 +479,7 @@ extern "C" int md_linear(const void* x, int64_t ldx, const void* w, int w_dtype,
     MD_CHECK_ARG(!(epilogue == EPI_SWIGLU && bias), "md_linear: SwiGLU epilogue takes no bias");
     MD_CHECK_ARG((((uintptr_t)x | (uintptr_t)w | (uintptr_t)out) & 15) == 0 && ldx % 8 == 0 && ldo % 4 == 0,
                  "md_linear: x / w / out must be 16-byte aligned, ldx %% 8 == 0, ldo %% 4 == 0");
-    GemmParams p;
+    GemmParams p = {};
     p.x = (const bf16_t*)x;
     p.w = w;
     p.bias = (const bf16_t*)bias;
@@ -395,6 +493,18 @@ extern "C" int md_linear(const void* x, int64_t ldx, const void* w, int w_dtype,
     p.Nout = epilogue == EPI_SWIGLU ? N / 2 : N;
     p.packed = w_packed ? 1 : 0;
     p.skip_reduce = 0;
+    const bool pro = pro_ssq != nullptr;
+    if (pro) {
+        MD_CHECK_ARG(w_dtype == MD_W_BF16, "md_linear_normed: bf16 weights only");
+        MD_CHECK_ARG(pro_w && (((uintptr_t)pro_w) & 15) == 0 && (((uintptr_t)pro_ssq) & 3) == 0,
+                     "md_linear_normed: the norm weight must be 16-byte aligned");
+        MD_CHECK_ARG(pro_tiles > 0 && pro_tiles * 32 == K,
+                     "md_linear_normed: ssq must hold K / 32 = %d partial sums per row, got %d", K / 32, pro_tiles);
+        p.pro_ssq = pro_ssq;
+        p.pro_w = (const bf16_t*)pro_w;
+        p.pro_eps = pro_eps;
+        p.pro_tiles = pro_tiles;
+    }
     const int cols_per_block = epilogue == EPI_SWIGLU ? 64 : 128;      // output columns per workgroup
     const int n_blocks = (p.Nout + cols_per_block - 1) / cols_per_block;
     p.S = pick_splits(n_blocks, K);
@@ -407,13 +517,32 @@ extern "C" int md_linear(const void* x, int64_t ldx, const void* w, int w_dtype,
     hipStream_t st = (hipStream_t)stream;
     int rc;
     const bool w8 = w_dtype == MD_W_INT8;
-    if (epilogue == EPI_SWIGLU)
+    if (pro)
+        rc = epilogue == EPI_SWIGLU ? launch_mt<EPI_SWIGLU, false, true>(p, n_blocks, st)
+                                    : launch_mt<EPI_NONE, false, true>(p, n_blocks, st);
+    else if (epilogue == EPI_SWIGLU)
         rc = w8 ? launch_mt<EPI_SWIGLU, true>(p, n_blocks, st) : launch_mt<EPI_SWIGLU, false>(p, n_blocks, st);
     else
         rc = w8 ? launch_mt<EPI_NONE, true>(p, n_blocks, st) : launch_mt<EPI_NONE, false>(p, n_blocks, st);
     if (rc != MD_OK) return rc;
     MD_CHECK_LAUNCH("md_linear");
     return MD_OK;
+}
+}  // namespace
+
+extern "C" int md_linear(const void* x, int64_t ldx, const void* w, int w_dtype, int w_packed, const void* scales,
+                         const void* bias, void* out, int64_t ldo, int M, int N, int K, int epilogue, void* workspace,
+                         size_t workspace_bytes, md_stream_t stream) {
+    return linear_impl(x, ldx, w, w_dtype, w_packed, scales, bias, out, ldo, M, N, K, epilogue, workspace, workspace_bytes,
+                       stream, nullptr, 0, nullptr, 0.f);
+}
+
+extern "C" int md_linear_normed(const void* h, int64_t ldh, const float* ssq, int ssq_tiles, const void* norm_weight,
+                                float eps, const void* w, int w_packed, const void* bias, void* out, int64_t ldo, int M,
+                                int N, int K, int epilogue, void* workspace, size_t workspace_bytes, md_stream_t stream) {
+    MD_CHECK_ARG(ssq && norm_weight, "md_linear_normed: null pointer argument");
+    return linear_impl(h, ldh, w, MD_W_BF16, w_packed, nullptr, bias, out, ldo, M, N, K, epilogue, workspace,
+                       workspace_bytes, stream, ssq, ssq_tiles, norm_weight, eps);
 }
 
 extern "C" int md_linear_add_rmsnorm_supported(int M, int N, int K) {
@@ -434,7 +563,7 @@ extern "C" int md_linear_add_rmsnorm(const void* x, int64_t ldx, const void* w, 
     MD_CHECK_ARG((((uintptr_t)x | (uintptr_t)w | (uintptr_t)resid | (uintptr_t)norm_weight | (uintptr_t)h_out |
                    (uintptr_t)y_out) & 15) == 0 && ldx % 8 == 0 && ldr % 8 == 0,
                  "md_linear_add_rmsnorm: pointers must be 16-byte aligned, ldx %% 8 == 0, ldr %% 8 == 0");
-    GemmParams p;
+    GemmParams p = {};
     p.x = (const bf16_t*)x;
     p.w = w;
     p.bias = nullptr;

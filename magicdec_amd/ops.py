@@ -302,12 +302,14 @@ class PackedWeight:
         self.data = rows.view(t, 32, K // 16, 2, 8).permute(0, 2, 3, 1, 4).contiguous()
 
 
-def linear(x, weight, bias=None, scales=None, swiglu=False, workspace: "AttnWorkspace" = None, out=None):
+def linear(x, weight, bias=None, scales=None, swiglu=False, workspace: "AttnWorkspace" = None, out=None,
+           pro: "DeferredNorm" = None):
     """F.linear(x, weight, bias) for M = x.shape[0] <= 256 rows on the hand-written gfx950 skinny GEMM (md_linear).
     x [M, K] bf16 with unit inner stride (row stride free); weight: a contiguous [N, K] tensor or a PackedWeight
     (streaming layout), bf16 -- or int8 with bf16 per-row `scales` (WeightOnlyInt8Linear semantics:
     bf16(x.w^T) * scales).  swiglu=True: weight = [w1; w3] (N = 2*I rows) and the result is
-    silu(x.w1^T) * (x.w3^T) [M, I] with the reference's bf16 rounding points."""
+    silu(x.w1^T) * (x.w3^T) [M, I] with the reference's bf16 rounding points.
+    pro (bf16 weights): x is pro.h, the un-normalised hidden state, and is normalised on the fly (md_linear_normed)."""
     packed = isinstance(weight, PackedWeight)
     wt = weight.data if packed else weight
     _gpu(x, wt, bias, scales)
@@ -344,9 +346,19 @@ def linear(x, weight, bias=None, scales=None, swiglu=False, workspace: "AttnWork
             raise ValueError("linear: this shape splits K and needs a workspace")
         ws = workspace.get(nbytes + 256)
         off = (-ws.data_ptr()) % 256
+    wsp = ctypes.c_void_p(ws.data_ptr() + off) if ws is not None else None
+    if pro is not None:
+        if wd != MD_W_BF16:
+            raise TypeError("linear: the deferred norm needs bf16 weights")
+        a = _lib.FusedLinearArgs()             # _set_pro's checks (x is pro.h, ssq [M, K / 32] fp32, bf16 weight [K])
+        _set_pro(a, x, pro)
+        check(lib.md_linear_normed(_p(x), x.stride(0), _p(pro.ssq), pro.ssq.shape[1], _p(pro.weight), pro.eps, _p(wt),
+                                   1 if packed else 0, _p(bias), _p(out), out.stride(0), M, N, K, epi, wsp, nbytes,
+                                   _stream()),
+              "md_linear_normed")
+        return out
     check(lib.md_linear(_p(x), x.stride(0), _p(wt), wd, 1 if packed else 0, _p(scales), _p(bias), _p(out),
-                        out.stride(0), M, N, K, epi,
-                        ctypes.c_void_p(ws.data_ptr() + off) if ws is not None else None, nbytes, _stream()),
+                        out.stride(0), M, N, K, epi, wsp, nbytes, _stream()),
           "md_linear")
     return out
 

@@ -217,3 +217,53 @@ def test_linear_add_rmsnorm_equals_linear_then_add_rmsnorm(ops, M, N, K, int8, p
     h, y = ops.linear_add_rmsnorm(x.to(DEV), wd, r.to(DEV), nw.to(DEV), 1e-5, scales=scales, workspace=ws)
     assert torch.equal(h.view(torch.int16), h_want.view(torch.int16))
     assert torch.equal(y.view(torch.int16), y_want.view(torch.int16))
+
+
+@pytest.mark.parametrize("M,N,K,swiglu,packed", [
+    (32, 28672, 4096, True, True),       # cfg2: the 8B w1|w3 of a draft pass (K split over workgroups)
+    (64, 16384, 2048, True, True),       # the 1B w1|w3 of a draft step
+    (1, 512, 256, False, False), (33, 1024, 1792, True, True), (100, 2048, 2048, False, True),
+    (128, 4096, 1024, True, False), (256, 1024, 4096, False, True), (64, 128256, 2048, False, True),
+])
+def test_linear_normed_equals_norm_then_linear(ops, M, N, K, swiglu, packed):
+    """Round 4: md_linear_normed -- the deferred RMSNorm on the weight-streaming kernel.  x is the un-normalised h with the
+    partial sums of squares the residual epilogue of md_linear_fused wrote; against md_rmsnorm followed by md_linear on
+    the same kernel the only arithmetic difference is the ORDER of the fp32 sum of squares (rstd in its last bit), so
+    nearly every output is bit-equal and none is further than 2 bf16 ulps away; the producer's real ssq is used (a
+    residual-epilogue launch), rows >= M and the ragged last slab included."""
+    g = torch.Generator().manual_seed(M * 3 + N + K)
+    prod_w = ops.PackedWeight((torch.randn(K, 256, generator=g) * 0.05).to(BF).to(DEV))
+    act = (torch.randn(M, 256, generator=g)).to(BF).to(DEV)
+    resid = torch.randn(M, K, generator=g).to(BF).to(DEV)
+    h, ssq = ops.fused_linear(act, prod_w, resid=resid, want_ssq=True)          # h [M, K], ssq [M, K / 32]
+    nw = (1 + 0.1 * torch.randn(K, generator=g)).to(BF).to(DEV)
+    w = (torch.randn(N, K, generator=g) * 0.05).to(BF).to(DEV)
+    wt = ops.PackedWeight(w, swiglu=swiglu) if packed else w
+    ws = ops.AttnWorkspace(DEV)
+    want = ops.linear(ops.rmsnorm(h, nw, 1e-5), wt, swiglu=swiglu, workspace=ws)
+    got = ops.linear(h, wt, swiglu=swiglu, workspace=ws, pro=ops.DeferredNorm(h, ssq, nw, 1e-5))
+    assert got.shape == want.shape and not torch.isnan(got.float()).any()
+    gi, wi = got.cpu().view(torch.int16), want.cpu().view(torch.int16)
+    eq = float((gi == wi).double().mean())
+    ulp = bf16_ulp(want.cpu().double()).float()
+    worst = float(((got.cpu().float() - want.cpu().float()).abs() / ulp).max())
+    parity_report(f"[gemm] md_linear_normed M={M} N={N} K={K} swiglu={swiglu} packed={packed}: bit-equal to "
+                  f"norm-then-linear {100 * eq:.3f}%, worst {worst:.2f} ulp")
+    assert eq >= 0.99 and worst <= 2.0
+    # same launch again: the same bits
+    again = ops.linear(h, wt, swiglu=swiglu, workspace=ws, pro=ops.DeferredNorm(h, ssq, nw, 1e-5))
+    assert torch.equal(again.view(torch.int16), got.view(torch.int16))
+
+
+def test_linear_normed_rejects_a_mismatched_norm(ops):
+    h = torch.randn(8, 256, device=DEV).to(BF)
+    w = torch.randn(64, 256, device=DEV).to(BF)
+    nw = torch.ones(256, device=DEV, dtype=BF)
+    ws = ops.AttnWorkspace(DEV)
+    with pytest.raises(ValueError):      # ssq must cover K / 32 tiles
+        ops.linear(h, w, workspace=ws, pro=ops.DeferredNorm(h, torch.zeros(8, 4, device=DEV), nw, 1e-5))
+    with pytest.raises(ValueError):      # x must be the h the sums belong to
+        ops.linear(h.clone(), w, workspace=ws, pro=ops.DeferredNorm(h, torch.zeros(8, 8, device=DEV), nw, 1e-5))
+    with pytest.raises(TypeError):       # bf16 weights only
+        ops.linear(h, torch.zeros(64, 256, dtype=torch.int8, device=DEV), scales=torch.ones(64, device=DEV, dtype=BF),
+                   workspace=ws, pro=ops.DeferredNorm(h, torch.zeros(8, 8, device=DEV), nw, 1e-5))

@@ -145,6 +145,9 @@ for model, tp, M in CASES:
         extra = ""
         if fused_pro is not None:
             extra += f" | pro: {timeit(fused_pro, a.iters):6.1f}"
+            if kind == "swiglu" and skinny_ok:                       # md_linear_normed: the same norm on the streaming kernel
+                extra += (f" | skinny+norm launch: {timeit(lambda i: ops.linear(ops.rmsnorm(x, pro.weight, 1e-5), pk[i % ncopy], swiglu=True, workspace=ws), a.iters):6.1f}"
+                          f" | skinny pro: {timeit(lambda i: ops.linear(x, pk[i % ncopy], swiglu=True, workspace=ws, pro=pro), a.iters):6.1f}")
         if a.tiles:
             import ctypes
             lib = _lib.load()
