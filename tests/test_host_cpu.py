@@ -1256,6 +1256,10 @@ def test_gemm_policy_encodes_the_measured_ab_table():
     assert c(128, 4096, 14336, "resid") == "skinny" and c(256, 4096, 4096, "resid") == "lib"
     assert c(256, 3584, 4096, "swiglu") == "lib" and c(256, 4096, 1792, "resid") == "lib"
     assert c(256, 2048, 8192, "resid") == "lib"
+    # round 4 (profiles/r04_skinny_norm_ab.txt): md_linear absorbs a deferred norm up to 64 rows only
+    if os.environ.get("MAGICDEC_SKINNY_NORM", "auto") == "auto":
+        assert g.skinny_absorbs_norm(1) and g.skinny_absorbs_norm(32) and g.skinny_absorbs_norm(64)
+        assert not g.skinny_absorbs_norm(65) and not g.skinny_absorbs_norm(128) and not g.skinny_absorbs_norm(256)
     # a streaming-layout copy only for weights some hand-written kernel can be chosen for
     assert g.want_packed(28672, 4096, True) and g.want_packed(4096, 14336) and g.want_packed(3072, 2048)
     assert not g.want_packed(1024, 16384) and not g.want_packed(4100, 4096)
