@@ -93,10 +93,25 @@ __global__ __launch_bounds__(256) void reduce_add_rmsnorm_kernel(const float* __
         const int i = threadIdx.x + it * 256;
         if (i < nvec) {
             f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
-            for (int s = 0; s < S; ++s) {
-                const float* pp = partial + s * plane + row * N + i * 8;
-                a0 += *reinterpret_cast<const f32x4*>(pp);
-                a1 += *reinterpret_cast<const f32x4*>(pp + 4);
+            // eight slices per trip, requested together and added in slice order: a load + add per loop trip was one
+            // memory round trip per slice (8.3 us for 32 rows x 8 slices; skinny_reduce_kernel does the same)
+            for (int s0 = 0; s0 < S; s0 += 8) {
+                f32x4 v0[8], v1[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    if (s0 + u < S) {                               // uniform: no load for a slice that does not exist
+                        const float* pp = partial + (s0 + u) * plane + row * N + i * 8;
+                        v0[u] = *reinterpret_cast<const f32x4*>(pp);
+                        v1[u] = *reinterpret_cast<const f32x4*>(pp + 4);
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    if (s0 + u < S) {                               // uniform
+                        a0 += v0[u];
+                        a1 += v1[u];
+                    }
+                }
             }
             f32x8 o;
 #pragma unroll

@@ -344,11 +344,25 @@ __global__ __launch_bounds__(256) void skinny_reduce_kernel(const GemmParams p) 
     const int row = (int)(t / per_row), c0 = (int)(t % per_row) * 4;
     const int64_t plane = (int64_t)p.M * p.N;
     f32x4 a = {0.f, 0.f, 0.f, 0.f}, b3 = {0.f, 0.f, 0.f, 0.f};
-    for (int s = 0; s < p.S; ++s) {
-        const float* pp = p.partial + s * plane + (int64_t)row * p.N + c0;
-        const f32x4 v = *reinterpret_cast<const f32x4*>(pp);
-        a += v;
-        if constexpr (EPI == EPI_SWIGLU) b3 += *reinterpret_cast<const f32x4*>(pp + (p.N >> 1));
+    // eight slices per trip, requested together and added in slice order (a load + add per loop trip is one memory round
+    // trip per slice)
+    for (int s0 = 0; s0 < p.S; s0 += 8) {
+        f32x4 va[8], vb[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            if (s0 + u < p.S) {                                     // uniform: no load for a slice that does not exist
+                const float* pp = p.partial + (s0 + u) * plane + (int64_t)row * p.N + c0;
+                va[u] = *reinterpret_cast<const f32x4*>(pp);
+                if constexpr (EPI == EPI_SWIGLU) vb[u] = *reinterpret_cast<const f32x4*>(pp + (p.N >> 1));
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            if (s0 + u < p.S) {                                     // uniform
+                a += va[u];
+                if constexpr (EPI == EPI_SWIGLU) b3 += vb[u];
+            }
+        }
     }
     bf16x4 o;
 #pragma unroll
