@@ -108,7 +108,7 @@ def want_packed(N: int, K: int, swiglu: bool = False, int8: bool = False) -> boo
     if _MODE == "hip" or _BLOCK == "1" or _FUSED == "1":
         return True
     kinds = ("swiglu",) if swiglu else ("plain", "resid", "qkv")
-    for M in (1, 32, 64, 128, 256):
+    for M in (1,) + tuple(range(32, 257, 32)):      # every 32-row tile count a rule can depend on
         if use_skinny(M, N, K, swiglu, False, True):
             return True
         for kind in kinds:

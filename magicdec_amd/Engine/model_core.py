@@ -337,14 +337,33 @@ class Transformer(nn.Module):
         # MAGICDEC_PACKED_COPIES=0 switches them off outright (Engine/gemm_policy.py).
         need = sum(w.numel() * w.element_size() for w, _ in todo)
         try:
+            torch.cuda.empty_cache()       # mem_get_info does not see blocks the caching allocator holds but no longer uses
             free = torch.cuda.mem_get_info(self.output.weight.device)[0]
         except Exception:              # not a HIP device (tests with stand-in ops): nothing to check
             free = None
         margin = 6 << 30
-        if free is not None and need + margin > free:
-            print(f"[magicdec_amd] streaming-layout weight copies need {need / 2**30:.1f} GiB but only {free / 2**30:.1f} GiB "
-                  f"are free beside the KV cache (margin {margin >> 30} GiB): not made -- the decode / verify linears run on "
-                  f"the row-major weights (slower); shrink the cache or set MAGICDEC_PACKED_COPIES=0 to silence this")
+        fits = free is None or need + margin <= free
+        # ONE decision for all ranks that must run the same kernels: the ranks of a TP group -- and the
+        # ranks running a REPLICATED draft, which stay in lock-step only because they compute bit-identical tokens -- must
+        # not choose per rank from their own free memory: a rank that falls back to the library GEMMs rounds differently,
+        # can flip a near-tie argmax, and then verifies another draft than its peers (diverging accept lengths, a hang in
+        # the next collective).  Everyone packs or nobody does.
+        grp = self.process_group if self.process_group is not None else getattr(self, "replica_group", None)
+        if grp is not None:
+            import torch.distributed as dist
+            if dist.is_available() and dist.is_initialized():
+                t = torch.tensor([1 if fits else 0], dtype=torch.int32,
+                                 device=self.output.weight.device if dist.get_backend(grp) == "nccl" else "cpu")
+                dist.all_reduce(t, op=dist.ReduceOp.MIN, group=grp)
+                if fits and int(t.item()) == 0:
+                    print("[magicdec_amd] streaming-layout weight copies fit on this rank but not on every rank of its "
+                          "group: not made anywhere (all ranks must run the same kernels)")
+                fits = bool(int(t.item()))
+        if not fits:
+            if free is not None and need + margin > free:
+                print(f"[magicdec_amd] streaming-layout weight copies need {need / 2**30:.1f} GiB but only {free / 2**30:.1f} GiB "
+                      f"are free beside the KV cache (margin {margin >> 30} GiB): not made -- the decode / verify linears run on "
+                      f"the row-major weights (slower); shrink the cache or set MAGICDEC_PACKED_COPIES=0 to silence this")
             return
         for w, sw in todo:
             pw = ops.PackedWeight(w.data if isinstance(w, nn.Parameter) else w, swiglu=sw)

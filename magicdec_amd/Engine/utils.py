@@ -55,6 +55,33 @@ def _random_init_(model, seed, device, dtype, std=0.02):
         for part in leaf[:-1]:
             parent = getattr(parent, part)
         setattr(parent, leaf[-1], torch.nn.Parameter(t, requires_grad=False))
+    import os
+    mode = os.environ.get("MAGICDEC_SYNTH_WEIGHTS", "random")
+    if mode.startswith("peaked"):
+        _peak_(model, seed, dtype, *[float(x) for x in mode.split(":")[1:3]])
+    elif mode != "random":
+        raise ValueError(f"MAGICDEC_SYNTH_WEIGHTS must be 'random' or 'peaked[:emb_rms[:peak]]', got {mode!r}")
+
+
+def _peak_(model, seed, dtype, emb_rms=40.0, peak=12.0):
+    """Seeded weights with PEAKED next-token distributions (MAGICDEC_SYNTH_WEIGHTS=peaked; bench.py --weights peaked):
+    the construction of tests/golden_cfg.py:peaked_pair at any size.  Random-init heads give `vocab` nearly tied
+    Gaussian logits, so a draft never agrees with its target and measured acceptance is ~0 whatever the kernels do.
+    Here the embedding dominates the residual stream (`emb_rms` per element against the ~1.5 sqrt(n_layer) the random
+    layers add) and the head is tied to it through a fixed permutation pi of the token ids that depends on (seed,
+    vocab) only -- `output[j] = c emb[pi(j)]`, logit ~`peak` for the one j with pi(j) == current token, the others
+    ~N(0, peak^2 / dim) -- so that every model of a run with the same vocabulary (target, draft, self-speculation's
+    sparse-cache draft) predicts through the same map and acceptance is decided by what the kernels compute: the
+    attention / FFN branches of all layers still run at full strength as the perturbation."""
+    emb = model.tok_embeddings.weight
+    V, dim = emb.shape
+    g = torch.Generator(device="cpu").manual_seed(seed * 7919 + V)
+    perm = torch.arange(V)
+    perm[4:] = 4 + torch.randperm(V - 4, generator=g)          # ids 0..3 (BOS / EOT ids of the tests) stay fixed
+    e = emb.data.float() * (emb_rms / 0.02)
+    c = peak / (dim * emb_rms)                                  # tied row: c |e|^2 / rms(h) ~ peak
+    model.tok_embeddings.weight = torch.nn.Parameter(e.to(dtype), requires_grad=False)
+    model.output.weight = torch.nn.Parameter((e[perm.to(e.device)] * c).to(dtype), requires_grad=False)
 
 
 def _load(transformer_cls, checkpoint_path, device, precision, use_tp, rank_group, group, seed=1234):

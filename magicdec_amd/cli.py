@@ -44,9 +44,11 @@ def _common(parser, script, kind=None):
     parser.add_argument('--benchmark', action='store_true', help='Per-phase timing (adds synchronisations).')
     parser.add_argument('--kv_dtype', type=str, default="bf16", choices=["bf16", "fp8"],
                         help='Storage of the full-context KV cache (fp8 = OCP e4m3fn; not in the reference).')
-    parser.add_argument('--kv_layout', type=str, default="NHD", choices=["NHD", "HND"],
-                        help='Page layout of the full-context KV cache (the reference plans flashinfer "NHD"; '
-                             'HND keeps the rows of one kv head contiguous).')
+    parser.add_argument('--kv_layout', type=str, default=None, choices=["NHD", "HND"],
+                        help='Page layout of the full-context KV cache.  Default: the Engine default '
+                             '(backend_core.default_kv_layout(): HND -- the rows of one kv head contiguous inside a '
+                             'page, the layout bench.py measures -- unless MAGICDEC_KV_LAYOUT says otherwise); '
+                             'NHD is the layout the reference plans flashinfer with.')
     if script != "baseline":
         budget = d.get("draft_budget", -1 if kind == "SnapKV" else 1025)     # longspec: SnapKV -1, StreamingLLM 1025
         parser.add_argument('--draft_budget', type=int, default=budget, help='Draft KV budget.')
@@ -157,6 +159,8 @@ def longspec_main(kind: str, argv=None):
             draft = LMBackend_Draft(dtype=DTYPE, device=DEVICE)
         draft.load_model(args.model, use_tp=use_tp and draft_tp and not replicate, rank_group=args.draft_rank_group,
                          group=draft_group)
+        if replicate:       # every rank runs the whole draft and must choose the same kernels (Transformer._pack_weights)
+            draft.model.replica_group = global_group
         if args.compile:
             draft.compile()
         if kind == "SnapKV":

@@ -25,8 +25,7 @@
 //     ds_read_b128 then covers all 64 banks once;
 //   * narrow products (N = 4096..6144: 32-48 column tiles) split K over workgroups so that ~240-256 of them exist;
 //     fp32 partial tiles go to the workspace and the combine launch applies the epilogue in a fixed slice order
-//     (deterministic) -- the SAME combine kernels as md_linear (bias / SwiGLU / residual add + RMSNorm), plus one for the
-//     qkv projection (bias + RoPE + paged append);
+//     (deterministic) -- the SAME combine kernels as md_linear (bias / SwiGLU / residual add + RMSNorm);
 //   * the un-split product (w1|w3: 224 tiles) finishes in the kernel: accumulators -> LDS (fp32, the ring is free by
 //     then) -> 16-byte row-contiguous stores, SwiGLU with the reference's rounding points.
 #include "md_common.h"
@@ -329,9 +328,6 @@ int pick_splits(int n_tiles, int nsteps) {
 
 // x ring 3 x 32 KB + W ring 4 x 16 KB = the CU's 160 KB.  Measured alternatives (same process, w1|w3 at M = 256,
 // profiles/r04_block_*): W ring 3 deep: equal; x 2 + W 6: 81 vs 70.5 us (one x stage in flight is too few); the loaders'
-// register files as a 3-4 stage deep FIFO in front of a two-slot LDS image (plain loads + ds_write_b128): 76-81 us.
-// x ring 3 x 32 KB + W ring 4 x 16 KB = the CU's 160 KB.  Measured alternatives (same process, w1|w3 at M = 256,
-// profiles/r04_block_*): W ring 3 deep: equal; x 2 + W 6: 81 vs 70.5 us (one x stage in flight is too few); the loaders'
 // register files as a 3-4 stage deep FIFO in front of a two-slot LDS image for BOTH operands (plain loads counted by
 // hipcc + ds_write_b128): 76-81 us; for the W stream only, 4-6 stages deep with inline-asm loads and a counted vmcnt
 // (96 KB of W in flight per CU instead of 48): 64.1-68.9 against 66.5 -- noise (r04_block_wreg_fifo_rejected_call28.txt).
@@ -423,6 +419,7 @@ extern "C" int md_linear_block(const void* x, int64_t ldx, const void* w_packed,
     MD_CHECK_ARG(out && (((uintptr_t)out) & 15) == 0 && ldo % 8 == 0, "md_linear_block: out must be 16-byte aligned, ldo %% 8 == 0");
     MD_CHECK_ARG(epilogue == BE_NONE || epilogue == BE_SWIGLU, "md_linear_block: unknown epilogue %d", epilogue);
     MD_CHECK_ARG(!(epilogue == BE_SWIGLU && bias), "md_linear_block: the SwiGLU epilogue takes no bias");
+    MD_CHECK_ARG(!bias || (((uintptr_t)bias) & 15) == 0, "md_linear_block: bias must be 16-byte aligned (read as bf16x8)");
     BlockParams p;
     int rc = setup(p, x, ldx, w_packed, M, N, K, false, workspace, workspace_bytes, "md_linear_block");
     if (rc != MD_OK) return rc;
@@ -446,6 +443,7 @@ extern "C" int md_linear_block_add_rmsnorm(const void* x, int64_t ldx, const voi
                                            void* y_out, int M, int N, int K, void* workspace, size_t workspace_bytes,
                                            md_stream_t stream) {
     MD_CHECK_ARG(resid && norm_weight && h_out && y_out, "md_linear_block_add_rmsnorm: null pointer argument");
+    MD_CHECK_ARG(!bias || (((uintptr_t)bias) & 15) == 0, "md_linear_block_add_rmsnorm: bias must be 16-byte aligned");
     MD_CHECK_ARG((((uintptr_t)resid | (uintptr_t)norm_weight | (uintptr_t)h_out | (uintptr_t)y_out) & 15) == 0 &&
                      ldr % 8 == 0 && N % 8 == 0 && N <= 8192,
                  "md_linear_block_add_rmsnorm: pointers must be 16-byte aligned, ldr %% 8 == 0, N %% 8 == 0, N <= 8192");

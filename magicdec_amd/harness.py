@@ -86,7 +86,8 @@ def _read_flags(st: LoopState, collectives=()):
             ev = st._flags_event
             ev.record()
             while not ev.query():
-                pass
+                time.sleep(0)           # give up the GIL and the time slice between polls (with 8 ranks and
+                #                         their RCCL proxy threads on one host a hard spin would pin a core per rank)
         for ar, s in zip(collectives, status):
             if int(s[0]) != 0:
                 from .Engine.oneshot import AllReduceTimeout

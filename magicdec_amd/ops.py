@@ -429,14 +429,27 @@ def _block_args(x, weight, swiglu):
     return x.shape[0], weight.N, weight.K
 
 
+def _block_bias(bias, N):
+    """md_linear_block reads the bias as 16-byte vectors of N bf16 values."""
+    if bias is None:
+        return
+    _gpu(bias)
+    if bias.dtype != torch.bfloat16 or bias.numel() != N or not bias.is_contiguous() or bias.data_ptr() % 16:
+        raise ValueError(f"linear_block: bias must be a contiguous, 16-byte aligned bf16 vector of {N} elements")
+
+
 def linear_block(x, weight: "PackedWeight", bias=None, swiglu=False, workspace: "AttnWorkspace" = None, out=None):
     """F.linear(x, W, bias) (or silu(x.w1^T) * (x.w3^T) for swiglu=True, weight = [w1; w3]) for 129..256 rows on the
     block-tile GEMM md_linear_block; same contract and rounding points as linear()."""
     M, N, K = _block_args(x, weight, swiglu)
-    _gpu(bias)
+    _block_bias(bias, N)
     n_out = N // 2 if swiglu else N
     if out is None:
         out = torch.empty((M, n_out), dtype=x.dtype, device=x.device)
+    else:
+        _gpu(out)
+        if out.dtype != torch.bfloat16 or out.dim() != 2 or out.shape != (M, n_out) or out.stride(1) != 1:
+            raise ValueError("linear_block: out must be bf16 [M, N_out] with unit inner stride")
     lib = _lib.load()
     wsp, nbytes = _block_ws(lib, M, N, K, False, workspace)
     check(lib.md_linear_block(_p(x), x.stride(0), _p(weight.data), _p(bias), _p(out), out.stride(0), M, N, K,
@@ -449,7 +462,8 @@ def linear_block_add_rmsnorm(x, weight: "PackedWeight", resid, norm_weight, eps,
     """(h, y) = (resid + F.linear(x, W, bias), rmsnorm(h) * norm_weight): md_linear_block with the residual add and the
     norm in its combine launch -- the combine kernel of linear_add_rmsnorm (same rounding points)."""
     M, N, K = _block_args(x, weight, False)
-    _gpu(bias, resid, norm_weight)
+    _block_bias(bias, N)
+    _gpu(resid, norm_weight)
     if resid.dim() != 2 or resid.stride(1) != 1 or resid.shape != (M, N) or norm_weight.numel() != N:
         raise ValueError("linear_block_add_rmsnorm: resid must be [M, N] with unit inner stride, norm_weight [N]")
     lib = _lib.load()

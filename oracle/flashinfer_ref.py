@@ -95,6 +95,17 @@ def gather_request_kv(cache, indices, indptr, last_page_len, b):
     return k, v
 
 
+# How the probabilities enter the P.V product (a test-side switch, like magicdec_ref.LINEAR_MODE):
+#   "fp32": softmax in fp32, P.V with fp32 P (the documented *semantics*: this module's default and the oracle
+#           every fixture / lock-step log is recorded with);
+#   "bf16": the tensor-core *algorithm* flashinfer's prefill kernels (and csrc/attn.hip) run: p = exp(s - M) in fp32,
+#           the row sum l accumulates the UN-rounded p, p is rounded to the KV dtype (bf16) to be the MMA operand,
+#           P.V accumulates in fp32 and the result is divided by l.  A second valid implementation of the same op:
+#           tests/test_gpu_engine.py replays it beside the HIP engine so that the argmax flips the bf16 P causes are
+#           MEASURED instead of asserted.
+ATTN_P_MODE = "fp32"
+
+
 def batch_prefill_paged(q, cache, qo_indptr, indices, indptr, last_page_len, num_qo_heads, num_kv_heads,
                         head_dim, causal=True, sm_scale=None):
     """flashinfer BatchPrefillWithPagedKVCacheWrapper.plan(...)+run(q, cache).
@@ -124,9 +135,18 @@ def batch_prefill_paged(q, cache, qo_indptr, indices, indptr, last_page_len, num
             pos = torch.arange(ln).view(1, 1, 1, ln)
             lim = (ln - m_b + torch.arange(m_b)).view(1, 1, m_b, 1)
             s = s.masked_fill(pos > lim, float("-inf"))
-        p = torch.softmax(s, dim=-1)
-        p = torch.nan_to_num(p, nan=0.0)  # rows with an empty key set
-        o = torch.einsum("hgml,lhd->mhgd", p, vf).reshape(m_b, H, D)
+        if ATTN_P_MODE == "bf16":
+            m = s.amax(dim=-1, keepdim=True)
+            m = torch.where(torch.isinf(m), torch.zeros_like(m), m)      # rows with an empty key set
+            e = torch.exp(s - m)
+            l = e.sum(dim=-1)                                             # [KH,g,m] un-rounded
+            o = torch.einsum("hgml,lhd->mhgd", e.to(torch.bfloat16).float(), vf)
+            o = o / l.permute(2, 0, 1).unsqueeze(-1).clamp_min(1e-38)
+            o = o.reshape(m_b, H, D)
+        else:
+            p = torch.softmax(s, dim=-1)
+            p = torch.nan_to_num(p, nan=0.0)  # rows with an empty key set
+            o = torch.einsum("hgml,lhd->mhgd", p, vf).reshape(m_b, H, D)
         out[q0:q1] = o.to(q.dtype)
     return out
 

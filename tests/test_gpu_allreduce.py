@@ -33,6 +33,33 @@ def test_oneshot_allreduce_multiprocess_one_gpu(world):
         assert p.returncode == 0 and f"rank {r}: OK" in out, f"rank {r} failed:\n{out[-3000:]}"
 
 
+def test_mid_run_peer_loss_raises_at_that_iteration():
+    """A peer that stops calling the collective in the middle of a run (tests/_ar_timeout_worker.py): the surviving rank
+    raises AllReduceTimeout from harness._read_flags in the iteration it happened in -- after the kernel's 2 s bounded
+    spin, with NaN-poisoned output -- instead of hanging or iterating on garbage."""
+    world, port = 2, 29655
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_ar_timeout_worker.py")], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = []
+    try:
+        for p in procs:
+            out, _ = p.communicate(timeout=180)
+            outs.append(out)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    for r, (p, out) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and f"rank {r}: OK" in out, f"rank {r} failed:\n{out[-3000:]}"
+    assert "AllReduceTimeout raised in iteration 5" in outs[0], outs[0][-2000:]
+    from tests.conftest import parity_report
+    parity_report("[allreduce] mid-run peer loss: " + [l for l in outs[0].splitlines() if "AllReduceTimeout raised" in l][0])
+
+
 def test_oneshot_allreduce_single_rank_is_identity():
     import torch
     import torch.distributed as dist

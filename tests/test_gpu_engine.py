@@ -101,57 +101,100 @@ class Recorder:
 
 class Stats:
     def __init__(self):
-        self.npos = self.nties = self.nties_alt = self.calls = 0
-        self.err_hip = self.err_alt = self.worst_ratio = 0.0
+        self.npos = self.nties = self.nties_alt = self.nties_p = self.nties_both = self.calls = 0
+        self.err_hip = self.err_alt = self.err_p = self.err_both = self.worst_ratio = 0.0
 
     def line(self, tag):
         return (f"[lockstep] {tag:34s} calls={self.calls:4d} positions={self.npos:6d} argmax flips vs the oracle: hip="
-                f"{self.nties:3d} fp64-linear oracle={self.nties_alt:3d}  max|hip-oracle|={self.err_hip:.4f}  "
-                f"max|fp64oracle-oracle|={self.err_alt:.4f}  worst err_hip/gate={self.worst_ratio:.3f}")
+                f"{self.nties:3d} fp64-linear oracle={self.nties_alt:3d} bf16-P oracle={self.nties_p:3d} "
+                f"fp64-linear+bf16-P oracle={self.nties_both:3d}  max|hip-oracle|={self.err_hip:.4f}  "
+                f"max|fp64oracle-oracle|={self.err_alt:.4f}  max|bf16P-oracle|={self.err_p:.4f}  "
+                f"max|fp64+bf16P-oracle|={self.err_both:.4f}  worst err_hip/gate={self.worst_ratio:.3f}")
+
+
+# Flip-count gate.  The HIP attention runs the tensor-core algorithm (P rounded to bf16 before the
+# P.V product, as flashinfer's kernels do); rounds 2-4 ASSERTED that this explains why the HIP engine flips more
+# near-tie argmaxes than the float64-linear yardstick.  Now it is measured: the bf16-P oracle ALONE flips 18-20 of
+# ~1 000-1 700 positions where the float64-linear one flips 6-13 and the HIP engine 15-18 (tools/lockstep_yardsticks.py
+# on the CPU; profiles/r05_parity_report.txt on the GPU box).  Gate: the HIP count may exceed the larger of the two
+# bf16-P yardsticks by 3 plus one standard deviation of a count of that size (two valid implementations are two draws of
+# the same near-tie lottery; the oracle's own log differs from host to host).
+def flip_gate(n_p, n_both):
+    y = max(n_p, n_both)
+    return y + 3 + y ** 0.5
+
+
+def _oracle_call(eng, rec, linear_mode, p_mode):
+    """One recorded call on a CPU oracle engine under the given arithmetic modes; returns (tokens, logits)."""
+    from oracle import flashinfer_ref as fr
+    for k in MUT:
+        if k in rec["pre"] and getattr(eng, k, None) is not None:
+            setattr(eng, k, rec["pre"][k].clone())
+    if "kv_scales" in rec:
+        eng.kv_scale_override = rec["kv_scales"]
+    kwa = {}
+    if rec["cu"] is not None:
+        kwa["cachelen_update"] = rec["cu"].clone()
+    mr.LINEAR_MODE, fr.ATTN_P_MODE = linear_mode, p_mode
+    try:
+        with capped_threads():          # the yardsticks only; the oracle's own run keeps torch's default
+            out = getattr(eng, rec["fn"])(rec["ids"].clone(), **kwa)
+    finally:
+        mr.LINEAR_MODE, fr.ATTN_P_MODE = "fp32", "fp32"
+    for k, v in rec["post"].items():
+        assert getattr(eng, k).tolist() == v.tolist(), ("yardstick oracle", linear_mode, p_mode, rec["tag"], rec["fn"], k)
+    return out, eng.model.last_logits.float()
 
 
 def replay(log, engines, alt_engines):
-    """Replays the oracle's call log on the HIP back-ends and on the float64-linear oracle; gates per call."""
+    """Replays the oracle's call log on the HIP back-ends and on three yardstick oracles -- float64 linears (another
+    summation order), bf16 P in the attention's P.V product (the tensor-core algorithm; oracle.flashinfer_ref
+    .ATTN_P_MODE), and both together (the arithmetic class the HIP engine belongs to); gates per call.  `engines` may
+    be None: the yardsticks alone (CPU), used by tools/lockstep_yardsticks.py."""
+    import copy
     st = Stats()
+    p_engines = copy.deepcopy(alt_engines)       # fresh engines: same weights, empty caches
+    both_engines = copy.deepcopy(alt_engines)
     for rec in log:
-        e, a = engines[rec["tag"]], alt_engines[rec["tag"]]
+        a = alt_engines[rec["tag"]]
+        out_alt, la = _oracle_call(a, rec, "fp64", "fp32")
+        out_p, lp = _oracle_call(p_engines[rec["tag"]], rec, "fp32", "bf16")
+        out_both, lb = _oracle_call(both_engines[rec["tag"]], rec, "fp64", "bf16")
+        ref = rec["logits"]
+        want = rec["out"]
+        st.calls += 1
+        st.npos += want.numel()
+        err_alt = (la.view(ref.shape) - ref).abs().max().item()
+        st.err_alt = max(st.err_alt, err_alt)
+        st.err_p = max(st.err_p, (lp.view(ref.shape) - ref).abs().max().item())
+        st.err_both = max(st.err_both, (lb.view(ref.shape) - ref).abs().max().item())
+        # the yardsticks' own flips: valid implementations of the same bf16 arithmetic also land on the other side of
+        # the oracle's near-ties
+        st.nties_alt += int((out_alt.view(want.shape) != want).sum())
+        st.nties_p += int((out_p.view(want.shape) != want).sum())
+        st.nties_both += int((out_both.view(want.shape) != want).sum())
+        if engines is None:
+            continue
+        e = engines[rec["tag"]]
         for k in MUT:
-            if k in rec["pre"]:
-                if getattr(e, k, None) is not None:
-                    setattr(e, k, rec["pre"][k].clone().to(DEV))
-                if getattr(a, k, None) is not None:
-                    setattr(a, k, rec["pre"][k].clone())
-        if "kv_scales" in rec:      # fp8 cache: both replays quantise with the oracle's static scales
+            if k in rec["pre"] and getattr(e, k, None) is not None:
+                setattr(e, k, rec["pre"][k].clone().to(DEV))
+        if "kv_scales" in rec:      # fp8 cache: all replays quantise with the oracle's static scales
             e.model.kv_scale_override = [(ks.to(DEV), vs.to(DEV)) for ks, vs in rec["kv_scales"]]
-            a.kv_scale_override = rec["kv_scales"]
-        kw, kwa = {}, {}
+        kw = {}
         if rec["cu"] is not None:
             kw["cachelen_update"] = rec["cu"].to(DEV)
-            kwa["cachelen_update"] = rec["cu"].clone()
         out = getattr(e, rec["fn"])(rec["ids"].to(DEV), **kw).cpu()
-        mr.LINEAR_MODE = "fp64"
-        try:
-            with capped_threads():          # the float64 yardstick only; the oracle's own run keeps torch's default
-                out_alt = getattr(a, rec["fn"])(rec["ids"].clone(), **kwa)
-        finally:
-            mr.LINEAR_MODE = "fp32"
         for k, v in rec["post"].items():
             assert getattr(e, k).cpu().tolist() == v.tolist(), (rec["tag"], rec["fn"], k)
-            assert getattr(a, k).tolist() == v.tolist(), ("alt oracle", rec["tag"], rec["fn"], k)
-        ref = rec["logits"]
         lg = e.model._last_logits.float().cpu().view(ref.shape)
-        la = a.model.last_logits.float().view(ref.shape)
         err_hip = (lg - ref).abs().max().item()
-        err_alt = (la - ref).abs().max().item()
         gate = GATE_FACTOR * err_alt + GATE_ULPS * _ulp_at(ref.abs().max().item())
-        st.calls += 1
-        st.err_hip, st.err_alt = max(st.err_hip, err_hip), max(st.err_alt, err_alt)
+        st.err_hip = max(st.err_hip, err_hip)
         st.worst_ratio = max(st.worst_ratio, err_hip / gate)
         assert err_hip <= gate, (rec["tag"], rec["fn"], f"err_hip {err_hip:.5f} > gate {gate:.5f} (err_alt {err_alt:.5f})")
-        want = rec["out"]
         assert out.shape == want.shape
         neq = out != want
-        st.npos += want.numel()
         if neq.any():
             # an argmax the allowed logit error can flip: the ORACLE's logit of our token within 2*gate of its maximum
             olg = ref.view(-1, ref.shape[-1])
@@ -160,19 +203,13 @@ def replay(log, engines, alt_engines):
             ok = (best - ours) <= 2 * gate
             assert bool(ok[neq].all()), (rec["tag"], rec["fn"], out[neq], want[neq], (best - ours)[neq], gate)
             st.nties += int(neq.sum())
-        # the yardstick's own flips: the correctly rounded (float64-linear) implementation of the same bf16 arithmetic
-        # also lands on the other side of the oracle's near-ties
-        st.nties_alt += int((out_alt.view(want.shape) != want).sum())
-    # Sanity bound on the COUNT (each single flip was already required to sit inside the oracle's own near-tie gap).
-    # Measured (profiles/r03_parity_report.txt): the float64-linear oracle itself flips 2-13 argmaxes per ~1000
-    # positions of these near-flat distributions, the HIP engine 4-18 -- it carries one more legitimate error source
-    # than that yardstick models, the bf16 P of the tensor-core attention algorithm (bound in tests/parity_util.py;
-    # flashinfer's kernels round P the same way).  On peaked distributions both counts are zero
+    # Bound on the COUNT (each single flip was already required to sit inside the oracle's own near-tie gap): against
+    # the bf16-P yardsticks, see flip_gate (rounds 2-4: hip <= 2 x float64-linear + 6).  All four counts are in every
+    # [lockstep] line of the parity report.  On peaked distributions all counts are zero
     # (test_peaked_logits_lockstep_has_zero_token_flips).
-    # The gate is the measured envelope (17 runs of profiles/r03_parity_report.txt, worst cases 18 vs 8 and 11 vs 4), not a
-    # loose multiple of it (VERDICT r3 weak #1b: 3 x alt + 10 would have let 10 flips through beside a perfect yardstick).
-    assert st.nties <= 2 * st.nties_alt + 6, \
-        f"hip flipped {st.nties} argmaxes vs the oracle, the float64-linear oracle {st.nties_alt}"
+    assert st.nties <= flip_gate(st.nties_p, st.nties_both), \
+        (f"hip flipped {st.nties} argmaxes vs the oracle; yardsticks: float64-linear {st.nties_alt}, bf16-P "
+         f"{st.nties_p}, both {st.nties_both} (gate {flip_gate(st.nties_p, st.nties_both):.1f}): a kernel carries a bias")
     return st
 
 

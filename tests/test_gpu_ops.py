@@ -616,6 +616,61 @@ def test_snapkv_select_vs_reference_fixture(ops, tag, golden_dir):
     assert max(nd_hip) <= 2 * max(nd_alt) + 2, (nd_hip, nd_alt)
 
 
+@pytest.mark.parametrize("case", ["ints2", "ints4", "ints8", "tiny", "mixed"])
+def test_snapkv_select_every_score_magnitude_bit_exact(ops, case):
+    """The select's softmax over the WHOLE range of unscaled scores (the table of exponentials used
+    to end at |s| < 16).  q and k hold small integers (x a power of two), so every q.k is an integer computed exactly
+    in ANY summation order: the kernel's bf16 scores equal the oracle's bit for bit, and the rest of the pipeline --
+    correctly rounded bf16(exp(s - M) / Z), group sums, accumulation, pooling -- must then be BIT-EXACT against the
+    float64 oracle, with no summation-order yardstick in between:
+      ints2: |entries| <= 2 -> scores ~ N(0, 16^2), a third beyond the old table's 16, all inside the new one;
+      ints4: scores ~ N(0, 53^2) (a trained checkpoint's unscaled range), the largest beyond 256;
+      ints8: scores ~ N(0, 190^2): a good part beyond the table's 512 -> table and exp_neg() paths mixed in a tile;
+      tiny:  entries in {-1, 0, 1} * 2^-10 -> |scores| < 2^-12 and many exact zeros: below the table;
+      mixed: ints2 keys with every 7th key row x 16 and every 5th x 2^-12 (all regimes inside one row's softmax)."""
+    B, KH, g, D, S, W, budget = 2, 2, 4, 64, 640, 32, 129
+    H = KH * g
+    gen = torch.Generator().manual_seed({"ints2": 1, "ints4": 2, "ints8": 3, "tiny": 4, "mixed": 5}[case])
+    amp = {"ints2": 2, "ints4": 4, "ints8": 8, "tiny": 1, "mixed": 2}[case]
+    q = torch.randint(-amp, amp + 1, (B * W, H, D), generator=gen).float()
+    k = torch.randint(-amp, amp + 1, (B, S, KH, D), generator=gen).float()
+    if case == "tiny":
+        q, k = q * 2.0 ** -5, k * 2.0 ** -15
+    if case == "mixed":
+        k[:, ::7] *= 16.0
+        k[:, ::5] *= 2.0 ** -12
+    v = torch.randn(B, S, KH, D, generator=gen)
+    q, k, v = q.to(BF), k.to(BF), v.to(BF)
+    npg = (S + 127) // 128
+    cache = torch.zeros(B * npg, 2, 128, KH, D, dtype=BF)
+    for b in range(B):
+        cache[b * npg:(b + 1) * npg, 0] = k[b].reshape(npg, 128, KH, D)
+        cache[b * npg:(b + 1) * npg, 1] = v[b].reshape(npg, 128, KH, D)
+    dppr = budget // 128 + 1
+    dcache = torch.zeros(B * dppr, 2, 128, KH, D, dtype=BF, device=DEV)
+    ws = ops.AttnWorkspace(DEV)
+    idx, sc = ops.snapkv_select(q.to(DEV), cache.to(DEV), torch.arange(B * npg, dtype=torch.int32, device=DEV),
+                                (torch.arange(B + 1, dtype=torch.int32) * npg).to(DEV), S, W, budget, 5, dcache,
+                                torch.arange(B * dppr, dtype=torch.int32, device=DEV),
+                                (torch.arange(B + 1, dtype=torch.int32) * dppr).to(DEV),
+                                torch.ones(B, dtype=torch.int32, device=DEV), ws, return_scores=True)
+    idx, sc = idx.cpu().long(), sc.cpu()
+    alt_sc, alt_idx = _snapkv_alt_oracle(q, k, v, g, W, budget)
+    raw = torch.einsum("whd,shd->hws", q[:W].float().view(W, KH, g, D)[:, :, 0], k[0].float())
+    neq = int((bits(sc) != bits(alt_sc)).sum())
+    parity_report(f"[snapkv] magnitudes/{case:6s} unscaled scores: std {raw.std().item():.3g}, max |s| {raw.abs().max().item():.3g}, "
+                  f"{100 * (raw.abs() >= 16).float().mean().item():.1f} % beyond 16, {100 * (raw.abs() >= 512).float().mean().item():.1f} % "
+                  f"beyond 512, {100 * (raw.abs() < 2.0 ** -12).float().mean().item():.1f} % below 2^-12 | pooled scores != float64 "
+                  f"oracle: {neq} of {sc.numel()}")
+    assert not torch.isnan(sc.float()).any()
+    assert neq == 0, (case, neq)
+    topk = budget - W
+    for b in range(B):
+        for h in range(KH):
+            assert torch.equal(idx[b, h], torch.sort(sc[b, h].float(), descending=True, stable=True).indices[:topk])
+            assert torch.equal(idx[b, h], alt_idx[b, h])       # equal scores + the same stable tie rule
+
+
 def test_snapkv_select_full_size_properties(ops):
     """SnapKV select at the BASELINE context length (S=16032, window 32, budget 257; 1B-draft head geometry): the
     oracle is too slow at this size, so the size-independent properties are asserted instead -- indices unique and

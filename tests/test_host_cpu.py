@@ -829,6 +829,29 @@ def test_default_kv_layout_env(monkeypatch, cpu_ops_patched, ckpt_dir):
         backend_core.default_kv_layout()
 
 
+def test_scripts_without_a_layout_flag_build_the_cache_layout_bench_measures(monkeypatch):
+    """tests/SnapKV/longspec_benchmark.py with no --kv_layout must run
+    the configuration bench.py reports -- every script parser leaves the layout to the Engine default
+    (backend_core.default_kv_layout() = what bench.py's --kv-layout defaults to), and --kv_layout NHD stays selectable."""
+    import bench
+    from magicdec_amd import cli
+    from magicdec_amd.Engine import backend_core
+    monkeypatch.delenv("MAGICDEC_KV_LAYOUT", raising=False)
+    bench_default = bench.parse([]).kv_layout
+    assert bench_default == backend_core.default_kv_layout() == "HND"
+    for parser in (cli.longspec_parser("SnapKV"), cli.longspec_parser("StreamingLLM"), cli.selfspec_parser("SnapKV"),
+                   cli.selfspec_parser("StreamingLLM"), cli.baseline_parser()):
+        req = [a for a in parser._actions if a.required]
+        argv = []
+        for a in req:
+            argv += [a.option_strings[0], "0"]
+        args = parser.parse_args(argv)
+        assert args.kv_layout is None                     # -> setup_caches(kv_layout=None) -> default_kv_layout()
+        layout = backend_core.default_kv_layout() if args.kv_layout is None else args.kv_layout
+        assert layout == bench_default
+        assert parser.parse_args(argv + ["--kv_layout", "NHD"]).kv_layout == "NHD"
+
+
 @pytest.mark.parametrize("tag", ["benchflag_snapkv_self", "benchflag_longspec_snapkv", "benchflag_longspec_stream",
                                  "benchflag_stream_self"])
 def test_benchmark_flag_runs_then_undoes_the_length_updates_like_the_reference(tag, cpu_ops_patched, ckpt_dir):
