@@ -544,7 +544,10 @@ def run(args, dev):
         "autoregressive_ms_per_step": round(dt_base / base_steps * 1e3, 4),
         "measured_acceptance_run": {"tokens_per_s": round(tok_meas / dt_meas, 2),
                                     "tokens_per_iter_per_seq": round(tok_meas / meas_steps / B, 3),
-                                    "ms_per_step": round(dt_meas / meas_steps * 1e3, 4)},
+                                    "accepted_drafts_per_drafted": round((tok_meas / meas_steps / B - 1) / G, 4),
+                                    "speedup_vs_autoregressive": round(tok_meas / dt_meas / base_tps, 4),
+                                    "ms_per_step": round(dt_meas / meas_steps * 1e3, 4),
+                                    "weights": weights},
         "prefill_s": round(t_pf, 2), "load_s": round(t_load, 2),
         # what "identical to the reference" means for this path (checked by `pytest -m gpu` and smoke(), not here)
         "parity": {"tokens": "identity with the CPU oracle, tie-aware: argmax flips <= 2 x those of a float64-linear "
@@ -574,21 +577,27 @@ def run(args, dev):
     return line if rank == 0 else None
 
 
-def speedup_condition(speedup_by_alpha, alpha, target=1.8):
+def speedup_condition(speedup_by_alpha, alpha, targets=(1.0, 1.8)):
     """What the headline speed-up is conditional on: `value` replays a FIXED acceptance rate, so
     "x over autoregressive" holds iff the real draft reaches that rate.  Linear interpolation of the measured
-    alpha -> speed-up sweep at `target` (north_star: >= 1.8x)."""
+    alpha -> speed-up sweep at break-even (1.0x) and at north_star's target (>= 1.8x)."""
     pts = sorted(speedup_by_alpha.items())
     head = f"speedup_vs_autoregressive is the fixed-acceptance replay at alpha={alpha}"
     if len(pts) < 2:
         return head + "; no alpha sweep in this run"
-    if pts[0][1] >= target:
-        return head + f"; >= {target}x already at alpha = {pts[0][0]} (lowest rate swept)"
-    for (a0, s0), (a1, s1) in zip(pts, pts[1:]):
-        if s0 < target <= s1:
-            a = a0 + (target - s0) * (a1 - a0) / (s1 - s0)
-            return head + f"; >= {target}x iff alpha >= {a:.2f} (interpolated between the measured {a0} -> {s0:.2f}x and {a1} -> {s1:.2f}x)"
-    return head + f"; {target}x is not reached at any swept alpha (best {pts[-1][1]:.2f}x at {pts[-1][0]})"
+    out = []
+    for target in targets:
+        if pts[0][1] >= target:
+            out.append(f">= {target}x already at alpha = {pts[0][0]} (lowest rate swept)")
+            continue
+        for (a0, s0), (a1, s1) in zip(pts, pts[1:]):
+            if s0 < target <= s1:
+                a = a0 + (target - s0) * (a1 - a0) / (s1 - s0)
+                out.append(f">= {target}x iff alpha >= {a:.2f} (between the measured {a0} -> {s0:.2f}x and {a1} -> {s1:.2f}x)")
+                break
+        else:
+            out.append(f"{target}x is not reached at any swept alpha (best {pts[-1][1]:.2f}x at {pts[-1][0]})")
+    return head + "; " + "; ".join(out)
 
 
 def allreduce_plan(engine, draft, B, G, tp, draft_tp):

@@ -43,12 +43,13 @@ def main():
             assert bool(torch.isnan(x.float()).any()), "rows that could not be completed must be NaN-poisoned"
             assert ar.status() != 0
             print(f"rank 0: AllReduceTimeout raised in iteration {it} after {dt:.2f} s, "
-                  f"{int(torch.isnan(x.float()).sum())} of {n} elements NaN")
+                  f"{int(torch.isnan(x.float()).sum())} of {n} elements NaN", flush=True)
             break
         assert it < good, "rank 0 did not notice the missing peer"
         assert bool((x.float() == 3.0).all()), (it, x[:4])
     dist.barrier()              # rank 1 waits here (host side) while rank 0's kernel spins
-    print(f"rank {rank}: OK")
+    print(f"rank {rank}: OK", flush=True)
+    sys.stdout.flush()
     os._exit(0)                 # the communicators' sequence numbers disagree now: no orderly teardown of the IPC state
 
 
