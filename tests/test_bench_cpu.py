@@ -91,3 +91,17 @@ def test_collective_report_runs_in_child_processes():
     assert p.returncode == 0, out
     r = json.loads(out.split("RESULT ", 1)[1].splitlines()[0])
     assert "timed out" in r["error"], r
+
+
+def test_allreduce_selection_from_the_collectives_report():
+    """bench.xgmi_verdict: a multi-GPU run takes the xGMI fused all-reduce only when the child processes validated it on
+    every message (no failure, no time-out) and measured it faster than RCCL + the add+norm launch on the verify message."""
+    import bench
+    ok = {"xgmi_fused_add_rmsnorm_auto": 11.0, "rccl_allreduce_then_add_rmsnorm": 31.0, "xgmi_timeouts": 0}
+    assert bench.xgmi_verdict({"verify": ok, "draft_step": dict(ok)})[0] is True
+    assert bench.xgmi_verdict({"verify": dict(ok, xgmi_fused_add_rmsnorm_auto=40.0)})[0] is False        # slower
+    assert bench.xgmi_verdict({"verify": dict(ok, xgmi_timeouts=1)})[0] is False                         # a spin timed out
+    assert bench.xgmi_verdict({"verify": ok, "draft_step": {"xgmi": "unavailable"}})[0] is False         # self-test failed
+    assert bench.xgmi_verdict({"error": "child timed out after 120 s"})[0] is False
+    assert bench.xgmi_verdict(dict({"verify": ok}, rank0_child="child exited with -11"))[0] is False    # a fault in the child
+    assert bench.xgmi_verdict(None)[0] is False and bench.xgmi_verdict({"autoregressive": ok})[0] is False
