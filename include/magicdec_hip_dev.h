@@ -22,6 +22,8 @@ void md_debug_set_prefill_mfma32(int kt);
 void md_debug_set_prefill_kt(int kt, int nw);
 /* md_linear: split-K policy (workgroups to aim for) */
 void md_debug_set_gemm_target_blocks(int n);
+/* md_linear: wavefronts per workgroup, 4 | 6 | 7 forced (bit-identical results); 0 = the balance rule (plan_of) */
+void md_debug_set_gemm_waves(int nw);
 /* md_linear_fused: wavefronts (K slices) per workgroup, 8 | 16; 11 / 22 = 1 x 1 / 2 x 2 MFMA tiles per workgroup with 8 K
  * slices (bit-identical results); 0 = the measured rules */
 void md_debug_set_fused_nw(int nw);

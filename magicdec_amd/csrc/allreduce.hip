@@ -24,8 +24,8 @@
 // (Engine/SnapKV/model.py:464-469) -- saving one kernel launch and one round trip of h per all-reduce.
 //
 // Protocol, per call k = 1, 2, ... (k lives in device memory so that a captured hipGraph replays correctly; every
-// block of a call reads the same k because only the LAST block to finish advances it) and per block b of a grid
-// that is sized to the message:
+// block of a call reads the same k because the counter is advanced only once ALL blocks of the call have read it:
+// round 5, see "call counter" below) and per block b of a grid that is sized to the message:
 //   1. copy the rows of block b from `in` into my data buffer half (k & 1);
 //   2. release; store k into start[b][me] of every peer; spin until start[b][p] >= k for every p; acquire;
 //   3. one-shot: sum the rows of block b over all ranks -> out.           two-shot: sum MY rows of block b -> my
@@ -54,14 +54,22 @@ constexpr unsigned long long kSpinTimeoutTicks = 200ull * 1000 * 1000;   // wall
 struct Signal {
     uint32_t start[kMaxBlocks][kMaxRanks];    // written by peers (system-scope release), read by the owner
     uint32_t start2[kMaxBlocks][kMaxRanks];   // second hop of the two-shot form
-    uint32_t call;                            // owner only: number of completed calls
-    uint32_t done;                            // owner only: blocks of the running call that have finished
     uint32_t status;                          // owner only: 0 ok, 1 = a spin timed out (output poisoned)
 };
 
+// Call counter (round 5).  Owner-only state in ORDINARY (cached) device memory: ctrl[0] = number of calls whose counter
+// has been handed on, ctrl[1] = blocks of the running call that have read it.  Rounds 2-4 kept both in the uncached signal
+// area and let the LAST block to FINISH advance the counter: an uncached read at the head of every launch (everything
+// else waits for k) and a returning atomic on uncached memory at its tail -- ~3 us of a 9 us launch with one rank
+// (tools/ar_bench.py).  All the protocol needs is that no block of call k reads the counter after it was advanced, so the
+// last block to have READ it advances it: thread 0 reads ctrl[0] (its value returns before the block's first barrier),
+// after the barrier lane 0 of wave 1 adds 1 to ctrl[1] -- the result is consumed only at the end of the kernel, so its
+// round trip hides under the row work -- and the block that drew G - 1 resets ctrl[1] and stores k.  The next launch on the
+// stream reads it behind a kernel boundary.  (tests/test_allreduce_protocol_model.py models exactly this.)
 struct ArDev {
     bf16_t* data[kMaxRanks];   // peer buffers: [data half 0][data half 1][result half 0][result half 1]
     Signal* sig[kMaxRanks];
+    uint32_t* ctrl;            // owner only, cached: [0] call counter, [1] blocks of the running call that have read it
     int rank, world;
     size_t buf_elems;          // elements per half buffer
 };
@@ -114,11 +122,15 @@ __device__ __forceinline__ u32x4 pack8(const float (&f)[8]) {
     return *reinterpret_cast<u32x4*>(&o);
 }
 
+constexpr int kPF = 8;    // vectors per lane a wave may hold ahead of the hand-shake: rows of <= 64 * 8 * 8 = 4096 bf16
+
 // A wavefront finishes one row whose reduced value it holds as vectors s[0..nv) (lane-strided: vector lane + 64*i).
 // Plain: store.  Fused: h = bf16(x + s) -> out, y = rmsnorm(h) * w -> out_y.  poisoned: NaN everywhere.
-template <bool FUSED>
+// PF (rows of <= 4096 elements): the RMSNorm weights are already in registers (`wpf`, loaded once per wave BEFORE the
+// hand-shake), and for the wave's first row so is the residual row (`xpf`, when x_ready).
+template <bool FUSED, bool PF>
 __device__ __forceinline__ void finish_row(const ArArgs& a, int row, int lane, int nvec_row, u32x4 (&s)[kMaxVecPerLane],
-                                           bool poisoned) {
+                                           bool poisoned, const u32x4 (&wpf)[kPF], const u32x4 (&xpf)[kPF], bool x_ready) {
     const size_t base = (size_t)row * a.row_vecs;
     u32x4* o = reinterpret_cast<u32x4*>(a.out) + base;
     if (poisoned) {
@@ -129,19 +141,29 @@ __device__ __forceinline__ void finish_row(const ArArgs& a, int row, int lane, i
         }
         return;
     }
+    constexpr int NV = PF ? kPF : kMaxVecPerLane;
     if constexpr (!FUSED) {
 #pragma unroll
-        for (int i = 0; i < kMaxVecPerLane; ++i)
+        for (int i = 0; i < NV; ++i)
             if (lane + 64 * i < nvec_row) o[lane + 64 * i] = s[i];
     } else {
         const u32x4* x = reinterpret_cast<const u32x4*>(a.resid) + base;
+        u32x4 xv[NV];
+        if (PF && x_ready) {                                       // wave-uniform
+#pragma unroll
+            for (int i = 0; i < NV; ++i) xv[i] = xpf[i < kPF ? i : 0];
+        } else {
+#pragma unroll
+            for (int i = 0; i < NV; ++i)
+                if (lane + 64 * i < nvec_row) xv[i] = x[lane + 64 * i];
+        }
         float ss = 0.f;
 #pragma unroll
-        for (int i = 0; i < kMaxVecPerLane; ++i) {
+        for (int i = 0; i < NV; ++i) {
             if (lane + 64 * i < nvec_row) {
                 float fs[8], fx[8], fh[8];
                 unpack8(s[i], fs);
-                unpack8(x[lane + 64 * i], fx);
+                unpack8(xv[i], fx);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) fh[e] = bf16_to_f32(f32_to_bf16(fx[e] + fs[e]));   // h = x + y in bf16
                 s[i] = pack8(fh);
@@ -155,11 +177,11 @@ __device__ __forceinline__ void finish_row(const ArArgs& a, int row, int lane, i
         const u32x4* w = reinterpret_cast<const u32x4*>(a.weight);
         u32x4* y = reinterpret_cast<u32x4*>(a.out_y) + base;
 #pragma unroll
-        for (int i = 0; i < kMaxVecPerLane; ++i) {
+        for (int i = 0; i < NV; ++i) {
             if (lane + 64 * i < nvec_row) {
                 float fh[8], fw[8], fy[8];
                 unpack8(s[i], fh);
-                unpack8(w[lane + 64 * i], fw);
+                unpack8(PF ? wpf[i < kPF ? i : 0] : w[lane + 64 * i], fw);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) fy[e] = bf16_to_f32(f32_to_bf16(fh[e] * rstd)) * fw[e];   // (x*rstd).type_as(x) * w
                 y[lane + 64 * i] = pack8(fy);
@@ -168,19 +190,22 @@ __device__ __forceinline__ void finish_row(const ArArgs& a, int row, int lane, i
     }
 }
 
-template <int NR, bool TWOSHOT, bool FUSED>
+// PF: rows of <= 4096 elements (every plain call: 512 vectors per row; the fused rows of the 1B / 8B / 32B models).
+// Everything a wave needs for its FIRST row that does not come from a peer -- its own partial, the residual row, the norm
+// weights -- is requested BEFORE the block waits for the call counter and for the peers' flags, so those round trips
+// overlap instead of queueing behind each other (round 5: 9.3 -> see tools/ar_bench.py).
+template <int NR, bool TWOSHOT, bool FUSED, bool PF>
 __global__ __launch_bounds__(kThreads) void allreduce_kernel(const ArDev c, const ArArgs a) {
     const int b = blockIdx.x, G = gridDim.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     __shared__ uint32_t s_k;
     __shared__ int s_bad;
     Signal* self = c.sig[c.rank];
     if (tid == 0) {
-        s_k = self->call + 1;
+        // a plain load: nobody writes the counter while a block of this call may still read it (that is the protocol),
+        // and the previous call's store is behind a kernel boundary
+        s_k = *reinterpret_cast<const volatile uint32_t*>(&c.ctrl[0]) + 1;
         s_bad = 0;
     }
-    __syncthreads();
-    const uint32_t k = s_k;
-    const size_t half = (k & 1u) ? c.buf_elems : 0;
 
     // rows of this block: row -> owner = row % NR, idx = row / NR, block = idx % G
     auto row_vecs_of = [&](int row) -> int {
@@ -188,6 +213,38 @@ __global__ __launch_bounds__(kThreads) void allreduce_kernel(const ArDev c, cons
         const size_t left = a.n_vec - v0;
         return left < (size_t)a.row_vecs ? (int)left : a.row_vecs;
     };
+
+    // the wave's first row (one-shot: rows of the block dealt to the 8 waves; two-shot: the rows this rank owns)
+    int row0;
+    bool have0;
+    if constexpr (!TWOSHOT) {
+        const int idx0 = b + (wave / NR) * G;
+        row0 = idx0 * NR + wave % NR;
+        have0 = idx0 * NR < a.rows && row0 < a.rows;
+    } else {
+        row0 = (b + wave * G) * NR + c.rank;
+        have0 = row0 < a.rows;
+    }
+    u32x4 own0[kPF], x0[kPF], wpf[kPF];
+    if constexpr (PF) {
+        const int nv0 = have0 ? row_vecs_of(row0) : 0;
+        const size_t base0 = (size_t)row0 * a.row_vecs;
+#pragma unroll
+        for (int i = 0; i < kPF; ++i) {
+            if (lane + 64 * i < nv0) {
+                own0[i] = reinterpret_cast<const u32x4*>(a.in)[base0 + lane + 64 * i];
+                if constexpr (FUSED) x0[i] = reinterpret_cast<const u32x4*>(a.resid)[base0 + lane + 64 * i];
+            }
+            if constexpr (FUSED)
+                if (lane + 64 * i < a.row_vecs) wpf[i] = reinterpret_cast<const u32x4*>(a.weight)[lane + 64 * i];
+        }
+    }
+    __syncthreads();
+    const uint32_t k = s_k;
+    const size_t half = (k & 1u) ? c.buf_elems : 0;
+    // this block has read the counter: count it (the result is used at the very end of the kernel)
+    uint32_t drawn = 0;
+    if (tid == 64) drawn = __hip_atomic_fetch_add(&c.ctrl[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 
     // 1. publish: copy every row of block b into my data buffer, write-through (a lone rank has nobody to publish to)
     if constexpr (NR > 1) {
@@ -219,11 +276,13 @@ __global__ __launch_bounds__(kThreads) void allreduce_kernel(const ArDev c, cons
     for (int r = 0; r < NR; ++r) peer[r] = reinterpret_cast<const u32x4*>(c.data[r] + half);
     peer[c.rank] = reinterpret_cast<const u32x4*>(a.in);
 
-    // sum of one row over the ranks, in rank order, fp32 accumulate, one rounding
-    auto reduce_row = [&](int row, int nv, u32x4 (&s)[kMaxVecPerLane]) {
+    constexpr int NV = PF ? kPF : kMaxVecPerLane;
+    // sum of one row over the ranks, in rank order, fp32 accumulate, one rounding (own_ready: this rank's vectors of the
+    // row are already in own0)
+    auto reduce_row = [&](int row, int nv, u32x4 (&s)[kMaxVecPerLane], bool own_ready) {
         const size_t base = (size_t)row * a.row_vecs;
 #pragma unroll
-        for (int i = 0; i < kMaxVecPerLane; ++i) {
+        for (int i = 0; i < NV; ++i) {
             if (lane + 64 * i < nv) {
                 float acc[8];
 #pragma unroll
@@ -231,8 +290,12 @@ __global__ __launch_bounds__(kThreads) void allreduce_kernel(const ArDev c, cons
 #pragma unroll
                 for (int r = 0; r < NR; ++r) {
                     float f[8];
-                    unpack8(r == c.rank ? peer[r][base + lane + 64 * i]
-                                        : __builtin_nontemporal_load(peer[r] + base + lane + 64 * i), f);
+                    u32x4 v;
+                    if (r == c.rank)
+                        v = (PF && own_ready) ? own0[i < kPF ? i : 0] : peer[r][base + lane + 64 * i];
+                    else
+                        v = __builtin_nontemporal_load(peer[r] + base + lane + 64 * i);
+                    unpack8(v, f);
 #pragma unroll
                     for (int e = 0; e < 8; ++e) acc[e] += f[e];
                 }
@@ -248,9 +311,10 @@ __global__ __launch_bounds__(kThreads) void allreduce_kernel(const ArDev c, cons
             if (idx * NR >= a.rows) break;
             if (row >= a.rows) continue;
             const int nv = row_vecs_of(row);
+            const bool first = t == wave;
             u32x4 s[kMaxVecPerLane];
-            if (!bad) reduce_row(row, nv, s);
-            finish_row<FUSED>(a, row, lane, nv, s, bad);
+            if (!bad) reduce_row(row, nv, s, first);
+            finish_row<FUSED, PF>(a, row, lane, nv, s, bad, wpf, x0, first);
         }
     } else {
         // 3a. reduce-scatter: my rows of block b -> my result buffer (+ finished locally)
@@ -258,23 +322,24 @@ __global__ __launch_bounds__(kThreads) void allreduce_kernel(const ArDev c, cons
         for (int idx = b + wave * G; idx * NR + c.rank < a.rows; idx += G * (kThreads / 64)) {
             const int row = idx * NR + c.rank;
             const int nv = row_vecs_of(row);
+            const bool first = idx == b + wave * G;
             u32x4 s[kMaxVecPerLane];
             if (!bad) {
-                reduce_row(row, nv, s);
+                reduce_row(row, nv, s, first);
             } else {
                 // a peer's partial never arrived: the rows this rank owns are NaN for EVERYONE -- the peers gather
                 // them from `myres` in step 3c, and must not find the rows of two calls ago there
                 const u32x4 nan = {0x7fc07fc0u, 0x7fc07fc0u, 0x7fc07fc0u, 0x7fc07fc0u};
 #pragma unroll
-                for (int i = 0; i < kMaxVecPerLane; ++i) s[i] = nan;
+                for (int i = 0; i < NV; ++i) s[i] = nan;
             }
             {
                 const size_t base = (size_t)row * a.row_vecs;
 #pragma unroll
-                for (int i = 0; i < kMaxVecPerLane; ++i)
+                for (int i = 0; i < NV; ++i)
                     if (lane + 64 * i < nv) store_wt(myres, base + lane + 64 * i, s[i]);
             }
-            finish_row<FUSED>(a, row, lane, nv, s, bad);
+            finish_row<FUSED, PF>(a, row, lane, nv, s, bad, wpf, x0, first);
         }
         drain_stores();
         __syncthreads();
@@ -297,25 +362,20 @@ __global__ __launch_bounds__(kThreads) void allreduce_kernel(const ArDev c, cons
             u32x4 s[kMaxVecPerLane];
             if (!bad) {
 #pragma unroll
-                for (int i = 0; i < kMaxVecPerLane; ++i)
+                for (int i = 0; i < NV; ++i)
                     if (lane + 64 * i < nv) s[i] = __builtin_nontemporal_load(src + lane + 64 * i);
             }
-            finish_row<FUSED>(a, row, lane, nv, s, bad);
+            finish_row<FUSED, PF>(a, row, lane, nv, s, bad, wpf, x0, false);
         }
     }
 
-    // the last block to finish advances the call counter (every block of the NEXT call then reads the same k)
-    __syncthreads();
-    if (tid == 0) {
-        // no fence: `done` is an atomic in uncached memory, and `call` / `status` are read by the NEXT launch on this
-        // stream (or by the host after it), i.e. behind a kernel boundary
-        if (bad || s_bad) self->status = 1;
-        const uint32_t d = __hip_atomic_fetch_add(&self->done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (d == (uint32_t)G - 1) {
-            __hip_atomic_store(&self->done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(&self->call, k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
+    // the block that drew the last ticket hands the call counter on (every block of this call has read it; the next
+    // launch on the stream reads it behind a kernel boundary); `status` is read by the host behind one, too
+    if (tid == 64 && drawn == (uint32_t)G - 1) {
+        __hip_atomic_store(&c.ctrl[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&c.ctrl[0], k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    if (tid == 0 && (bad || s_bad)) self->status = 1;
 }
 
 }  // namespace
@@ -324,6 +384,7 @@ struct md_ar_comm {
     ArDev dev;
     void* my_data;
     void* my_sig;
+    void* my_ctrl;
     void* opened[2 * kMaxRanks];
     int n_opened;
     size_t max_bytes;
@@ -337,17 +398,19 @@ extern "C" int md_ar_create(int rank, int world, size_t max_bytes, md_ar_comm** 
     c->n_opened = 0;
     c->max_bytes = max_bytes;
     // one registered allocation: data halves 0/1 (published partials), result halves 0/1 (two-shot reduced rows)
-    if (hipMalloc(&c->my_data, 4 * max_bytes) != hipSuccess ||
+    c->my_data = c->my_sig = c->my_ctrl = nullptr;
+    if (hipMalloc(&c->my_data, 4 * max_bytes) != hipSuccess || hipMalloc(&c->my_ctrl, 256) != hipSuccess ||
         hipExtMallocWithFlags(&c->my_sig, sizeof(Signal), hipDeviceMallocUncached) != hipSuccess) {
         md_set_error("md_ar_create: device allocation failed: %s", hipGetErrorString(hipGetLastError()));
         delete c;
         return MD_ERR_WORKSPACE;
     }
     if (hipMemset(c->my_sig, 0, sizeof(Signal)) != hipSuccess || hipMemset(c->my_data, 0, 4 * max_bytes) != hipSuccess ||
-        hipDeviceSynchronize() != hipSuccess) {
+        hipMemset(c->my_ctrl, 0, 256) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
         md_set_error("md_ar_create: clearing the buffers failed: %s", hipGetErrorString(hipGetLastError()));
         (void)hipFree(c->my_data);
         (void)hipFree(c->my_sig);
+        (void)hipFree(c->my_ctrl);
         delete c;
         return MD_ERR_WORKSPACE;
     }
@@ -360,6 +423,7 @@ extern "C" int md_ar_create(int rank, int world, size_t max_bytes, md_ar_comm** 
     c->dev.buf_elems = max_bytes / 2;
     c->dev.data[rank] = (bf16_t*)c->my_data;
     c->dev.sig[rank] = (Signal*)c->my_sig;
+    c->dev.ctrl = (uint32_t*)c->my_ctrl;
     *comm_out = c;
     return MD_OK;
 }
@@ -400,9 +464,13 @@ namespace {
 
 template <bool TWOSHOT, bool FUSED>
 void launch_world(const md_ar_comm* c, const ArArgs& a, int grid, hipStream_t st) {
+    const bool pf = a.row_vecs <= 64 * kPF;
 #define MD_AR_LAUNCH(N)                                                                                         \
     case N:                                                                                                     \
-        hipLaunchKernelGGL((allreduce_kernel<N, TWOSHOT, FUSED>), dim3(grid), dim3(kThreads), 0, st, c->dev, a); \
+        if (pf)                                                                                                 \
+            hipLaunchKernelGGL((allreduce_kernel<N, TWOSHOT, FUSED, true>), dim3(grid), dim3(kThreads), 0, st, c->dev, a); \
+        else                                                                                                    \
+            hipLaunchKernelGGL((allreduce_kernel<N, TWOSHOT, FUSED, false>), dim3(grid), dim3(kThreads), 0, st, c->dev, a); \
         break;
     switch (c->dev.world) {
         MD_AR_LAUNCH(1)
@@ -517,6 +585,7 @@ extern "C" int md_ar_destroy(md_ar_comm* c) {
     for (int i = 0; i < c->n_opened; ++i) (void)hipIpcCloseMemHandle(c->opened[i]);
     (void)hipFree(c->my_data);
     (void)hipFree(c->my_sig);
+    (void)hipFree(c->my_ctrl);
     delete c;
     return MD_OK;
 }

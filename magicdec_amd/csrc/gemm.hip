@@ -94,15 +94,21 @@ __device__ __forceinline__ float silu_bf16(float h1) {
     return bf16_to_f32(f32_to_bf16(h1 / (1.0f + expf(-h1))));
 }
 
-// One workgroup: 4 wavefronts x 32 GEMM columns, rows [0, M), k in [blockIdx.y*kblk, +kblk).
+// One workgroup: NW wavefronts x 32 GEMM columns, rows [0, M), k in [blockIdx.y*kblk, +kblk).
+// NW (round 5): 4 by default; 6 or 7 where that makes the grid a whole number of workgroups per CU.  A CU ingests ~24 GB/s
+// of HBM whatever is resident on it (profiles/r04_ingest_probe.txt), so a launch ends when the most loaded CU does: the
+// 8B w1|w3 (896 wave tiles, two K slices) ran as 448 four-wave workgroups = 192 CUs with two and 64 with one (1 048 KB
+// against a mean of 918 KB); as 256 seven-wave workgroups every CU streams 917 KB.  Bits do not change: a wave's tile,
+// K range and slab order are the same, only its neighbours in the workgroup differ.
 // PRO (round 4): the deferred RMSNorm of md_linear_fused on this kernel's activation path -- x is the un-normalised h
 // the residual epilogue of the producing linear wrote together with per-row partial sums of squares; the workgroup forms
 // rstd per row (the tile kernel's sum, term for term) and normalises every slab on its way from registers to LDS:
 // y = bf16(bf16(h * rstd) * w).  A slab is normalised once per workgroup and shared by its 128 columns, so the cost is a
 // few dozen vector instructions per slab -- against a 5 us md_rmsnorm launch in front of every w1|w3 of a draft pass.
-template <int MT, int EPI, bool W8, int RD, bool PRO>
-__global__ __launch_bounds__(256) void skinny_gemm_kernel(const GemmParams p) {
+template <int MT, int EPI, bool W8, int RD, bool PRO, int NW>
+__global__ __launch_bounds__(64 * NW) void skinny_gemm_kernel(const GemmParams p) {
     constexpr int MP = MT * 32;
+    constexpr int NT = 64 * NW;                      // threads
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];   // 2 x [MP][kPitch] (+ MP floats rstd when PRO)
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 31, kh = lane >> 5;
     const int k_beg = blockIdx.y * p.kblk;
@@ -113,26 +119,28 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(const GemmParams p) {
     int out_col = -1;   // output column this lane is responsible for (epilogue), -1: none
     if constexpr (EPI == EPI_SWIGLU) {
         const int I = p.N >> 1;
-        const int i = (blockIdx.x * 4 + wave) * 16 + (j & 15);
+        const int i = (blockIdx.x * NW + wave) * 16 + (j & 15);
         col = (j < 16 ? 0 : I) + (i < I ? i : I - 1);
         if (j < 16 && i < I) out_col = i;
     } else {
-        const int n = (blockIdx.x * 4 + wave) * 32 + j;
+        const int n = (blockIdx.x * NW + wave) * 32 + j;
         col = n < p.N ? n : p.N - 1;
         if (n < p.N) out_col = n;
     }
     // element offset of this lane's first fragment and the distance between consecutive k-steps.
     // row-major: 32 rows x 32 B per wave instruction.  packed: tile-major [n_tile][k_step][lane][8]: one fully
     // contiguous KiB per wave instruction and one sequential stream per wavefront (the layout HBM likes best).
-    // (a workgroup covers 4 tiles; the last workgroup may reach past the last tile: re-read that one, like `col`)
+    // (a workgroup covers NW tiles; the last workgroup may reach past the last tile: re-read that one, like `col`)
     const int ntiles = (EPI == EPI_SWIGLU) ? ((p.N >> 1) + 15) / 16 : (p.N + 31) / 32;
-    const int tile = min(blockIdx.x * 4 + wave, ntiles - 1);
+    const int tile = min(blockIdx.x * NW + wave, ntiles - 1);
     const int64_t w_off = p.packed ? ((int64_t)tile * (p.K >> 4) + (k_beg >> 4)) * 512 + lane * 8
                                    : (int64_t)col * p.K + k_beg + kh * 8;
     const int64_t w_step = p.packed ? 512 : 16;
 
-    // ---- activation slab staging: MP rows x 16 chunks of 16 B; thread t takes chunks t, t+256, ...
-    constexpr int XCH = MP * 16 / 256;   // chunks per thread (MT * 2)
+    // ---- activation slab staging: MP rows x 16 chunks of 16 B; thread t takes chunks t, t+NT, ... (NT = 256: exactly
+    // MT * 2 each; other NT: the last round is partial)
+    constexpr int XCH = (MP * 16 + NT - 1) / NT;   // chunks per thread
+    constexpr bool XFULL = (MP * 16) % NT == 0;
     u32x4 xs[XCH];
     u32x4 nwv = {0u, 0u, 0u, 0u};        // PRO: the norm weights of this thread's 8 columns of the slab (c16 = tid & 15)
     const float* rstd_lds = reinterpret_cast<const float*>(lds + 2 * MP * kPitch);
@@ -141,10 +149,10 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(const GemmParams p) {
             nwv = *reinterpret_cast<const u32x4*>(p.pro_w + k_beg + slab * kSlabK + (tid & 15) * 8);
 #pragma unroll
         for (int q = 0; q < XCH; ++q) {
-            const int c = tid + 256 * q;
+            const int c = tid + NT * q;
             const int row = c >> 4, c16 = c & 15;
-            // rows >= M re-read row M-1 (branch-free: a branch per load would serialise the staging, and the results
-            // of those rows are never stored)
+            // rows >= M (and, when NT does not divide the slab, chunks past it) re-read row M-1 (branch-free: a branch per
+            // load would serialise the staging, and those values are never stored)
             const int rr = row < p.M ? row : p.M - 1;
             xs[q] = *reinterpret_cast<const u32x4*>(p.x + (int64_t)rr * p.ldx + k_beg + slab * kSlabK + c16 * 8);
         }
@@ -155,7 +163,7 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(const GemmParams p) {
     auto x_norm = [&]() {
 #pragma unroll
         for (int q = 0; q < XCH; ++q) {
-            const int row = (tid + 256 * q) >> 4;
+            const int row = XFULL ? (tid + NT * q) >> 4 : min((tid + NT * q) >> 4, MP - 1);
             const float rs = rstd_lds[row];
             u32x4 v = xs[q];
 #pragma unroll
@@ -173,9 +181,10 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(const GemmParams p) {
     auto x_store = [&](int buf) {
 #pragma unroll
         for (int q = 0; q < XCH; ++q) {
-            const int c = tid + 256 * q;
+            const int c = tid + NT * q;
             const int row = c >> 4, c16 = c & 15;
-            *reinterpret_cast<u32x4*>(lds + buf * (MP * kPitch) + row * kPitch + c16 * 16) = xs[q];
+            if (XFULL || c < MP * 16)
+                *reinterpret_cast<u32x4*>(lds + buf * (MP * kPitch) + row * kPitch + c16 * 16) = xs[q];
         }
     };
 
@@ -198,6 +207,7 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(const GemmParams p) {
         constexpr int RPT = MP / 16;                               // rows per thread
         const int part = tid & 15;
         float t[RPT];
+        if (tid < 256) {                                           // (wave-uniform) the first four waves, as with NW = 4
         if constexpr (MT <= 2) {
             // <= 64 rows (where the policy uses this form): the partial sums of ALL rows of a thread are requested
             // before the first one is needed -- one L2 round trip per 128 tiles instead of one per 16 rows (a serial
@@ -238,6 +248,7 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(const GemmParams p) {
             a += __shfl_xor(a, 4);
             a += __shfl_xor(a, 8);
             if (part == 0) rw[it * 16 + (tid >> 4)] = rsqrtf(__fadd_rn(__fdiv_rn(a, (float)p.K), p.pro_eps));
+        }
         }
         __syncthreads();
         x_norm();
@@ -298,7 +309,7 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(const GemmParams p) {
     if (p.S > 1) {
         float* pp = p.partial + (int64_t)blockIdx.y * p.M * p.N;
         const int n = (EPI == EPI_SWIGLU) ? col : out_col;
-        const bool ok = (EPI == EPI_SWIGLU) ? ((blockIdx.x * 4 + wave) * 16 + (j & 15) < (p.N >> 1)) : (out_col >= 0);
+        const bool ok = (EPI == EPI_SWIGLU) ? ((blockIdx.x * NW + wave) * 16 + (j & 15) < (p.N >> 1)) : (out_col >= 0);
         if (ok) {
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
@@ -385,6 +396,7 @@ __global__ __launch_bounds__(256) void skinny_reduce_kernel(const GemmParams p) 
 }
 
 int g_target_blocks = 256;   // split-K is chosen so that about this many workgroups exist (1 per CU: measured best)
+int g_force_nw = 0;          // dev knob (md_debug_set_gemm_waves): 0 = the rule below, 4 / 6 / 7 = forced
 
 int pick_splits(int n_blocks, int K) {
     const int nslab = K / kSlabK;
@@ -397,6 +409,34 @@ int pick_splits(int n_blocks, int K) {
     return best;
 }
 
+// (waves per workgroup, K slices) of a product with `ntiles` wave tiles (32 GEMM columns each; SwiGLU: 16 + 16).
+// Four waves and the split of pick_splits unless that leaves the most loaded CU with > 8 % more bytes than the mean AND
+// six or seven waves per workgroup with the SAME split (same partial planes, same bits) bring it within 2 %.
+struct SkinnyPlan { int nw, S; };
+SkinnyPlan plan_of(int ntiles, int K, bool allow_nw) {
+    SkinnyPlan pl;
+    pl.nw = 4;
+    pl.S = pick_splits((ntiles + 3) / 4, K);
+    if (g_force_nw == 4 || !allow_nw) return pl;
+    constexpr int kCUs = 256;
+    auto load = [&](int nw) {                       // bytes of the most loaded CU over the mean (round-robin placement)
+        const long wgs = (long)((ntiles + nw - 1) / nw) * pl.S;
+        const long per_cu = (wgs + kCUs - 1) / kCUs;
+        return (double)per_cu * nw * kCUs / ((double)ntiles * pl.S);
+    };
+    if (g_force_nw == 6 || g_force_nw == 7) {
+        pl.nw = g_force_nw;
+        return pl;
+    }
+    if (load(4) <= 1.08) return pl;
+    for (int nw : {7, 6})
+        if (load(nw) <= 1.02) {
+            pl.nw = nw;
+            break;
+        }
+    return pl;
+}
+
 }  // namespace
 
 // elementwise.hip: split-K combine + residual add + RMSNorm (compiled there, without FMA contraction, next to the
@@ -407,13 +447,13 @@ int md_internal_launch_reduce_add_rmsnorm(const float* partial, int S, int M, in
 
 namespace {
 
-template <int MT, int EPI, bool W8, bool PRO = false>
+template <int MT, int EPI, bool W8, bool PRO, int NW>
 int launch(const GemmParams& p, int n_blocks, hipStream_t st) {
     constexpr int RD = 8;
     const size_t lds = (size_t)2 * MT * 32 * kPitch + (PRO ? MT * 32 * 4 : 0);
-    auto k = skinny_gemm_kernel<MT, EPI, W8, RD, PRO>;
+    auto k = skinny_gemm_kernel<MT, EPI, W8, RD, PRO, NW>;
     if (lds > 64 * 1024) {
-        static MdPerDeviceOnce once;   // per (MT, EPI, W8, PRO) instantiation and per device
+        static MdPerDeviceOnce once;   // per (MT, EPI, W8, PRO, NW) instantiation and per device
         if (once.first()) {
             if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)lds) != hipSuccess) {
@@ -422,7 +462,7 @@ int launch(const GemmParams& p, int n_blocks, hipStream_t st) {
             }
         }
     }
-    hipLaunchKernelGGL(k, dim3(n_blocks, p.S), dim3(256), lds, st, p);
+    hipLaunchKernelGGL(k, dim3(n_blocks, p.S), dim3(64 * NW), lds, st, p);
     if (p.S > 1 && !p.skip_reduce) {
         const int64_t threads = (int64_t)p.M * (p.Nout / 4);
         hipLaunchKernelGGL((skinny_reduce_kernel<EPI, W8>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, p);
@@ -430,13 +470,26 @@ int launch(const GemmParams& p, int n_blocks, hipStream_t st) {
     return MD_OK;
 }
 
-template <int EPI, bool W8, bool PRO = false>
-int launch_mt(const GemmParams& p, int n_blocks, hipStream_t st) {
-    if (p.M <= 32) return launch<1, EPI, W8, PRO>(p, n_blocks, st);
-    if (p.M <= 64) return launch<2, EPI, W8, PRO>(p, n_blocks, st);
-    if (p.M <= 128) return launch<4, EPI, W8, PRO>(p, n_blocks, st);
-    return launch<8, EPI, W8, PRO>(p, n_blocks, st);
+// the 6- / 7-wave forms exist for bf16 weights at M <= 128 (nw_allowed below); everything else runs four waves
+template <int MT, int EPI, bool W8, bool PRO>
+int launch_nw(const GemmParams& p, int nw, int n_blocks, hipStream_t st) {
+    if constexpr (!W8 && MT <= 4) {
+        if (nw == 7) return launch<MT, EPI, W8, PRO, 7>(p, n_blocks, st);
+        if (nw == 6) return launch<MT, EPI, W8, PRO, 6>(p, n_blocks, st);
+    }
+    return launch<MT, EPI, W8, PRO, 4>(p, n_blocks, st);
 }
+
+template <int EPI, bool W8, bool PRO = false>
+int launch_mt(const GemmParams& p, int nw, int n_blocks, hipStream_t st) {
+    if (p.M <= 32) return launch_nw<1, EPI, W8, PRO>(p, nw, n_blocks, st);
+    if (p.M <= 64) return launch_nw<2, EPI, W8, PRO>(p, nw, n_blocks, st);
+    if (p.M <= 128) return launch_nw<4, EPI, W8, PRO>(p, nw, n_blocks, st);
+    return launch_nw<8, EPI, W8, PRO>(p, nw, n_blocks, st);
+}
+
+bool nw_allowed(int M, bool w8) { return !w8 && M <= 128; }
+int wave_tiles(int N, int epilogue) { return epilogue == EPI_SWIGLU ? ((N >> 1) + 15) / 16 : (N + 31) / 32; }
 
 }  // namespace
 
@@ -463,13 +516,12 @@ int md_internal_launch_skinny_reduce(const float* partial, int S, int M, int N, 
 
 #ifdef MD_DEV_KNOBS
 extern "C" void md_debug_set_gemm_target_blocks(int n) { g_target_blocks = n > 0 ? n : 256; }
+extern "C" void md_debug_set_gemm_waves(int nw) { g_force_nw = (nw == 4 || nw == 6 || nw == 7) ? nw : 0; }
 #endif
 
 extern "C" size_t md_linear_workspace_bytes(int M, int N, int K, int epilogue) {
     if (M <= 0 || N <= 0 || K <= 0 || K % kSlabK) return 0;
-    const int nout = epilogue == EPI_SWIGLU ? N / 2 : N;
-    const int cols_per_block = epilogue == EPI_SWIGLU ? 64 : 128;
-    const int S = pick_splits((nout + cols_per_block - 1) / cols_per_block, K);
+    const int S = plan_of(wave_tiles(N, epilogue), K, false).S;     // the split does not depend on the waves per workgroup
     return S > 1 ? (size_t)S * M * N * 4 : 0;     // fp32 partial sums of the K slices
 }
 
@@ -519,9 +571,11 @@ int linear_impl(const void* x, int64_t ldx, const void* w, int w_dtype, int w_pa
         p.pro_eps = pro_eps;
         p.pro_tiles = pro_tiles;
     }
-    const int cols_per_block = epilogue == EPI_SWIGLU ? 64 : 128;      // output columns per workgroup
-    const int n_blocks = (p.Nout + cols_per_block - 1) / cols_per_block;
-    p.S = pick_splits(n_blocks, K);
+    const bool w8 = w_dtype == MD_W_INT8;
+    const int ntiles = wave_tiles(N, epilogue);
+    const SkinnyPlan pl = plan_of(ntiles, K, nw_allowed(M, w8));
+    const int n_blocks = (ntiles + pl.nw - 1) / pl.nw;
+    p.S = pl.S;
     p.kblk = K / p.S;
     p.partial = (float*)workspace;
     if (p.S > 1) {
@@ -530,14 +584,13 @@ int linear_impl(const void* x, int64_t ldx, const void* w, int w_dtype, int w_pa
     }
     hipStream_t st = (hipStream_t)stream;
     int rc;
-    const bool w8 = w_dtype == MD_W_INT8;
     if (pro)
-        rc = epilogue == EPI_SWIGLU ? launch_mt<EPI_SWIGLU, false, true>(p, n_blocks, st)
-                                    : launch_mt<EPI_NONE, false, true>(p, n_blocks, st);
+        rc = epilogue == EPI_SWIGLU ? launch_mt<EPI_SWIGLU, false, true>(p, pl.nw, n_blocks, st)
+                                    : launch_mt<EPI_NONE, false, true>(p, pl.nw, n_blocks, st);
     else if (epilogue == EPI_SWIGLU)
-        rc = w8 ? launch_mt<EPI_SWIGLU, true>(p, n_blocks, st) : launch_mt<EPI_SWIGLU, false>(p, n_blocks, st);
+        rc = w8 ? launch_mt<EPI_SWIGLU, true>(p, pl.nw, n_blocks, st) : launch_mt<EPI_SWIGLU, false>(p, pl.nw, n_blocks, st);
     else
-        rc = w8 ? launch_mt<EPI_NONE, true>(p, n_blocks, st) : launch_mt<EPI_NONE, false>(p, n_blocks, st);
+        rc = w8 ? launch_mt<EPI_NONE, true>(p, pl.nw, n_blocks, st) : launch_mt<EPI_NONE, false>(p, pl.nw, n_blocks, st);
     if (rc != MD_OK) return rc;
     MD_CHECK_LAUNCH("md_linear");
     return MD_OK;
@@ -561,7 +614,7 @@ extern "C" int md_linear_normed(const void* h, int64_t ldh, const float* ssq, in
 
 extern "C" int md_linear_add_rmsnorm_supported(int M, int N, int K) {
     if (!md_linear_supported(M, N, K, EPI_NONE) || N % 8 || N > 8192) return 0;
-    return pick_splits((N + 127) / 128, K) > 1 ? 1 : 0;      // needs the split-K combine launch to fuse into
+    return plan_of(wave_tiles(N, EPI_NONE), K, false).S > 1 ? 1 : 0;      // needs the split-K combine launch to fuse into
 }
 
 extern "C" int md_linear_add_rmsnorm(const void* x, int64_t ldx, const void* w, int w_dtype, int w_packed,
@@ -591,16 +644,18 @@ extern "C" int md_linear_add_rmsnorm(const void* x, int64_t ldx, const void* w, 
     p.Nout = N;
     p.packed = w_packed ? 1 : 0;
     p.skip_reduce = 1;
-    const int n_blocks = (N + 127) / 128;
-    p.S = pick_splits(n_blocks, K);
+    const bool w8 = w_dtype == MD_W_INT8;
+    const int ntiles = wave_tiles(N, EPI_NONE);
+    const SkinnyPlan pl = plan_of(ntiles, K, nw_allowed(M, w8));
+    const int n_blocks = (ntiles + pl.nw - 1) / pl.nw;
+    p.S = pl.S;
     p.kblk = K / p.S;
     p.partial = (float*)workspace;
     MD_CHECK_ARG(workspace && workspace_bytes >= (size_t)p.S * M * N * 4 && (((uintptr_t)workspace) & 15) == 0,
                  "md_linear_add_rmsnorm: workspace too small (need %zu bytes) or not 16-byte aligned",
                  (size_t)p.S * M * N * 4);
     hipStream_t st = (hipStream_t)stream;
-    const bool w8 = w_dtype == MD_W_INT8;
-    int rc = w8 ? launch_mt<EPI_NONE, true>(p, n_blocks, st) : launch_mt<EPI_NONE, false>(p, n_blocks, st);
+    int rc = w8 ? launch_mt<EPI_NONE, true>(p, pl.nw, n_blocks, st) : launch_mt<EPI_NONE, false>(p, pl.nw, n_blocks, st);
     if (rc != MD_OK) return rc;
     rc = md_internal_launch_reduce_add_rmsnorm(p.partial, p.S, M, N, bias, w8 ? scales : nullptr, resid, ldr,
                                                norm_weight, h_out, y_out, eps, st);

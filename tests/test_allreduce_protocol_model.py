@@ -4,8 +4,13 @@ The kernel's correctness argument (double-buffered data and result buffers, one 
 rank) and hop, a per-call sequence number, a grid sized to the message, no closing barrier, stream order between
 calls) is easy to get subtly wrong and cannot be exercised across real GPUs on the development box, so the protocol
 is restated here as interleaved state machines and run under thousands of random schedules.  Every rank r executes the
-same sequence of calls; call k (k = 1, 2, ..., the same for every block of the call: only the last block to finish
-advances the counter) launches G(k) = min(MAXB, ceil(rows / N)) blocks, and block b
+same sequence of calls; call k launches G(k) = min(MAXB, ceil(rows / N)) blocks, and block b
+
+    0. reads the rank's call counter (k = counter + 1), THEN draws a ticket from the rank's `started` count; the block
+       that draws ticket G - 1 -- every block of the call has read the counter by then -- resets `started` and stores k
+       into the counter at some LATER point of its run (round 5; rounds 2-4: the last block to FINISH advanced it).
+       Blocks of one launch start at different times, so a late block may read the counter long after an early one has
+       finished: it must still see the same k.  Checked as a second invariant.
 
     1. writes the rows of block b into data[r][k & 1]               (rows are dealt by (row / N) % G)
     2. stores k into start[p][b][r] of every peer p;  waits until start[r][b][p] >= k for every p
@@ -34,7 +39,9 @@ def simulate(n_ranks, calls, seed):
     res = [[[None] * cap, [None] * cap] for _ in range(N)]
     start = [[[0] * N for _ in range(MAXB)] for _ in range(N)]       # start[owner][b][src]
     start2 = [[[0] * N for _ in range(MAXB)] for _ in range(N)]
-    done_calls = [0] * N
+    counter = [0] * N            # ctrl[0]: the call counter blocks read
+    started = [0] * N            # ctrl[1]: blocks of the running call that have read it
+    launch_k = [1] * N           # the k every block of the rank's running launch must obtain
 
     def grid_of(rows):
         return max(1, min(MAXB, (rows + N - 1) // N))
@@ -43,12 +50,12 @@ def simulate(n_ranks, calls, seed):
         def __init__(self, r, ci, b, G):
             self.r, self.ci, self.b, self.G = r, ci, b, G
             self.rows_n, self.two = calls[ci]
-            self.k = done_calls[r] + 1
-            self.half = self.k & 1
+            self.k = None                                       # read in step -2 (blocks of a launch start at different times)
             self.rows = [i for i in range(self.rows_n) if (i // N) % G == b]
             self.mine = [i for i in self.rows if i % N == r]
             self.others = [i for i in self.rows if i % N != r]
-            self.pc, self.i, self.p = 0, 0, 0
+            self.pc, self.i, self.p = -2, 0, 0
+            self.hand_on = False                                # drew the last ticket: stores k into the counter when it ends
             self.done = False
 
         def runnable(self):
@@ -59,7 +66,23 @@ def simulate(n_ranks, calls, seed):
             return True
 
         def step(self):
-            r, b, k, h = self.r, self.b, self.k, self.half
+            r, b = self.r, self.b
+            if self.pc == -2:                                    # read the call counter
+                self.k = counter[r] + 1
+                self.half = self.k & 1
+                if self.k != launch_k[r]:
+                    return f"rank {r} block {b}: read call number {self.k}, its launch is call {launch_k[r]}"
+                self.pc = -1
+                return None
+            if self.pc == -1:                                    # draw a ticket (the read above has returned: barrier)
+                t = started[r]
+                started[r] += 1
+                if t == self.G - 1:
+                    started[r] = 0
+                    self.hand_on = True
+                self.pc = 0
+                return None
+            k, h = self.k, self.half
             if self.pc == 0:
                 self.pc, self.i = (1 if self.rows else 2), 0
             elif self.pc == 1:                                   # publish one row
@@ -106,6 +129,8 @@ def simulate(n_ranks, calls, seed):
                 if self.i == len(self.others):
                     self.pc = 9
             if self.pc == 9:
+                if self.hand_on:
+                    counter[r] = self.k                          # at the END of the block that drew the last ticket
                 self.done = True
             return None
 
@@ -123,7 +148,8 @@ def simulate(n_ranks, calls, seed):
                 break
         r = blk.r
         if all(x.done for x in live[r]):
-            done_calls[r] += 1                                   # the last block advances the call counter
+            assert counter[r] == launch_k[r] and started[r] == 0, (r, counter[r], launch_k[r], started[r])
+            launch_k[r] += 1                                     # kernels of one stream run in order
             ci[r] += 1
             if ci[r] < len(calls):
                 G = grid_of(calls[ci[r]][0])

@@ -267,3 +267,39 @@ def test_linear_normed_rejects_a_mismatched_norm(ops):
     with pytest.raises(TypeError):       # bf16 weights only
         ops.linear(h, torch.zeros(64, 256, dtype=torch.int8, device=DEV), scales=torch.ones(64, device=DEV, dtype=BF),
                    workspace=ws, pro=ops.DeferredNorm(h, torch.zeros(8, 8, device=DEV), nw, 1e-5))
+
+
+@pytest.mark.parametrize("M,N,K,swiglu,packed,normed", [
+    (32, 28672, 4096, True, True, False),     # the 8B w1|w3 of a cfg2 draft pass: the balance rule picks 7 waves
+    (32, 28672, 4096, True, True, True),      # ... with the deferred RMSNorm on its activation path
+    (64, 6144, 4096, False, True, False),     # 8B wqkv (192 wave tiles, 8 K slices): the rule picks 6 waves
+    (33, 1024, 1792, True, False, False), (100, 2048, 2048, False, True, True), (128, 3584, 4096, True, True, False),
+    (17, 4096, 512, False, False, False),
+])
+def test_linear_waves_per_workgroup_do_not_change_the_bits(ops, M, N, K, swiglu, packed, normed):
+    """Round 5: md_linear with 4, 6 or 7 wavefronts per workgroup (md_debug_set_gemm_waves; 0 = the balance rule of
+    csrc/gemm.hip:plan_of, which takes 6 / 7 waves where four leave some CUs with twice the bytes of others).  A wave's
+    tile, K range and slab order do not depend on its neighbours in the workgroup, and the K split is the same: every
+    form must give the SAME bits, for plain / SwiGLU / deferred-norm products, ragged row counts and partial last
+    workgroups (ntiles % 6, % 7 != 0)."""
+    import ctypes
+    lib = ops._lib.load()
+    g = torch.Generator().manual_seed(M + N + K)
+    x = torch.randn(M, K, generator=g).to(BF).to(DEV)
+    w = (torch.randn(N, K, generator=g) * 0.05).to(BF).to(DEV)
+    wt = ops.PackedWeight(w, swiglu=swiglu) if packed else w
+    ws = ops.AttnWorkspace(DEV)
+    pro = None
+    if normed:
+        ssq = (x.float().view(M, K // 32, 32) ** 2).sum(-1).contiguous()
+        pro = ops.DeferredNorm(x, ssq, (1 + 0.1 * torch.randn(K, generator=g)).to(BF).to(DEV), 1e-5)
+    outs = {}
+    try:
+        for nw in (4, 6, 7, 0):
+            lib.md_debug_set_gemm_waves(ctypes.c_int(nw))
+            outs[nw] = ops.linear(x, wt, swiglu=swiglu, workspace=ws, pro=pro).clone()
+    finally:
+        lib.md_debug_set_gemm_waves(ctypes.c_int(0))
+    assert not torch.isnan(outs[4].float()).any()
+    for nw in (6, 7, 0):
+        assert torch.equal(outs[nw].view(torch.int16), outs[4].view(torch.int16)), f"{nw} waves per workgroup != 4"

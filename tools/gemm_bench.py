@@ -14,9 +14,11 @@ from magicdec_amd import _lib, ops                     # noqa: E402
 from magicdec_amd.Engine.utils import enable_tuned_gemms   # noqa: E402
 
 ap = argparse.ArgumentParser()
-ap.add_argument("--blocks", type=int, nargs="+", default=[512])
+ap.add_argument("--blocks", type=int, nargs="+", default=[256])
 ap.add_argument("--only", default="")
 ap.add_argument("--iters", type=int, default=30)
+ap.add_argument("--waves", type=int, nargs="+", default=[0],
+                help="md_linear wavefronts per workgroup: 0 = the balance rule (plan_of), 4 / 6 / 7 forced (bit-identical)")
 a = ap.parse_args()
 print('tuned GEMM table loaded:', enable_tuned_gemms())
 dev = "cuda"
@@ -64,7 +66,7 @@ def timeit(fn, n):
 
 lib = _lib.load()
 ws = ops.AttnWorkspace(dev)
-print(f"{'shape':14s} {'M':>4s} {'N':>6s} {'K':>6s} | hipBLASLt us  TB/s |" + "".join(f" md_linear@{b}: row-major us TB/s / packed us TB/s |" for b in a.blocks))
+print(f"{'shape':14s} {'M':>4s} {'N':>6s} {'K':>6s} | hipBLASLt us  TB/s |" + "".join(f" md_linear@{b}/nw{nw}: row-major us TB/s / packed us TB/s |" for b in a.blocks for nw in a.waves))
 for name, M, N, K, swiglu in SHAPES:
     if a.only and a.only not in name:
         continue
@@ -81,10 +83,13 @@ for name, M, N, K, swiglu in SHAPES:
     line = f"{name:14s} {M:4d} {N:6d} {K:6d} | {t_ref:9.1f} {nbytes / t_ref / 1e6:6.2f} |"
     plist = [ops.PackedWeight(w, swiglu=bool(swiglu)) for w in wlist]
     for b in a.blocks:
-        lib.md_debug_set_gemm_target_blocks(ctypes.c_int(b))
-        t = timeit(lambda i: ops.linear(x, wlist[i % ncopy], swiglu=bool(swiglu), workspace=ws), a.iters)
-        tp = timeit(lambda i: ops.linear(x, plist[i % ncopy], swiglu=bool(swiglu), workspace=ws), a.iters)
-        line += f" {t:7.1f} {nbytes / t / 1e6:5.2f} / packed {tp:7.1f} {nbytes / tp / 1e6:5.2f} |"
+        for nw in a.waves:
+            lib.md_debug_set_gemm_target_blocks(ctypes.c_int(b))
+            lib.md_debug_set_gemm_waves(ctypes.c_int(nw))
+            t = timeit(lambda i: ops.linear(x, wlist[i % ncopy], swiglu=bool(swiglu), workspace=ws), a.iters)
+            tp = timeit(lambda i: ops.linear(x, plist[i % ncopy], swiglu=bool(swiglu), workspace=ws), a.iters)
+            line += f" {t:7.1f} {nbytes / t / 1e6:5.2f} / packed {tp:7.1f} {nbytes / tp / 1e6:5.2f} |"
+    lib.md_debug_set_gemm_waves(ctypes.c_int(0))
     del plist
     print(line, flush=True)
     del wlist
