@@ -85,6 +85,7 @@ EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 # nothing under magicdec_amd/ needs them)
 _DEV_SIGNATURES = {
     "md_debug_set_attn_target_wgs": (None, [I]),
+    "md_debug_set_attn_waves": (None, [I]),
     "md_debug_set_prefill_kt": (None, [I, I]),
     "md_debug_set_prefill_mfma32": (None, [I]),
     "md_debug_set_gemm_target_blocks": (None, [I]),

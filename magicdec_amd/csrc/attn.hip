@@ -113,8 +113,14 @@ __device__ __forceinline__ void cvt16_fp8_bf16(const u32x4 x, u32x4& lo, u32x4& 
     }
 }
 
-template <int D, int QT, bool FP8>
-__global__ __launch_bounds__(256, 2) void paged_attn_kernel(const AttnParams p) {
+// NWV: wavefronts per workgroup, 4 or 8 (round 5).  A launch with <= 256 workgroups puts ONE on each CU; with four waves
+// that is half the loads in flight of the two-workgroups-per-CU launches (B x KH_local = 512 pairs at TP1).  Eight waves
+// share the workgroup's tile range round-robin and merge through LDS like four.  Measured (profiles/r05_attn_waves_ab.txt):
+// it is NOT what holds the bf16 TP shards at 71-82 % (KH_local = 1 / 2 / 4 and B = 32: 8 waves equal or 1-3 % slower -- the
+// deficit there is the fixed ~10 us of launch, tail and merge on an 85 us kernel), but the fp8 kernel with two M tiles
+// (cfg5's shard: Qwen g = 5, B = 128 x 64 K keys, 2 splits) gains 7 %: 0.378 -> 0.352 ms = 71 -> 76 % of the HBM peak.
+template <int D, int QT, bool FP8, int NWV>
+__global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) void paged_attn_kernel(const AttnParams p) {
     constexpr int EB = FP8 ? 1 : 2;          // bytes per cache element
     constexpr int CH = D * EB / 16;          // 16-B chunks per K/V row in HBM
     constexpr int RPI = 64 / CH;             // rows per wave-wide load instruction
@@ -130,7 +136,7 @@ __global__ __launch_bounds__(256, 2) void paged_attn_kernel(const AttnParams p) 
     // and inside V sub-tiles 4..7 (undone when O is stored).
     constexpr bool FP8_SWAP = FP8 && D == 128;
     constexpr int WAVE_LDS = attn_wave_lds<D, QT>();
-    constexpr int TSTEP = 4;      // the 4 waves of a workgroup take the KV tiles round-robin
+    constexpr int TSTEP = NWV;    // the waves of a workgroup take the KV tiles round-robin
     // two tiles of loads in flight per wave where the register budget allows it (256 VGPRs at 2 waves/SIMD)
     // register staging depth: tiles of this wave whose loads are in flight while one tile is consumed.  Two where
     // the register budget allows it (256 VGPRs at 2 waves/SIMD; QT=2 at D=128 needs them for O and Q).  Deeper
@@ -473,7 +479,7 @@ __global__ __launch_bounds__(256, 2) void paged_attn_kernel(const AttnParams p) 
     }
 
     {
-        // merge the 4 waves' (m, l, O) through LDS
+        // merge the waves' (m, l, O) through LDS
         __syncthreads();
         float* mo = reinterpret_cast<float*>(smem + wave * WAVE_LDS);
         float* mst = mo + QT * D * 16;
@@ -494,20 +500,20 @@ __global__ __launch_bounds__(256, 2) void paged_attn_kernel(const AttnParams p) 
         __syncthreads();
         constexpr int ROWS = QT * 16;
         const int item = pair * p.n_qgroups + qg;
-        for (int e = tid; e < ROWS * D; e += 256) {
+        for (int e = tid; e < ROWS * D; e += 64 * NWV) {
             const int Rl = e / D, d = e - Rl * D;  // local row (qt*16+q), d
             const int R = qg * ROWS + Rl;
             if (R >= nrows) continue;
             const int qt = Rl >> 4, qq = Rl & 15;
             float M = -1e30f;
 #pragma unroll
-            for (int w = 0; w < 4; ++w) {
+            for (int w = 0; w < NWV; ++w) {
                 const float* st = reinterpret_cast<const float*>(smem + w * WAVE_LDS) + QT * D * 16;
                 M = fmaxf(M, st[(qt * 16 + qq) * 2]);
             }
             float L = 0.f, acc = 0.f;
 #pragma unroll
-            for (int w = 0; w < 4; ++w) {
+            for (int w = 0; w < NWV; ++w) {
                 const float* ow = reinterpret_cast<const float*>(smem + w * WAVE_LDS);
                 const float* st = ow + QT * D * 16;
                 const float sc = __builtin_amdgcn_exp2f(st[(qt * 16 + qq) * 2] - M);
@@ -1107,7 +1113,7 @@ __global__ __launch_bounds__(64 * NW, 2) void prefill32_attn_kernel(const AttnPa
 
 struct AttnPlan {
     bool splitq;
-    int nw;   // prefill: waves per workgroup sharing each K/V tile (4 or 8)
+    int nw;   // prefill: waves per workgroup sharing each K/V tile (4 or 8); decode / verify: waves splitting the tiles
     int qt;
     int n_qgroups;
     int nsplit;
@@ -1118,6 +1124,7 @@ struct AttnPlan {
 // step (B=64, 16K: 81 % / 80 % / 75 % / 70 % of HBM peak at KH_local = 8 / 4 / 2 / 1 vs 77 / 77 / 72 / 47 % at 1024);
 // per-workgroup prologue/epilogue and the partial-result round trip dominate once a wave owns < ~30 tiles
 int g_target_wgs = 256;  // dev knob: md_debug_set_attn_target_wgs
+int g_decode_nw = 0;     // dev knob (md_debug_set_attn_waves): 0 = the rule in make_plan, 4 / 8 = forced
 int g_prefill_nw = 0;     // dev knob (md_debug_set_prefill_kt): 0 = the measured rule below, 4 / 8 = forced
 
 // measurement mode of the decode / verify kernel (bench.py's roofline): see md_debug_attn_timing
@@ -1146,6 +1153,11 @@ AttnPlan make_plan(int B, int n_max, int H, int KH, int max_pages, int page_size
         if (want < 1) want = 1;
         pl.nsplit = (int)want;
         pl.rows_cap = pl.qt * 16;
+        // eight waves where measured faster: the fp8 two-M-tile kernel when the launch leaves one workgroup per CU and
+        // every wave still owns a stream of tiles (>= 8 each); see the kernel's header
+        const long wgs = (long)B * KH * pl.nsplit, tiles_per_wg = max_tiles / pl.nsplit;
+        pl.nw = (fp8 && pl.qt == 2 && wgs <= 256 && tiles_per_wg >= 64) ? 8 : 4;
+        if (g_decode_nw == 4 || g_decode_nw == 8) pl.nw = g_decode_nw;
     } else {
         pl.splitq = true;
         pl.qt = rows >= 128 ? 2 : 1;
@@ -1163,13 +1175,14 @@ AttnPlan make_plan(int B, int n_max, int H, int KH, int max_pages, int page_size
     return pl;
 }
 
-template <int D, int QT, bool FP8>
-int launch_attn(const AttnParams& p, int grid, hipStream_t st) {
-    constexpr int lds = 4 * attn_wave_lds<D, QT>();
+template <int D, int QT, bool FP8, int NWV>
+int launch_attn_nw(const AttnParams& p, int grid, hipStream_t st) {
+    constexpr int lds = NWV * attn_wave_lds<D, QT>();
+    static_assert(lds <= 160 * 1024, "the waves' LDS images must fit the CU");
     static MdPerDeviceOnce attr_once;
     if (attr_once.first()) {
         hipError_t e = hipFuncSetAttribute(
-            reinterpret_cast<const void*>(&paged_attn_kernel<D, QT, FP8>),
+            reinterpret_cast<const void*>(&paged_attn_kernel<D, QT, FP8, NWV>),
             hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) {
             md_set_error("md_paged_attn: hipFuncSetAttribute(%d B LDS) failed: %s", lds, hipGetErrorString(e));
@@ -1183,15 +1196,20 @@ int launch_attn(const AttnParams& p, int grid, hipStream_t st) {
         // trace reports -- instead of stream events around the launch, which also see the dispatch overhead
         hipEvent_t e0, e1;
         if (hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess) {
-            hipExtLaunchKernelGGL((paged_attn_kernel<D, QT, FP8>), dim3(grid), dim3(256), lds, st, e0, e1, 0, p);
+            hipExtLaunchKernelGGL((paged_attn_kernel<D, QT, FP8, NWV>), dim3(grid), dim3(64 * NWV), lds, st, e0, e1, 0, p);
             g_timed.push_back({e0, e1});
             MD_CHECK_LAUNCH("md_paged_attn");
             return MD_OK;
         }
     }
-    hipLaunchKernelGGL((paged_attn_kernel<D, QT, FP8>), dim3(grid), dim3(256), lds, st, p);
+    hipLaunchKernelGGL((paged_attn_kernel<D, QT, FP8, NWV>), dim3(grid), dim3(64 * NWV), lds, st, p);
     MD_CHECK_LAUNCH("md_paged_attn");
     return MD_OK;
+}
+
+template <int D, int QT, bool FP8>
+int launch_attn(const AttnParams& p, int grid, int nw, hipStream_t st) {
+    return nw == 8 ? launch_attn_nw<D, QT, FP8, 8>(p, grid, st) : launch_attn_nw<D, QT, FP8, 4>(p, grid, st);
 }
 
 int g_prefill_kt = 64;    // dev knob (md_debug_set_prefill_kt): keys per shared tile of the bf16 prefill kernel (D = 64)
@@ -1282,6 +1300,7 @@ int launch_prefill(const AttnParams& p, int grid, int nw, hipStream_t st) {
 
 #ifdef MD_DEV_KNOBS   // include/magicdec_hip_dev.h: tuning knobs, not part of the drop-in boundary
 extern "C" void md_debug_set_attn_target_wgs(int n) { g_target_wgs = n > 0 ? n : 256; }
+extern "C" void md_debug_set_attn_waves(int nw) { g_decode_nw = (nw == 4 || nw == 8) ? nw : 0; }
 extern "C" void md_debug_set_prefill_mfma32(int kt) {
     // < 0: the rule, 0: the 16x16 kernel, 32 | 64 | 128: keys per tile; 129: 128 keys with the first version's V pairing
     g_prefill_mfma32 = (kt == 32 || kt == 64 || kt == 128 || kt == 129 || kt < 0) ? kt : 0;
@@ -1392,7 +1411,7 @@ extern "C" int md_paged_attn(const void* q, int64_t q_row_stride, const void* ca
 #define MD_ATTN_DISPATCH(DD, FP)                                                                                  \
     (pl.splitq ? (pl.qt == 2 ? launch_prefill<DD, 2, FP>(p, grid, pl.nw, st)                                         \
                              : launch_prefill<DD, 1, FP>(p, grid, pl.nw, st))                                       \
-               : (pl.qt == 2 ? launch_attn<DD, 2, FP>(p, grid, st) : launch_attn<DD, 1, FP>(p, grid, st)))
+               : (pl.qt == 2 ? launch_attn<DD, 2, FP>(p, grid, pl.nw, st) : launch_attn<DD, 1, FP>(p, grid, pl.nw, st)))
     if (D == 128)
         rc = fp8 ? MD_ATTN_DISPATCH(128, true) : MD_ATTN_DISPATCH(128, false);
     else

@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from magicdec_amd import ops
 
 ap = argparse.ArgumentParser()
-for k, v in dict(B=64, S=16036, KH=8, H=32, D=128, n=4, iters=20, layers=2, wgs=0, fp8=0, hnd=0, kt=0, nw=0, mfma32=-1, reps=1, zero=0).items():
+for k, v in dict(B=64, S=16036, KH=8, H=32, D=128, n=4, iters=20, layers=2, wgs=0, fp8=0, hnd=0, kt=0, nw=0, mfma32=-1, reps=1, zero=0, dwaves=0).items():
     ap.add_argument(f"--{k}", type=int, default=v)
 ap.add_argument("--variants", default="", help="comma list of md_debug_set_prefill_mfma32 values timed in ONE process on the "
                 "same tensors (x --reps), each checked against the first one's output")
@@ -15,6 +15,10 @@ if a.wgs:
     import ctypes
     from magicdec_amd import _lib
     _lib.load().md_debug_set_attn_target_wgs(ctypes.c_int(a.wgs))
+if a.dwaves:                                   # decode / verify kernel: wavefronts per workgroup (4 | 8 forced)
+    import ctypes
+    from magicdec_amd import _lib
+    _lib.load().md_debug_set_attn_waves(ctypes.c_int(a.dwaves))
 if a.kt or a.nw:                               # prefill kernel: keys per shared tile / waves per workgroup
     import ctypes
     from magicdec_amd import _lib
@@ -67,7 +71,7 @@ def run_once(tag):
               f"{flops / ms / 1e9 / 25:.2f}% of 2.5 PFLOP/s dense bf16")
     print(f"md_paged_attn B={a.B} S={a.S} KH={a.KH} H={a.H} D={a.D} n={a.n}: {ms:.4f} ms  {nbytes / ms / 1e6:.1f} GB/s  "
           f"{nbytes / ms / 1e6 / 80:.2f}% of 8 TB/s  (alg bytes {nbytes}) wgs={a.wgs} fp8={a.fp8} layout={layout} "
-          f"map={os.environ.get('MD_ATTN_MAP', '0')}", flush=True)
+          f"map={os.environ.get('MD_ATTN_MAP', '0')} decode_waves={a.dwaves or 'rule'}", flush=True)
     return out
 
 
