@@ -569,12 +569,21 @@ def run(args, dev):
                                     "weights": weights},
         "prefill_s": round(t_pf, 2), "load_s": round(t_load, 2),
         # what "identical to the reference" means for this path (checked by `pytest -m gpu` and smoke(), not here)
-        "parity": {"tokens": "identity with the CPU oracle, tie-aware: argmax flips <= 2 x those of a float64-linear "
-                             "oracle + 6 per ~1000 positions (tests/test_gpu_engine.py lock-step)",
+        "parity": {"tokens": "identity with the CPU oracle; zero flips over 16 832 positions at the real layer widths and "
+                             "B = 64 (peaked weights, rejections in the run) and over 1 670 on the tiny peaked pair; on the "
+                             "near-flat logits of random-init tiny models argmax flips are MEASURED against three yardstick "
+                             "oracles per lock-step run of ~450-1 700 positions: hip 2-18, float64-linear oracle 0-13, "
+                             "bf16-P oracle (the tensor-core attention algorithm) 1-20, both 2-20 -- the bf16 P alone "
+                             "explains the HIP count; gate hip <= max(bf16-P, both) + 3 + one standard deviation "
+                             "(tests/test_gpu_engine.py, profiles/r05_parity_report.txt)",
                    "logits": "max |hip - oracle| <= 2 x the error of a correctly-rounded bf16 implementation + 2 bf16 "
-                             "ulp (measured 0.012-0.047 on logits of magnitude 1-4), NOT 1e-3 absolute: every bf16 "
-                             "linear output carries 2^-8 relative rounding",
-                   "integer_paths": "page tables, SnapKV top-k order, gather, accept/rollback: bit-exact"},
+                             "ulp (measured 0.012-0.047 on logits of magnitude 1-4; 1 ulp = 0.0625 on the peaked full-"
+                             "width run), NOT 1e-3 absolute: every bf16 linear output carries 2^-8 relative rounding",
+                   "integer_paths": "page tables, accept/rollback, gather, top-k order GIVEN the scores: bit-exact; SnapKV "
+                                    "pooled scores bit-identical to the reference fixtures; ties at the selection "
+                                    "threshold go to the lowest index (reference: torch.topk, unspecified among equal "
+                                    "scores -- fixture index sets differ by <= 4 of 225 per (request, kv head), all at "
+                                    "the threshold score)"},
         "roofline": {"kernel": f"paged_attn_kernel<{D},{1 if (G + 1) * (H_loc // KH_loc) <= 16 else 2},"
                                f"{'true' if args.kv_dtype == 'fp8' else 'false'}> (verify attention, md_paged_attn, "
                                f"{kv_layout} pages)",

@@ -9,7 +9,7 @@
 #   4. the whole -m gpu suite's parity report
 # usage: tools/profile_round.sh <tag>      outputs: gpurun_out/<tag>_*
 set -u
-TAG=${1:-r04}
+TAG=${1:-r05}
 OUT=$PWD/gpurun_out
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
@@ -21,7 +21,7 @@ timeout 900 rocprofv3 --kernel-trace --stats --output-format csv rocpd -d /tmp/p
     python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-pmc > $OUT/${TAG}_prof_bench.log 2>&1
 echo "bench under rocprofv3 rc=$?"
 KS=$(find /tmp/prof_b -name "*kernel_stats.csv" | head -1)
-[ -n "$KS" ] && head -60 "$KS" > $OUT/${TAG}_bench_cfg3_kernel_stats.csv
+[ -n "$KS" ] && head -70 "$KS" > $OUT/${TAG}_bench_cfg3_kernel_stats.csv
 DB=$(find /tmp/prof_b -name "*.db" | head -1)
 [ -n "$DB" ] && python tools/iter_breakdown.py $DB $OUT/${TAG}_bench_cfg3_iter_breakdown.csv > /dev/null
 grep '^{"metric"' $OUT/${TAG}_prof_bench.log > $OUT/${TAG}_bench_cfg3_under_rocprofv3.json
@@ -31,14 +31,24 @@ DB=$(find /tmp/prof_t -name "*.db" | head -1)
 [ -n "$DB" ] && python tools/iter_breakdown.py $DB $OUT/${TAG}_emulated_tp8_iter_breakdown.csv > /dev/null
 python3 bench.py --emulate-tp 8 --steps 20 --warmup 5 --no-cpu-baseline --no-pmc > $OUT/${TAG}_emulated_tp8.log 2>&1
 MAGICDEC_ONESHOT_AR=1 python3 bench.py --emulate-tp 8 --steps 20 --warmup 5 --no-cpu-baseline --no-pmc > $OUT/${TAG}_emulated_tp8_fused_ar.log 2>&1
-python3 bench.py --workload cfg2 --steps 20 --warmup 5 --no-cpu-baseline --no-pmc > $OUT/${TAG}_bench_cfg2.log 2>&1
+# configs[1] with PEAKED synthetic weights: the fixed-acceptance replay is the headline as before, and the measured-acceptance
+# run beside it now reports what the draft / verify kernels really accept (self-speculation through a StreamingLLM cache)
+python3 bench.py --workload cfg2 --weights peaked --steps 20 --warmup 5 --no-cpu-baseline --no-pmc > $OUT/${TAG}_bench_cfg2.log 2>&1
+rm -rf /tmp/prof_c
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv rocpd -d /tmp/prof_c -o bench -- \
+    python3 bench.py --workload cfg2 --weights peaked --steps 20 --warmup 5 --no-cpu-baseline --no-pmc > $OUT/${TAG}_prof_cfg2.log 2>&1
+DB=$(find /tmp/prof_c -name "*.db" | head -1)
+[ -n "$DB" ] && python tools/iter_breakdown.py $DB $OUT/${TAG}_bench_cfg2_iter_breakdown.csv > /dev/null
+timeout 300 python tools/snapkv_bench.py --dist all > $OUT/${TAG}_snapkv_bench.txt 2>&1
+timeout 200 python tools/ar_bench.py 2>&1 | grep " x " > $OUT/${TAG}_ar_bench.txt
 for f in emulated_tp8 emulated_tp8_fused_ar bench_cfg2; do grep '^{"metric"' $OUT/${TAG}_$f.log > $OUT/${TAG}_$f.json; done
 python3 -c "import __graft_entry__ as g; g.smoke()" > $OUT/${TAG}_smoke.log 2>&1
 echo "smoke rc=$?"; tail -2 $OUT/${TAG}_smoke.log
-timeout 900 python -m pytest tests -m gpu -q -p no:cacheprovider > $OUT/${TAG}_gpu_tests.log 2>&1
+timeout 1500 python -m pytest tests -m gpu -q -p no:cacheprovider > $OUT/${TAG}_gpu_tests.log 2>&1
 echo "suite rc=$?"; tail -1 $OUT/${TAG}_gpu_tests.log
 cp $OUT/parity_report.txt $OUT/${TAG}_parity_report.txt 2>/dev/null
 for f in bench_cfg3 bench_cfg3_under_rocprofv3 emulated_tp8 emulated_tp8_fused_ar bench_cfg2; do echo "== $f"; python3 -c "
 import json,sys
-l=json.load(open('$OUT/${TAG}_$f.json')); print(l['value'], l['ms_per_step'], l['autoregressive_ms_per_step'], l['speedup_vs_autoregressive'], l['roofline'], l['prefill_s']); print(l.get('cpu_baseline'))"; done
+l=json.load(open('$OUT/${TAG}_$f.json')); print(l['value'], l['ms_per_step'], l['autoregressive_ms_per_step'], l['speedup_vs_autoregressive'], l['roofline'], l['prefill_s']); print(l.get('cpu_baseline')); print(l['measured_acceptance_run']); print(l['speedup_condition'])"; done
+grep -i snapkv $OUT/${TAG}_bench_cfg3_kernel_stats.csv | cut -c1-160
 head -12 $OUT/${TAG}_bench_cfg3_kernel_stats.csv | cut -c1-150
