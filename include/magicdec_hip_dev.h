@@ -15,8 +15,8 @@ extern "C" {
 
 /* md_paged_attn: target number of workgroups of the split-KV decomposition; n <= 0 restores the default (256) */
 void md_debug_set_attn_target_wgs(int n);
-/* md_paged_attn (decode / verify): wavefronts per workgroup, 4 | 8 forced; 0 = the rule (8 when the launch leaves one
- * workgroup per CU and >= 8 tiles per wave) */
+/* md_paged_attn, decode / verify: wavefronts per workgroup, 4 | 8 forced; 0 = the rule of make_plan (8 for the fp8 two-M-tile
+ * kernel when the launch leaves one workgroup per CU and >= 8 tiles per wave) */
 void md_debug_set_attn_waves(int nw);
 /* md_paged_attn, prefill: 32x32x16-MFMA kernel: -1 = the measured rule (default), 0 = off (the 16x16x32 kernel),
  * 32 | 64 | 128 = keys per shared tile (halved until it divides the page size); 129 = 128 keys, first V sub-tile pairing */
