@@ -49,6 +49,11 @@ MIN_STREAM_BYTES_M128 = 100e6
 FUSED_MAX_L2_BYTES = 70e6
 FUSED_MAX_K = 4096
 FUSED_QKV_M256_MAX_L2_BYTES = 110e6
+# round 5 (profiles/r05_fused_tp8_shard_tiles.txt, M = 256): two more TP8 shards of the 8B verify pass go to the fused kernel --
+# w1|w3 (29.4 MB; 2 x 2 tiles: 21.1-22.3 us against 24.1 for the library + the SiLU*mul launch) and wo (4.2 MB, K = 512:
+# 12.0 against 14.1 incl. the add + norm behind it); w2 (14.7 MB: 17.1 vs 16.9) and everything wider stay on the library
+FUSED_M256_SWIGLU_MAX_BYTES = 32e6
+FUSED_M256_NARROW_MAX_BYTES = 5e6
 # a linear that can ALSO absorb the RMSNorm in front of it (deferred norm: its input is the un-normalised h of a fused
 # residual epilogue) saves that launch (~5 us + a boundary): the 1B w1|w3 at M = 64 (134 MB of tile traffic, 22.2 us
 # against md_linear's 21.9) then wins on the fused kernel
@@ -127,6 +132,10 @@ def use_fused(M: int, N: int, K: int, kind: str = "plain", absorbs_norm: bool = 
     l2_bytes = ((M + 31) // 32) * N * K * 2
     if M <= 128:
         return l2_bytes <= (FUSED_MAX_L2_BYTES_WITH_NORM if absorbs_norm else FUSED_MAX_L2_BYTES) and K <= FUSED_MAX_K
+    if kind == "swiglu":
+        return N * K * 2 <= FUSED_M256_SWIGLU_MAX_BYTES and K <= FUSED_MAX_K
+    if kind in ("plain", "resid"):
+        return N * K * 2 <= FUSED_M256_NARROW_MAX_BYTES
     return kind == "qkv" and l2_bytes <= FUSED_QKV_M256_MAX_L2_BYTES and K <= FUSED_MAX_K
 
 

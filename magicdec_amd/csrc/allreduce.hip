@@ -93,6 +93,13 @@ struct ArArgs {
 // stores (s_waitcnt vmcnt(0), inline asm: the compiler cannot drop it), the flags are polled with RELAXED loads and ONE
 // acquire fence per hop follows the poll (the guide's R1 hand-off in its cross-device form); the call counter needs no
 // fence at all -- its only reader is the next launch on the same stream.
+// INVARIANT: every store into a registered buffer that a PEER reads -- data[] (the published partials) and the
+// result halves (`myres`) -- must go through store_wt and be followed by drain_stores() before the flag is raised; a plain
+// store would sit in this XCD's L2 behind a relaxed flag.  finish_row's plain stores write the caller's OUTPUT tensors, which
+// no peer reads.  The correctness of the hand-off rests on vmcnt retiring a write-through store only once it is visible
+// at system scope; it has been validated between processes sharing one GPU (tests/test_gpu_allreduce.py: thousands of
+// calls, bit-exact) and NOT yet over xGMI links -- bench.py's child-process report is what decides
+// whether a multi-GPU run uses it.
 __device__ __forceinline__ void store_wt(bf16_t* base, size_t vec_index, const u32x4 v) {
     u32x4* p = reinterpret_cast<u32x4*>(base) + vec_index;
     asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");

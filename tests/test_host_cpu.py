@@ -1271,13 +1271,16 @@ def test_gemm_policy_encodes_the_measured_ab_table():
         assert c(64, N, K, kind) == "fused", (N, K, kind)
     # verify pass (M = 256): only the sharded qkv projection goes to the fused kernel; the 8B model's w2 streams
     assert c(256, 768, 4096, "qkv") == "fused" and c(256, 1536, 4096, "qkv") == "fused"
-    assert c(256, 6144, 4096, "qkv") == "lib" and c(256, 4096, 512, "plain") == "lib"
+    assert c(256, 6144, 4096, "qkv") == "lib"
+    # round 5 (profiles/r05_fused_tp8_shard_tiles.txt): two more TP8 shards of the verify pass -- w1|w3 and the K = 512 wo
+    assert c(256, 4096, 512, "plain") == "fused" and c(256, 3584, 4096, "swiglu") == "fused"
+    assert c(256, 7168, 4096, "swiglu") == "lib" and c(256, 4096, 1024, "plain") == "lib"       # the TP4 shards
     # round 4 (profiles/r04_block_ab_final.txt): the wide 129..256-row products and the K = 14336 down projection run
     # on the block-tile GEMM; the narrow projections and every TP shard stay where they were
     assert c(256, 28672, 4096, "swiglu") == "block" and c(256, 4096, 14336, "resid") == "block"
     assert c(256, 128256, 4096, "plain") == "block" and c(128, 28672, 4096, "swiglu") == "block"
     assert c(128, 4096, 14336, "resid") == "skinny" and c(256, 4096, 4096, "resid") == "lib"
-    assert c(256, 3584, 4096, "swiglu") == "lib" and c(256, 4096, 1792, "resid") == "lib"
+    assert c(256, 4096, 1792, "resid") == "lib" and c(256, 4096, 1792, "plain") == "lib"
     assert c(256, 2048, 8192, "resid") == "lib"
     # round 4 (profiles/r04_skinny_norm_ab.txt): md_linear absorbs a deferred norm up to 64 rows only
     if os.environ.get("MAGICDEC_SKINNY_NORM", "auto") == "auto":
