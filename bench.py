@@ -705,7 +705,13 @@ def xgmi_verdict(report):
         return False, "no report"
     if "error" in report or "rank0_child" in report:
         return False, "a child process failed: " + str(report.get("error") or report.get("rank0_child"))[:160]
+    stress = report.get("xgmi_stress")
+    if not isinstance(stress, dict) or stress.get("mismatched_elements_all_ranks", 1) != 0 or \
+            stress.get("timeouts_all_ranks", 1) != 0 or stress.get("calls", 0) < 100:
+        return False, f"the bit-exact stress of the xGMI kernels did not pass ({stress})"
     for name, r in report.items():
+        if name == "xgmi_stress":
+            continue
         if not isinstance(r, dict) or "xgmi_fused_add_rmsnorm_auto" not in r:
             return False, f"xGMI kernels unavailable for '{name}' (set-up or self-test against RCCL failed)"
         if r.get("xgmi_timeouts", 1) != 0:
@@ -761,6 +767,45 @@ def collective_microbench(group, shapes, dev, iters=30):
             r["xgmi"] = "unavailable (set-up or self-test against RCCL failed on some rank)"
         out[name] = r
     if ar is not None:
+        # Bit-exact stress of the kernels over THESE links before a run may rely on them (round 5): the hand-off rests on
+        # write-through stores being visible to a peer when the relaxed flag is (csrc/allreduce.hip), which the
+        # shared-GPU tests cannot probe and try_create's tolerance self-test would miss if it failed rarely.  16 inputs
+        # per round are all-gathered over RCCL, summed locally in rank order (fp32, one rounding = the kernel's
+        # definition), then 16 xGMI calls are queued back to back with no host synchronisation, algorithms and sizes
+        # interleaved, and compared bit for bit.
+        sizes = sorted({rows * dim for _, rows, dim in shapes} | {2048})
+        algos = (oneshot.ALGO_ONESHOT, oneshot.ALGO_TWOSHOT, oneshot.ALGO_AUTO)
+        world, rk = dist.get_world_size(group), dist.get_rank(group)
+        mism = calls = 0
+        gen = torch.Generator(device=dev).manual_seed(4321 + rk)
+        for rnd in range(40):
+            xs, wants = [], []
+            for j in range(16):
+                n = sizes[(rnd + j) % len(sizes)]
+                x = (torch.randn(n, device=dev, generator=gen, dtype=torch.float32) * 3).to(torch.bfloat16)
+                if dist.get_backend(group) == "nccl":
+                    parts = [torch.empty_like(x) for _ in range(world)]
+                    dist.all_gather(parts, x, group=group)
+                else:                         # gloo (the shared-GPU test): all_gather takes host tensors only
+                    host = [torch.empty(n, dtype=torch.bfloat16) for _ in range(world)]
+                    dist.all_gather(host, x.cpu(), group=group)
+                    parts = [h.to(dev) for h in host]
+                acc = parts[0].float()
+                for r in range(1, world):
+                    acc = acc + parts[r].float()
+                xs.append(x)
+                wants.append(acc.to(torch.bfloat16))
+            torch.cuda.synchronize()
+            dist.barrier(group=group)
+            for j, x in enumerate(xs):
+                ar.all_reduce_(x, algos[(rnd + j) % 3])
+            torch.cuda.synchronize()
+            for x, w_ in zip(xs, wants):
+                mism += int((x.view(torch.int16) != w_.view(torch.int16)).sum())
+                calls += 1
+        t = torch.tensor([mism, ar.status()], dtype=torch.int64, device=dev)
+        dist.all_reduce(t, group=group)
+        out["xgmi_stress"] = {"calls": calls, "mismatched_elements_all_ranks": int(t[0]), "timeouts_all_ranks": int(t[1])}
         ar.close()
     return out
 

@@ -98,10 +98,13 @@ def test_allreduce_selection_from_the_collectives_report():
     every message (no failure, no time-out) and measured it faster than RCCL + the add+norm launch on the verify message."""
     import bench
     ok = {"xgmi_fused_add_rmsnorm_auto": 11.0, "rccl_allreduce_then_add_rmsnorm": 31.0, "xgmi_timeouts": 0}
-    assert bench.xgmi_verdict({"verify": ok, "draft_step": dict(ok)})[0] is True
-    assert bench.xgmi_verdict({"verify": dict(ok, xgmi_fused_add_rmsnorm_auto=40.0)})[0] is False        # slower
-    assert bench.xgmi_verdict({"verify": dict(ok, xgmi_timeouts=1)})[0] is False                         # a spin timed out
-    assert bench.xgmi_verdict({"verify": ok, "draft_step": {"xgmi": "unavailable"}})[0] is False         # self-test failed
+    st = {"calls": 640, "mismatched_elements_all_ranks": 0, "timeouts_all_ranks": 0}
+    assert bench.xgmi_verdict({"verify": ok, "draft_step": dict(ok), "xgmi_stress": st})[0] is True
+    assert bench.xgmi_verdict({"verify": ok})[0] is False                                                 # no stress report
+    assert bench.xgmi_verdict({"verify": ok, "xgmi_stress": dict(st, mismatched_elements_all_ranks=3)})[0] is False
+    assert bench.xgmi_verdict({"verify": dict(ok, xgmi_fused_add_rmsnorm_auto=40.0), "xgmi_stress": st})[0] is False   # slower
+    assert bench.xgmi_verdict({"verify": dict(ok, xgmi_timeouts=1), "xgmi_stress": st})[0] is False      # a spin timed out
+    assert bench.xgmi_verdict({"verify": ok, "draft_step": {"xgmi": "unavailable"}, "xgmi_stress": st})[0] is False
     assert bench.xgmi_verdict({"error": "child timed out after 120 s"})[0] is False
-    assert bench.xgmi_verdict(dict({"verify": ok}, rank0_child="child exited with -11"))[0] is False    # a fault in the child
-    assert bench.xgmi_verdict(None)[0] is False and bench.xgmi_verdict({"autoregressive": ok})[0] is False
+    assert bench.xgmi_verdict(dict({"verify": ok, "xgmi_stress": st}, rank0_child="child exited with -11"))[0] is False
+    assert bench.xgmi_verdict(None)[0] is False and bench.xgmi_verdict({"autoregressive": ok, "xgmi_stress": st})[0] is False

@@ -669,6 +669,10 @@ def test_tp2_on_one_gpu(ckpt_dir, graphs=False):
     probe = r0["collectives"]["probe"]
     assert probe["xgmi_timeouts"] == 0 and all(probe[k] > 0 for k in ("rccl_allreduce", "xgmi_oneshot", "xgmi_twoshot",
                                                                       "xgmi_fused_add_rmsnorm_auto")), probe
+    # the bit-exact stress bench.py's N > 1 runs select the collective by: 640 queued calls, every element equal to "sum
+    # in rank order, fp32, one rounding"
+    stress = r0["collectives"]["xgmi_stress"]
+    assert stress["calls"] >= 600 and stress["mismatched_elements_all_ranks"] == 0 and stress["timeouts_all_ranks"] == 0, stress
     # numerics of the sharded engine: teacher-forced logits (vocab shards concatenated) vs the TP=1 HIP engine
     tgt, drf = _hip("target", ckpt_dir), _hip("snapkv_draft", ckpt_dir)
     ids = gc.synthetic_batches()[0].to(DEV)
