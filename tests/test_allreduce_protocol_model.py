@@ -30,8 +30,10 @@ import random
 MAXB = 4          # blocks of the model (kMaxBlocks = 64 in the kernel)
 
 
-def simulate(n_ranks, calls, seed):
-    """calls: list of (rows, two_shot).  Returns None, or a description of the first violation."""
+def simulate(n_ranks, calls, seed, handoff="last_reader"):
+    """calls: list of (rows, two_shot).  Returns None, or a description of the first violation.
+    handoff: "last_reader" = the kernel's rule (the block that drew the last ticket stores k when it ends);
+    "first_finisher" = a deliberately BROKEN rule (the first block to finish stores k) -- the negative control."""
     rng = random.Random(seed)
     N = n_ranks
     cap = max(c[0] for c in calls)
@@ -129,7 +131,7 @@ def simulate(n_ranks, calls, seed):
                 if self.i == len(self.others):
                     self.pc = 9
             if self.pc == 9:
-                if self.hand_on:
+                if (self.hand_on if handoff == "last_reader" else True):
                     counter[r] = self.k                          # at the END of the block that drew the last ticket
                 self.done = True
             return None
@@ -176,3 +178,14 @@ def test_protocol_invariant_under_random_schedules():
             for seed in range(150):
                 err = simulate(n_ranks, _calls(mode), seed)
                 assert err is None, (n_ranks, mode, seed, err)
+
+
+def test_model_catches_a_counter_handed_on_too_early():
+    """Negative control: if the FIRST block to finish advanced the call counter (instead of the block that drew the
+    last ticket), a block of the same launch that starts late reads k + 1 -- the model must find that schedule."""
+    found = None
+    for seed in range(300):
+        found = simulate(3, _calls("mixed"), seed, handoff="first_finisher")
+        if found:
+            break
+    assert found is not None and "read call number" in found, found
