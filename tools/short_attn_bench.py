@@ -16,10 +16,14 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from magicdec_amd import ops  # noqa: E402
 
 ap = argparse.ArgumentParser()
-for k, v in dict(B=64, KH=8, H=32, D=64, n=1, iters=40, hnd=0).items():
+for k, v in dict(B=64, KH=8, H=32, D=64, n=1, iters=40, hnd=0, dwaves=0).items():
     ap.add_argument(f"--{k}", type=int, default=v)
 a = ap.parse_args()
 dev = "cuda"
+if a.dwaves:                                   # wavefronts per workgroup of the decode kernel forced (4 | 8)
+    import ctypes
+    from magicdec_amd import _lib
+    _lib.load().md_debug_set_attn_waves(ctypes.c_int(a.dwaves))
 
 
 def timeit(fn, n):
@@ -62,5 +66,5 @@ for S in (16, 33, 65, 129, 257, 385, 513, 1025, 2049):
     qo = torch.arange(a.B + 1, dtype=torch.int32, device=dev) * a.n
     t = timeit(lambda: ops.paged_attention(q, cache, qo, indices, indptr, last, a.n, mp, ws, kv_layout=layout), a.iters)
     nbytes = a.B * S * a.KH * a.D * 2 * 2
-    print(f"B={a.B} KH={a.KH} H={a.H} D={a.D} n={a.n} S={S:5d} ({(S + 31) // 32:3d} tiles): {t:6.2f} us  "
+    print(f"B={a.B} KH={a.KH} H={a.H} D={a.D} n={a.n} waves={a.dwaves or 'rule'} S={S:5d} ({(S + 31) // 32:3d} tiles): {t:6.2f} us  "
           f"({nbytes / 1e6:6.1f} MB, {nbytes / t / 1e6:5.2f} TB/s)", flush=True)
