@@ -108,3 +108,42 @@ def test_allreduce_selection_from_the_collectives_report():
     assert bench.xgmi_verdict({"error": "child timed out after 120 s"})[0] is False
     assert bench.xgmi_verdict(dict({"verify": ok, "xgmi_stress": st}, rank0_child="child exited with -11"))[0] is False
     assert bench.xgmi_verdict(None)[0] is False and bench.xgmi_verdict({"autoregressive": ok, "xgmi_stress": st})[0] is False
+
+
+def test_speedup_condition_states_what_the_headline_is_conditional_on():
+    """bench.speedup_condition: break-even and the north-star threshold interpolated from the alpha
+    sweep; says so when a threshold is never reached or already met at the lowest swept rate."""
+    import bench
+    s = bench.speedup_condition({0.5: 1.43, 0.6: 1.73, 0.7: 1.98, 0.8: 2.29, 0.9: 2.73}, 0.8)
+    assert "alpha=0.8" in s and ">= 1.0x already at alpha = 0.5" in s and ">= 1.8x iff alpha >= 0.63" in s, s
+    s = bench.speedup_condition({0.5: 0.72, 0.6: 0.82, 0.7: 0.98, 0.8: 1.12, 0.9: 1.33}, 0.8)
+    assert ">= 1.0x iff alpha >= 0.71" in s and "1.8x is not reached" in s and "1.33x at 0.9" in s, s
+    assert "no alpha sweep" in bench.speedup_condition({0.8: 2.2}, 0.8)
+
+
+def test_peaked_synthetic_weights_predict_through_one_permutation(monkeypatch):
+    """Engine/utils._peak_ (bench.py --weights peaked): the seeded layers with a dominant embedding and a head tied to it
+    through a permutation that depends on (seed, vocab) only -- the next-token logit of the tied row stands far above
+    the rest, and two models of one vocabulary (different widths) predict through the same map."""
+    import torch
+    from magicdec_amd.Engine import model_core, utils
+    monkeypatch.setenv("MAGICDEC_SYNTH_WEIGHTS", "peaked")
+    maps = []
+    for name, dim in (("peak_a", 256), ("peak_b", 128)):
+        model_core.transformer_configs[name] = dict(block_size=2048, n_layer=1, n_head=4, n_local_heads=2, dim=dim,
+                                                    intermediate_size=2 * dim, vocab_size=1000)
+        with torch.device("meta"):
+            m = model_core.Transformer.from_name(name)
+        utils._random_init_(m, 1234, "cpu", torch.bfloat16)
+        e, o = m.tok_embeddings.weight.float(), m.output.weight.float()
+        assert 30.0 < float(e.std()) < 50.0                                  # the embedding dominates: rms ~ 40 per element
+        lg = o @ (e / e.pow(2).mean(dim=1, keepdim=True).sqrt()).t()          # [vocab out, vocab in]: logits of every token
+        top2 = lg.topk(2, dim=0).values
+        assert float((top2[0] - top2[1]).min()) > 4.0                        # peaked: the tied row wins by a wide margin
+        maps.append(lg.argmax(dim=0))
+    assert torch.equal(maps[0], maps[1])                                     # the same permutation at both widths
+    assert len(set(maps[0].tolist())) == 1000 and maps[0][:4].tolist() == [0, 1, 2, 3]
+    monkeypatch.setenv("MAGICDEC_SYNTH_WEIGHTS", "bogus")
+    import pytest
+    with pytest.raises(ValueError):
+        utils._random_init_(m, 1234, "cpu", torch.bfloat16)
