@@ -418,7 +418,7 @@ SkinnyPlan plan_of(int ntiles, int K, bool allow_nw) {
     pl.nw = 4;
     pl.S = pick_splits((ntiles + 3) / 4, K);
     if (g_force_nw == 4 || !allow_nw) return pl;
-    constexpr int kCUs = 256;
+    constexpr int kCUs = 256;                       // MI355X (gfx950 is the only target of this library)
     auto load = [&](int nw) {                       // bytes of the most loaded CU over the mean (round-robin placement)
         const long wgs = (long)((ntiles + nw - 1) / nw) * pl.S;
         const long per_cu = (wgs + kCUs - 1) / kCUs;

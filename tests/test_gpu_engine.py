@@ -871,15 +871,17 @@ def test_full_width_8b_and_1b_layers_b64_lockstep_token_identity():
         npos += lg.shape[0]
         wide += int(((top2[:, 0] - top2[:, 1]) >= 16 * ulp).sum())
     assert wide >= 0.99 * npos, (npos, wide)
-    e_t = LMBackend(dtype=torch.bfloat16, device=DEV, dec_len=G + 1)
-    e_t.load_model(Path(d) / "wide8b" / "model.pth", use_tp=False)
-    e_t.setup_caches(max_batch_size=B, max_seq_length=ML)
-    e_d = LMBackend_Draft(dtype=torch.bfloat16, device=DEV, draft_budget=BUD)
-    e_d.load_model(Path(d) / "wide1b" / "model.pth", use_tp=False)
-    e_d.setup_caches(max_batch_size=B, max_seq_length=ML, draft_budget=BUD)
-    st = replay(log, {"T": e_t, "D": e_d}, None)
     import shutil
-    shutil.rmtree(d, ignore_errors=True)
+    try:
+        e_t = LMBackend(dtype=torch.bfloat16, device=DEV, dec_len=G + 1)
+        e_t.load_model(Path(d) / "wide8b" / "model.pth", use_tp=False)
+        e_t.setup_caches(max_batch_size=B, max_seq_length=ML)
+        e_d = LMBackend_Draft(dtype=torch.bfloat16, device=DEV, draft_budget=BUD)
+        e_d.load_model(Path(d) / "wide1b" / "model.pth", use_tp=False)
+        e_d.setup_caches(max_batch_size=B, max_seq_length=ML, draft_budget=BUD)
+    finally:
+        shutil.rmtree(d, ignore_errors=True)          # 3 GB of checkpoints: gone whether or not the load worked
+    st = replay(log, {"T": e_t, "D": e_d}, None)
     verify_rows = sum(r["out"].numel() for r in log if r["tag"] == "T" and r["fn"] == "inference")
     n_two = sum(1 for r in log if r["cu"] is not None)
     assert n_two >= 1, "no two-token draft step in the run"
