@@ -36,7 +36,7 @@ def layer_shapes(dim, H, KH, D, I, tp):
 
 MODELS = {"1B": (2048, 32, 8, 64, 8192), "8B": (4096, 32, 8, 128, 14336)}
 CASES = [("1B", 1, 64), ("1B", 1, 128), ("1B", 4, 64), ("1B", 4, 128), ("8B", 8, 256), ("8B", 8, 64), ("8B", 4, 256),
-         ("8B", 2, 256), ("8B", 1, 64), ("8B", 1, 256)]
+         ("8B", 2, 256), ("8B", 1, 64), ("8B", 1, 256), ("8B", 1, 128), ("8B", 1, 32)]
 
 
 def timeit(fn, n):
