@@ -62,9 +62,10 @@ struct Signal {
 // area and let the LAST block to FINISH advance the counter: an uncached read at the head of every launch (everything
 // else waits for k) and a returning atomic on uncached memory at its tail -- ~3 us of a 9 us launch with one rank
 // (tools/ar_bench.py).  All the protocol needs is that no block of call k reads the counter after it was advanced, so the
-// last block to have READ it advances it: thread 0 reads ctrl[0] (its value returns before the block's first barrier),
-// after the barrier lane 0 of wave 1 adds 1 to ctrl[1] -- the result is consumed only at the end of the kernel, so its
-// round trip hides under the row work -- and the block that drew G - 1 resets ctrl[1] and stores k.  The next launch on the
+// last block to have READ it advances it: thread 0 reads ctrl[0] (behind the waves' prefetch loads; its value returns
+// before the block's first barrier), after the barrier lane 0 of the last wave adds 1 to ctrl[1] -- at once if that wave
+// has no row in this call (usual: nobody waits for the round trip), after its rows otherwise -- and the block that drew
+// G - 1 resets ctrl[1] and stores k.  The next launch on the
 // stream reads it behind a kernel boundary.  (tests/test_allreduce_protocol_model.py models exactly this.)
 struct ArDev {
     bf16_t* data[kMaxRanks];   // peer buffers: [data half 0][data half 1][result half 0][result half 1]
@@ -207,12 +208,6 @@ __global__ __launch_bounds__(kThreads) void allreduce_kernel(const ArDev c, cons
     __shared__ uint32_t s_k;
     __shared__ int s_bad;
     Signal* self = c.sig[c.rank];
-    if (tid == 0) {
-        // a plain load: nobody writes the counter while a block of this call may still read it (that is the protocol),
-        // and the previous call's store is behind a kernel boundary
-        s_k = *reinterpret_cast<const volatile uint32_t*>(&c.ctrl[0]) + 1;
-        s_bad = 0;
-    }
 
     // rows of this block: row -> owner = row % NR, idx = row / NR, block = idx % G
     auto row_vecs_of = [&](int row) -> int {
@@ -246,12 +241,24 @@ __global__ __launch_bounds__(kThreads) void allreduce_kernel(const ArDev c, cons
                 if (lane + 64 * i < a.row_vecs) wpf[i] = reinterpret_cast<const u32x4*>(a.weight)[lane + 64 * i];
         }
     }
+    if (tid == 0) {
+        // BEHIND the wave's prefetch in program order, so that the two round trips overlap.  A plain (cacheable) load:
+        // nobody writes the counter while a block of this call may still read it (that is the protocol), and the
+        // previous call's store is behind a kernel boundary
+        s_k = c.ctrl[0] + 1;
+        s_bad = 0;
+    }
     __syncthreads();
     const uint32_t k = s_k;
     const size_t half = (k & 1u) ? c.buf_elems : 0;
-    // this block has read the counter: count it (the result is used at the very end of the kernel)
+    // This block has read the counter: count it.  The ticket is drawn by lane 0 of the LAST wave -- at once if that wave has
+    // no row in this call (the usual case: a block's rows go to its first waves), so that the atomic's round trip costs
+    // nobody anything; after its rows otherwise.  The result is used at the very end of the kernel only.
+    const bool drawer = tid == kThreads - 64;
+    const bool draw_early = !have0;                  // wave-uniform
     uint32_t drawn = 0;
-    if (tid == 64) drawn = __hip_atomic_fetch_add(&c.ctrl[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (drawer && draw_early)
+        drawn = __hip_atomic_fetch_add(&c.ctrl[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 
     // 1. publish: copy every row of block b into my data buffer, write-through (a lone rank has nobody to publish to)
     if constexpr (NR > 1) {
@@ -378,7 +385,9 @@ __global__ __launch_bounds__(kThreads) void allreduce_kernel(const ArDev c, cons
 
     // the block that drew the last ticket hands the call counter on (every block of this call has read it; the next
     // launch on the stream reads it behind a kernel boundary); `status` is read by the host behind one, too
-    if (tid == 64 && drawn == (uint32_t)G - 1) {
+    if (drawer && !draw_early)
+        drawn = __hip_atomic_fetch_add(&c.ctrl[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (drawer && drawn == (uint32_t)G - 1) {
         __hip_atomic_store(&c.ctrl[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(&c.ctrl[0], k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }

@@ -58,7 +58,16 @@ def simulate(n_ranks, calls, seed, handoff="last_reader"):
             self.others = [i for i in self.rows if i % N != r]
             self.pc, self.i, self.p = -2, 0, 0
             self.hand_on = False                                # drew the last ticket: stores k into the counter when it ends
+            self.late = rng.random() < 0.5                      # the ticket is drawn at once (the last wave has no row) or
+            #                                                     after the block's rows (it has): both occur in the kernel
             self.done = False
+
+        def draw(self):
+            t = started[self.r]
+            started[self.r] += 1
+            if t == self.G - 1:
+                started[self.r] = 0
+                self.hand_on = True
 
         def runnable(self):
             if self.pc == 3:
@@ -74,14 +83,10 @@ def simulate(n_ranks, calls, seed, handoff="last_reader"):
                 self.half = self.k & 1
                 if self.k != launch_k[r]:
                     return f"rank {r} block {b}: read call number {self.k}, its launch is call {launch_k[r]}"
-                self.pc = -1
+                self.pc = 0 if self.late else -1
                 return None
             if self.pc == -1:                                    # draw a ticket (the read above has returned: barrier)
-                t = started[r]
-                started[r] += 1
-                if t == self.G - 1:
-                    started[r] = 0
-                    self.hand_on = True
+                self.draw()
                 self.pc = 0
                 return None
             k, h = self.k, self.half
@@ -131,6 +136,8 @@ def simulate(n_ranks, calls, seed, handoff="last_reader"):
                 if self.i == len(self.others):
                     self.pc = 9
             if self.pc == 9:
+                if self.late:
+                    self.draw()
                 if (self.hand_on if handoff == "last_reader" else True):
                     counter[r] = self.k                          # at the END of the block that drew the last ticket
                 self.done = True
