@@ -885,6 +885,8 @@ def test_full_width_8b_and_1b_layers_b64_lockstep_token_identity():
         e_d.setup_caches(max_batch_size=B, max_seq_length=ML, draft_budget=BUD)
     finally:
         shutil.rmtree(d, ignore_errors=True)          # 3 GB of checkpoints: gone whether or not the load worked
+        for name in ("wide8b", "wide1b"):             # the config table is process-global
+            model_core.transformer_configs.pop(name, None)
     st = replay(log, {"T": e_t, "D": e_d}, None)
     verify_rows = sum(r["out"].numel() for r in log if r["tag"] == "T" and r["fn"] == "inference")
     n_two = sum(1 for r in log if r["cu"] is not None)
