@@ -350,12 +350,19 @@ int md_linear_fused(const md_fused_linear_args* args, md_stream_t stream);
  * K10  argmax over a vocab shard / TP merge
  *     reference: Engine/SnapKV/model.py:175-188
  * argmax: per row, max bf16 logit and its lowest index (+index_offset).
+ * argmax_tp_slots (round 5): the same argmax written as the one-hot-slot
+ * tensors the reference all-reduces (model.py:178-184: torch.zeros + index
+ * assignment): vals_out / idx_out [rows, tp_world], the row's result in
+ * column tp_rank, zeros elsewhere -- one launch instead of five.
  * tp_argmax_merge: vals/idx [rows, tp] -> token of the lowest rank among
  * equal maxima (torch.argmax over [..,tp], model.py:185).
  * ---------------------------------------------------------------------- */
 int md_argmax(const void* logits, int64_t row_stride, int rows, int vocab, int64_t index_offset,
               void* max_val_out /* bf16 [rows], may be NULL */, int64_t* idx_out,
               md_stream_t stream);
+int md_argmax_tp_slots(const void* logits, int64_t row_stride, int rows, int vocab, int64_t index_offset,
+                       int tp_rank, int tp_world, void* vals_out /* bf16 [rows,tp_world] */,
+                       int64_t* idx_out /* [rows,tp_world] */, md_stream_t stream);
 int md_tp_argmax_merge(const void* vals /* bf16 [rows,tp] */, const int64_t* idx /* [rows,tp] */,
                        int rows, int tp, int64_t* out, md_stream_t stream);
 

@@ -525,12 +525,8 @@ class Transformer(nn.Module):
         one-hot-slot tensors, then the lowest rank among equal maxima."""
         if self.process_group is None:
             return ops.argmax(logits)
-        rows = logits.shape[0]
-        vals, idx = ops.argmax(logits, index_offset=self.rank * logits.shape[1], return_values=True)
-        all_v = torch.zeros((rows, self.world_size), dtype=logits.dtype, device=logits.device)
-        all_i = torch.zeros((rows, self.world_size), dtype=torch.long, device=logits.device)
-        all_v[:, self.rank] = vals
-        all_i[:, self.rank] = idx
+        # the one-hot-slot tensors of the reference (zeros + this rank's column), written by the argmax launch itself
+        all_v, all_i = ops.argmax_tp_slots(logits, self.rank, self.world_size, index_offset=self.rank * logits.shape[1])
         dist.all_reduce(all_v, group=self.process_group)
         dist.all_reduce(all_i, group=self.process_group)
         return ops.tp_argmax_merge(all_v, all_i)

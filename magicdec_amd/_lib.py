@@ -11,7 +11,7 @@ from ctypes import c_char_p, c_double, c_float, c_int, c_int64, c_size_t, c_void
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmagicdec_hip.so")
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 _lib = None
 _err = None
@@ -75,6 +75,7 @@ _SIGNATURES = {
     "md_add_rmsnorm": (c_int, [P, P, P, P, P, I, I, c_float, P]),
     "md_silu_mul": (c_int, [P, P, L, L, P, I, I, P]),
     "md_argmax": (c_int, [P, L, I, I, L, P, P, P]),
+    "md_argmax_tp_slots": (c_int, [P, L, I, I, L, I, I, P, P, P]),
     "md_tp_argmax_merge": (c_int, [P, P, I, I, P, P]),
     "md_accept_rollback": (c_int, [P, P, P, I, P, P, P, P, P, I, I, I, I, L, L, L, P, P, P, P, P, P]),
 }

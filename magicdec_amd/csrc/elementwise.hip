@@ -166,9 +166,13 @@ __global__ __launch_bounds__(256) void silu_mul_kernel(const bf16_t* __restrict_
 // one workgroup of NT threads per row; lowest index among equal maxima.  Decode steps have few rows (64..256) of a
 // 128K vocabulary: with NT = 1024 (16 waves, 4 loads in flight each) a row is limited by its CU's load issue rate
 // instead of by one wave's memory latency (49 -> ~15 us for 64 rows)
+// slots > 0 (md_argmax_tp_slots): the outputs are [rows, slots] and the row's result goes to column `slot`, zeros to the
+// others -- the one-hot-slot tensors the reference builds with torch.zeros + an index assignment before its two
+// all-reduces (Engine/SnapKV/model.py:178-184), in the argmax launch itself
 template <int NT>
 __global__ __launch_bounds__(NT) void argmax_kernel(const bf16_t* __restrict__ logits, int64_t row_stride, int vocab,
-                                                    int64_t index_offset, bf16_t* max_val_out, int64_t* idx_out) {
+                                                    int64_t index_offset, bf16_t* max_val_out, int64_t* idx_out,
+                                                    int slots, int slot) {
     __shared__ float sv[NT / 64];
     __shared__ int si[NT / 64];
     const int64_t row = blockIdx.x;
@@ -229,8 +233,15 @@ __global__ __launch_bounds__(NT) void argmax_kernel(const bf16_t* __restrict__ l
                 bi = si[w];
             }
         if (bi == 0x7fffffff) bi = 0;  // all -inf / NaN row: torch.argmax returns an index too; pick 0
-        idx_out[row] = (int64_t)bi + index_offset;
-        if (max_val_out) max_val_out[row] = f32_to_bf16(best);
+        if (slots > 0) {
+            for (int s = 0; s < slots; ++s) {
+                idx_out[row * slots + s] = s == slot ? (int64_t)bi + index_offset : (int64_t)0;
+                max_val_out[row * slots + s] = f32_to_bf16(s == slot ? best : 0.f);
+            }
+        } else {
+            idx_out[row] = (int64_t)bi + index_offset;
+            if (max_val_out) max_val_out[row] = f32_to_bf16(best);
+        }
     }
 }
 
@@ -312,11 +323,27 @@ extern "C" int md_argmax(const void* logits, int64_t row_stride, int rows, int v
     MD_CHECK_ARG(rows > 0 && vocab > 0, "md_argmax: bad shape rows=%d vocab=%d", rows, vocab);
     if (rows <= 512 && vocab >= 16384)
         hipLaunchKernelGGL((argmax_kernel<1024>), dim3(rows), dim3(1024), 0, (hipStream_t)stream, (const bf16_t*)logits,
-                           row_stride, vocab, index_offset, (bf16_t*)max_val_out, idx_out);
+                           row_stride, vocab, index_offset, (bf16_t*)max_val_out, idx_out, 0, 0);
     else
         hipLaunchKernelGGL((argmax_kernel<256>), dim3(rows), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)logits,
-                           row_stride, vocab, index_offset, (bf16_t*)max_val_out, idx_out);
+                           row_stride, vocab, index_offset, (bf16_t*)max_val_out, idx_out, 0, 0);
     MD_CHECK_LAUNCH("md_argmax");
+    return MD_OK;
+}
+
+extern "C" int md_argmax_tp_slots(const void* logits, int64_t row_stride, int rows, int vocab, int64_t index_offset,
+                                  int tp_rank, int tp_world, void* vals_out, int64_t* idx_out, md_stream_t stream) {
+    MD_CHECK_ARG(logits && vals_out && idx_out, "md_argmax_tp_slots: null pointer argument");
+    MD_CHECK_ARG(rows > 0 && vocab > 0, "md_argmax_tp_slots: bad shape rows=%d vocab=%d", rows, vocab);
+    MD_CHECK_ARG(tp_world >= 1 && tp_world <= 64 && tp_rank >= 0 && tp_rank < tp_world,
+                 "md_argmax_tp_slots: need 1 <= tp_world <= 64 and 0 <= tp_rank < tp_world (got %d of %d)", tp_rank, tp_world);
+    if (rows <= 512 && vocab >= 16384)
+        hipLaunchKernelGGL((argmax_kernel<1024>), dim3(rows), dim3(1024), 0, (hipStream_t)stream, (const bf16_t*)logits,
+                           row_stride, vocab, index_offset, (bf16_t*)vals_out, idx_out, tp_world, tp_rank);
+    else
+        hipLaunchKernelGGL((argmax_kernel<256>), dim3(rows), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)logits,
+                           row_stride, vocab, index_offset, (bf16_t*)vals_out, idx_out, tp_world, tp_rank);
+    MD_CHECK_LAUNCH("md_argmax_tp_slots");
     return MD_OK;
 }
 

@@ -658,6 +658,21 @@ def argmax(logits, index_offset=0, return_values=False):
     return (vals, idx) if return_values else idx
 
 
+def argmax_tp_slots(logits, tp_rank, tp_world, index_offset=0):
+    """(vals [rows, tp_world] bf16, idx [rows, tp_world] int64): the row-wise argmax of this rank's vocab shard in column
+    tp_rank, zeros elsewhere -- the tensors the reference sum-all-reduces before its merge (Engine/SnapKV/model.py:178-184),
+    written by the argmax launch itself."""
+    _gpu(logits)
+    if logits.dim() != 2 or logits.stride(1) != 1:
+        raise ValueError("argmax_tp_slots expects [rows, vocab] with unit inner stride")
+    rows, vocab = logits.shape
+    vals = torch.empty((rows, tp_world), dtype=logits.dtype, device=logits.device)
+    idx = torch.empty((rows, tp_world), dtype=torch.int64, device=logits.device)
+    check(_lib.load().md_argmax_tp_slots(_p(logits), logits.stride(0), rows, vocab, int(index_offset), int(tp_rank),
+                                         int(tp_world), _p(vals), _p(idx), _stream()), "md_argmax_tp_slots")
+    return vals, idx
+
+
 def tp_argmax_merge(vals, idx):
     """vals [rows, tp] bf16, idx [rows, tp] int64 -> winning global index per row (lowest rank on ties)."""
     _gpu(vals, idx)

@@ -151,6 +151,15 @@ def argmax(logits, index_offset=0, return_values=False):
     return (vals, idx) if return_values else idx
 
 
+def argmax_tp_slots(logits, tp_rank, tp_world, index_offset=0):
+    vals, idx = torch.max(logits, dim=-1)                     # Engine/SnapKV/model.py:178-184
+    all_v = torch.zeros((logits.shape[0], tp_world), dtype=logits.dtype)
+    all_i = torch.zeros((logits.shape[0], tp_world), dtype=torch.long)
+    all_v[:, tp_rank] = vals
+    all_i[:, tp_rank] = idx + index_offset
+    return all_v, all_i
+
+
 def tp_argmax_merge(vals, idx):
     return mr.tp_argmax_merge(vals, idx)
 
@@ -171,7 +180,7 @@ def accept_rollback(tokens_buffer, target_tokens, output, num_nodes, cachelens, 
 
 
 ALL = ["RopeTable", "AttnWorkspace", "update_kv", "rope", "rope_append", "paged_attention", "snapkv_select",
-       "streaming_shift_append", "streaming_rotate", "rmsnorm", "add_rmsnorm", "silu_mul", "argmax", "tp_argmax_merge",
+       "streaming_shift_append", "streaming_rotate", "rmsnorm", "add_rmsnorm", "silu_mul", "argmax", "argmax_tp_slots", "tp_argmax_merge",
        "accept_rollback"]
 
 

@@ -419,6 +419,14 @@ def test_argmax_lowest_index_and_tp_merge(ops, vocab):
     tpi = torch.randint(0, 100000, (9, 8), generator=g)
     out = ops.tp_argmax_merge(tpv.to(DEV), tpi.to(DEV)).cpu()
     assert torch.equal(out, mr.tp_argmax_merge(tpv, tpi))
+    # round 5: the one-hot-slot form (what the reference builds with zeros + an index assignment before its all-reduces)
+    for rank, world in ((0, 1), (2, 3), (7, 8)):
+        sv, si = ops.argmax_tp_slots(logits.to(DEV), rank, world, index_offset=rank * vocab)
+        want_v = torch.zeros(9, world, dtype=BF)
+        want_i = torch.zeros(9, world, dtype=torch.long)
+        want_v[:, rank] = logits.float().max(dim=-1).values.to(BF)
+        want_i[:, rank] = ref + rank * vocab
+        assert torch.equal(bits(sv.cpu()), bits(want_v)) and torch.equal(si.cpu(), want_i), (rank, world)
 
 
 # ----------------------------------------------------------------------------------------- accept loop
