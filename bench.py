@@ -237,7 +237,8 @@ def run(args, dev):
     # with its low-latency intra-node all-reduce on (README.md:59, ENABLE_INTRA_NODE_COMM=1); ours was opt-in because it
     # had never crossed a link.  With MAGICDEC_ONESHOT_AR unset, the fused xGMI all-reduce + add + RMSNorm becomes the
     # run's collective iff the CHILD processes -- where a fault or hang costs nothing -- validated it against RCCL on these
-    # very GPUs (no error, no time-out) and measured it faster than RCCL + the add+norm launch on the verify message;
+    # very GPUs (no error, no time-out, a 640-call bit-exact stress: collective_microbench) and measured it faster than RCCL
+    # + the add+norm launch on the verify message;
     # otherwise RCCL.  Rank 0 decides, every rank follows (one broadcast); Engine/oneshot.try_create still self-tests it
     # at load and falls back collectively.
     coll_report = None
