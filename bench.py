@@ -449,6 +449,29 @@ def run(args, dev):
         restore()
     prime()
 
+    # Probation of the xGMI all-reduce inside the run's own processes and hipGraphs (round 5): the children validated the
+    # kernels on these links, try_create self-tested them eagerly at load; prime() has now replayed every captured step
+    # variant once with them inside.  If ANY rank saw a time-out there, every rank drops to RCCL here -- a point where all
+    # ranks stand at the same statement and no other collective is in flight -- instead of failing in the timed region,
+    # where a time-out is fatal by design (AllReduceTimeout at the iteration it happened in).
+    if use_tp and world > 1 and on_gpu and os.environ.get("MAGICDEC_ONESHOT_AR") == "1":
+        models = [engine.model] + ([draft.model] if draft is not None else [])
+        bad = any(getattr(m, "_oneshot", None) is not None and m._oneshot.status() != 0 for m in models)
+        t = torch.tensor([1 if bad else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        if int(t.item()):
+            from magicdec_amd.Engine.graph import clear_graphs
+            for m in models:
+                m._oneshot = None                     # Transformer._reduce_add_norm / _reduce fall back to RCCL
+            clear_graphs(engine)
+            if draft is not None:
+                clear_graphs(draft)
+            ar_selection += " -- DROPPED after a time-out in the first graph-replayed steps: every rank runs rccl"
+            if rank == 0:
+                print("[collectives_us] xGMI all-reduce timed out during probation: every rank drops to RCCL",
+                      file=sys.stderr, flush=True)
+            prime()
+
     gen = torch.Generator(device=dev if on_gpu else "cpu").manual_seed(2024)
     forced = truncated_geometric(args.alpha, G, (args.warmup + args.steps, B), gen, dev)
     dt_replay, tok_replay = run_spec(args.warmup, args.steps, forced)
