@@ -161,14 +161,42 @@ def truncated_geometric(alpha, gamma, shape, gen, device):
     return a
 
 
-def main():
+def self_launch(n, argv=None):
+    """`python bench.py --gpus N` (N > 1) started plainly, i.e. not under torch.distributed.run: re-execute the SAME
+    command line as N ranks of one node -- `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr
+    127.0.0.1 --master-port <free port> <this script> <same argv>`, the form the driver uses and the reference's README
+    prescribes for its own scripts (README.md:59-69: torchrun --nproc_per_node=8; Engine/tp.py:54-64 reads the ranks from
+    the environment) -- and hand its exit code on.  Rank 0 of the children prints the JSON line on the inherited stdout."""
+    import socket
+    import subprocess
+    argv = list(sys.argv if argv is None else argv)
+    with socket.socket() as s:                      # a free rendezvous port on the loopback interface
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: RCCL / peer-mapped buffers need it on this driver
+    env.setdefault("OMP_NUM_THREADS", "8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.abspath(argv[0])] + argv[1:]
+    print(f"[bench] --gpus {n} without WORLD_SIZE: launching {n} ranks: {' '.join(cmd[:10])} ...", file=sys.stderr,
+          flush=True)
+    return subprocess.call(cmd, env=env)
+
+
+def main(device=None):
+    """`device` is None in production (one cuda device per rank); tests/test_bench_cpu.py passes "cpu" from a wrapper
+    that first installs its device-op stand-ins, to drive the launcher + rendezvous + JSON contract without a GPU."""
     args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(self_launch(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)"
-    assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
-    torch.cuda.set_device(local_rank)
-    line = run(args, f"cuda:{local_rank}")
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (a launcher exported another world size)"
+    if device is None:
+        assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
+        torch.cuda.set_device(local_rank)
+        device = f"cuda:{local_rank}"
+    line = run(args, device)
     # RCCL prints its version banner through C stdio, which is fully buffered on a pipe and would otherwise be
     # flushed at process exit, i.e. AFTER the JSON line: flush it first so that the JSON line is the last line
     import ctypes
@@ -261,12 +289,16 @@ def run(args, dev):
             except OSError:
                 pass
         if "MAGICDEC_ONESHOT_AR" not in os.environ:
-            use_xgmi, why = xgmi_verdict(coll_report) if rank == 0 else (False, "")
-            flag = torch.tensor([1 if use_xgmi else 0], dtype=torch.int32, device=dev)
+            arm, why = xgmi_verdict(coll_report) if rank == 0 else (None, "")
+            flag = torch.tensor([{"wt": 1, "fence": 2}.get(arm, 0)], dtype=torch.int32, device=dev)
             dist.broadcast(flag, src=0)
             os.environ["MAGICDEC_ONESHOT_AR"] = "1" if int(flag.item()) else "0"
-            ar_selection = ("xgmi fused all-reduce + add + RMSNorm" if int(flag.item()) else "rccl") + \
-                           f" (chosen from this run's collectives_us: {why})" if rank == 0 else ""
+            if int(flag.item()) == 2:
+                os.environ["MAGICDEC_AR_PUBLISH"] = "fence"      # read by every OneShotAllReduce this process creates
+            ar_selection = (("xgmi fused all-reduce + add + RMSNorm" +
+                             (" [release-fence publish]" if int(flag.item()) == 2 else " [write-through publish]")
+                             if int(flag.item()) else "rccl") +
+                            f" (chosen from this run's collectives_us: {why})") if rank == 0 else ""
             if rank == 0:
                 print(f"[collectives_us] all-reduce of this run: {ar_selection}", file=sys.stderr, flush=True)
         dist.barrier()
@@ -454,22 +486,24 @@ def run(args, dev):
     # variant once with them inside.  If ANY rank saw a time-out there, every rank drops to RCCL here -- a point where all
     # ranks stand at the same statement and no other collective is in flight -- instead of failing in the timed region,
     # where a time-out is fatal by design (AllReduceTimeout at the iteration it happened in).
+    ar_probation = None
     if use_tp and world > 1 and on_gpu and os.environ.get("MAGICDEC_ONESHOT_AR") == "1":
         models = [engine.model] + ([draft.model] if draft is not None else [])
-        bad = any(getattr(m, "_oneshot", None) is not None and m._oneshot.status() != 0 for m in models)
-        t = torch.tensor([1 if bad else 0], dtype=torch.int32, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        if int(t.item()):
+        ar_probation = xgmi_probation(models, dev)
+        if ar_probation["drop"]:
             from magicdec_amd.Engine.graph import clear_graphs
-            for m in models:
+            _sync(dev)                                # nothing of the communicators is in flight on any rank (the
+            for m in models:                          # all-reduce inside xgmi_probation ordered the ranks)
+                if getattr(m, "_oneshot", None) is not None:
+                    m._oneshot.close()                # md_ar_destroy: registered buffers, signal area, IPC mappings
                 m._oneshot = None                     # Transformer._reduce_add_norm / _reduce fall back to RCCL
             clear_graphs(engine)
             if draft is not None:
                 clear_graphs(draft)
-            ar_selection += " -- DROPPED after a time-out in the first graph-replayed steps: every rank runs rccl"
+            ar_selection += f" -- DROPPED in probation ({ar_probation['why']}): every rank runs rccl"
             if rank == 0:
-                print("[collectives_us] xGMI all-reduce timed out during probation: every rank drops to RCCL",
-                      file=sys.stderr, flush=True)
+                print(f"[collectives_us] xGMI all-reduce dropped in probation ({ar_probation['why']}): every rank drops "
+                      "to RCCL", file=sys.stderr, flush=True)
             prime()
 
     gen = torch.Generator(device=dev if on_gpu else "cpu").manual_seed(2024)
@@ -538,6 +572,13 @@ def run(args, dev):
     if want_pmc and on_gpu and rank == 0:
         traffic, traffic_source = measure_traffic(B, S + 40 + G + 1, KH_loc, H_loc, D, G + 1, args.kv_dtype == "fp8",
                                                   kv_layout == "HND")
+    # the same kernel on the OTHER page layout, stand-alone: the line says which layout the headline
+    # ran and what the reference's own layout (NHD) would give
+    other = "NHD" if kv_layout == "HND" else "HND"
+    roofline_other = None
+    if on_gpu and rank == 0 and args.workload.startswith("cfg") and os.environ.get("MAGICDEC_BENCH_LAYOUT_AB", "1") != "0":
+        roofline_other = layout_roofline(engine, timer, B, G + 1, L_kv, H_loc, KH_loc, D, args.kv_dtype == "fp8", other,
+                                         attn_bytes, dev)
     ar_timeouts = None
     if use_tp:
         ars = [m._oneshot for m in ([engine.model] + ([draft.model] if draft is not None else []))
@@ -545,7 +586,12 @@ def run(args, dev):
         ar_timeouts = sum(a.status() for a in ars) if ars else None      # must be 0: a time-out invalidates the run
     line = {
         "metric": "decode tokens/s/node + speedup vs autoregressive, Llama-3.1-8B B=64 prefix=16K",
-        "value": round(value, 2), "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "value": round(value, 2), "unit": "tokens/s", "n_gpus": world,
+        # the group size the collective backend itself reports (RCCL under "nccl"): a multi-GPU record whose ranks did not
+        # form ONE communicator would show here, not only in n_gpus (= WORLD_SIZE)
+        "rccl_ranks": (dist.get_world_size(group) if (use_tp and group is not None) else 1),
+        "collective_backend": (dist.get_backend(group) if (use_tp and group is not None) else None),
+        "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(dt_replay / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong",
         "vs_baseline": None, "dtype": "bf16", "kv_cache_dtype": args.kv_dtype, "kv_cache_layout": kv_layout,
         "data": "synthetic",
@@ -572,6 +618,7 @@ def run(args, dev):
                    "allreduce": (None if not use_tp else
                                  "oneshot-ipc" if getattr(engine.model, "_oneshot", None) is not None else "rccl"),
                    "allreduce_selection": ar_selection,
+                   "allreduce_probation": ar_probation,
                    "allreduce_timeouts": ar_timeouts,
                    "allreduce_plan": allreduce_plan(engine, draft, B, G, len(rank_group),
                                                     1 if replicate_draft else len(draft_ranks)) if use_tp
@@ -619,6 +666,11 @@ def run(args, dev):
                                "(hipExtLaunchKernel start/stop events on the launching stream) = the duration a "
                                "rocprofv3 kernel trace reports"},
     }
+    line["roofline"]["kv_cache_layout"] = kv_layout
+    if roofline_other is not None:
+        line["roofline_" + other.lower()] = roofline_other
+    if kv_layout == "NHD":
+        line["roofline_nhd"] = dict(line["roofline"])       # the headline itself ran the reference's layout
     if rank == 0 and not args.no_cpu_baseline and world == 1 and not selfspec:
         line["cpu_baseline"] = cpu_baseline(tgt_name, drf_name, S, BUDGET, G, args.alpha)
     if coll_report is not None and rank == 0:
@@ -627,6 +679,113 @@ def run(args, dev):
         dist.barrier()
         dist.destroy_process_group()
     return line if rank == 0 else None
+
+
+def xgmi_probation(models, dev, rounds=4):
+    """Probation of the xGMI all-reduce inside the run's OWN processes, communicators and hipGraphs (rounds 5-6).  The
+    children validated the kernels on these links (collective_microbench), try_create self-tested them eagerly at load and
+    prime() has replayed every captured step variant once with them inside.  Two checks, one collective decision:
+      * time-outs: any rank whose status word is set (a bounded spin gave up, output rows poisoned);
+      * numerics: a short BIT-EXACT stress on each model's own communicator -- `rounds` x 6 all-reduces of the
+        run's message sizes, algorithms interleaved, queued back to back, against the rank-ordered fp32 sum of the
+        RCCL-all-gathered inputs (the kernels' definition).  A stale read that rounds differently would otherwise corrupt
+        tokens silently while the timings still looked valid.
+    Returns {"drop": bool, "why": str, "status": [...], "mismatched_elements": n, "calls": n} -- identical on every rank
+    (max-reduced), so that all ranks drop to RCCL at this common point or none does."""
+    from magicdec_amd.Engine import oneshot
+    ars = [m._oneshot for m in models if getattr(m, "_oneshot", None) is not None]
+    status = [a.status() for a in ars]
+    mism = calls = 0
+    algos = (oneshot.ALGO_ONESHOT, oneshot.ALGO_TWOSHOT, oneshot.ALGO_AUTO)
+    for ai, ar in enumerate(ars):
+        dim = models[ai].tok_embeddings.weight.shape[1]
+        sizes = [n for n in (64 * dim, 256 * dim, 2048) if n * 2 <= ar.max_bytes]
+        gen = torch.Generator(device=dev).manual_seed(9100 + 17 * ai + ar.rank)
+        for rnd in range(rounds):
+            xs, wants = [], []
+            for j in range(6):
+                n = sizes[(rnd + j) % len(sizes)]
+                x = (torch.randn(n, device=dev, generator=gen, dtype=torch.float32) * 3).to(torch.bfloat16)
+                if dist.get_backend(ar.group) == "nccl":
+                    parts = [torch.empty_like(x) for _ in range(ar.world)]
+                    dist.all_gather(parts, x, group=ar.group)
+                else:                             # gloo (ranks sharing one GPU): all_gather takes host tensors only
+                    host = [torch.empty(n, dtype=torch.bfloat16) for _ in range(ar.world)]
+                    dist.all_gather(host, x.cpu(), group=ar.group)
+                    parts = [h.to(dev) for h in host]
+                acc = parts[0].float()
+                for r in range(1, ar.world):
+                    acc = acc + parts[r].float()
+                xs.append(x)
+                wants.append(acc.to(torch.bfloat16))
+            torch.cuda.synchronize()
+            dist.barrier(group=ar.group)
+            for j, x in enumerate(xs):
+                ar.all_reduce_(x, algos[(rnd + j) % 3])
+            torch.cuda.synchronize()
+            for x, w_ in zip(xs, wants):
+                mism += int((x.view(torch.int16) != w_.view(torch.int16)).sum())
+                calls += 1
+        status[ai] = max(status[ai], ar.status())
+    t = torch.tensor([max(status) if status else 0, mism], dtype=torch.int64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    timed_out, bad_bits = int(t[0]) != 0, int(t[1]) != 0
+    why = "; ".join(w for w, on in (("a peer time-out in the first graph-replayed steps or the stress", timed_out),
+                                    ("the bit-exact stress on the run's own communicator mismatched", bad_bits)) if on)
+    return {"drop": timed_out or bad_bits, "why": why or "passed", "status_this_rank": status,
+            "status_max_over_ranks": int(t[0]), "mismatched_elements_max_over_ranks": int(t[1]), "calls": calls}
+
+
+def layout_roofline(engine, timer, B, n, L_kv, H, KH, D, fp8, layout, attn_bytes, dev, launches=24):
+    """The verify-attention launch of this run's shard shape on pages of `layout`, timed like `roofline` (the kernel's own
+    begin / end timestamps, md_debug_attn_timing) on TWO scratch layer caches of random values used alternately (2 x 4.2 GB at
+    cfg3: Infinity-Cache cold, like consecutive layers of the run) with the page table of a request that holds L_kv rows.
+    Reported beside `roofline` so that the driver record carries both the Engine default (HND) and the layout the
+    reference's flashinfer plan uses (NHD, Engine/SnapKV/backend.py:30) -- same kernel, bit-identical outputs
+    (tests/test_gpu_hnd.py).  Returns the roofline-shaped dict, or {"error": ...} when the scratch caches do not fit."""
+    from magicdec_amd import ops
+    mp = (L_kv + 127) // 128
+    try:
+        free = torch.cuda.mem_get_info(dev)[0]
+        need = 2 * B * mp * 2 * 128 * KH * D * (1 if fp8 else 2)
+        if need + (4 << 30) > free:
+            return {"error": f"scratch caches need {need >> 20} MiB, {free >> 20} MiB free"}
+        g = torch.Generator(device=dev).manual_seed(77)
+        shape = (B * mp, 2, KH, 128, D) if layout == "HND" else (B * mp, 2, 128, KH, D)
+        caches = []
+        for _ in range(2):
+            c = torch.empty(shape, device=dev, dtype=torch.bfloat16)
+            c.normal_(generator=g)
+            caches.append(c.to(ops.FP8_DTYPE) if fp8 else c)
+        scales = (torch.full((KH,), 0.5, device=dev), torch.full((KH,), 0.25, device=dev)) if fp8 else None
+        q = torch.randn(B * n, H, D, device=dev, generator=g, dtype=torch.float32).to(torch.bfloat16)
+        indices = torch.arange(B * mp, dtype=torch.int32, device=dev)
+        indptr = torch.arange(B + 1, dtype=torch.int32, device=dev) * mp
+        last = torch.full((B,), L_kv - (mp - 1) * 128, dtype=torch.int32, device=dev)
+        qo = torch.arange(B + 1, dtype=torch.int32, device=dev) * n
+        ws = engine.model.workspace
+        for i in range(4):
+            ops.paged_attention(q, caches[i % 2], qo, indices, indptr, last, n, mp, ws, kv_scales=scales, kv_layout=layout)
+        _sync(dev)
+        timer.clear()
+        timer.enabled = True
+        for i in range(launches):
+            ops.paged_attention(q, caches[i % 2], qo, indices, indptr, last, n, mp, ws, kv_scales=scales, kv_layout=layout)
+        _sync(dev)
+        timer.enabled = False
+        ms, cnt = timer.mean_ms(), len(timer.ms)
+        timer.clear()
+        del caches
+        torch.cuda.empty_cache()
+    except RuntimeError as e:                 # out of memory on a shape this helper was not sized for
+        timer.enabled = False
+        return {"error": f"{type(e).__name__}: {str(e)[:120]}"}
+    achieved = attn_bytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+    return {"kernel": f"paged_attn_kernel<{D},...> (verify attention, md_paged_attn, {layout} pages; stand-alone launches at "
+                      f"this run's shard shape, kv length {L_kv})",
+            "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "bytes_per_launch": attn_bytes,
+            "avg_launch_ms": round(ms, 4), "launches_timed": cnt}
 
 
 def speedup_condition(speedup_by_alpha, alpha, targets=(1.0, 1.8)):
@@ -721,30 +880,53 @@ def collective_microbench_isolated(shapes, iters=30, timeout_s=120, dry=False):
 
 
 def xgmi_verdict(report):
-    """(use the xGMI all-reduce for this run?, why) from the children's collectives_us report: only if every shape was
-    measured with the xGMI kernels validated against RCCL (try_create's self-test inside the child), no child failed or
-    timed out, no kernel spin timed out, and the fused all-reduce + add + RMSNorm beat RCCL + the add+norm launch on the
-    verify message."""
+    """(collective of this run, why) from the children's collectives_us report, collective in {"wt", "fence", None}:
+    "wt" = the xGMI fused all-reduce with the write-through publish, "fence" = the same kernels with the release-fence
+    publish (MAGICDEC_AR_PUBLISH=fence), None = RCCL.  An arm qualifies only if every shape was measured with the xGMI
+    kernels validated against RCCL (try_create's self-test inside the child), no child failed or timed out, no kernel spin
+    timed out, ITS bit-exact stress passed, and its fused all-reduce + add + RMSNorm beat RCCL + the add+norm launch on the
+    verify message.  The write-through arm is preferred (it is the faster one); when its stress fails -- the one hardware
+    assumption it rests on does not hold on these links -- the fence arm is still eligible (VERDICT r5 weak #10)."""
     if not isinstance(report, dict) or not report:
-        return False, "no report"
+        return None, "no report"
     if "error" in report or "rank0_child" in report:
-        return False, "a child process failed: " + str(report.get("error") or report.get("rank0_child"))[:160]
-    stress = report.get("xgmi_stress")
-    if not isinstance(stress, dict) or stress.get("mismatched_elements_all_ranks", 1) != 0 or \
-            stress.get("timeouts_all_ranks", 1) != 0 or stress.get("calls", 0) < 100:
-        return False, f"the bit-exact stress of the xGMI kernels did not pass ({stress})"
+        return None, "a child process failed: " + str(report.get("error") or report.get("rank0_child"))[:160]
+    meta = ("xgmi_stress", "xgmi_fence_stress")
     for name, r in report.items():
-        if name == "xgmi_stress":
+        if name in meta:
             continue
         if not isinstance(r, dict) or "xgmi_fused_add_rmsnorm_auto" not in r:
-            return False, f"xGMI kernels unavailable for '{name}' (set-up or self-test against RCCL failed)"
-        if r.get("xgmi_timeouts", 1) != 0:
-            return False, f"an xGMI kernel timed out waiting for a peer on '{name}'"
+            return None, f"xGMI kernels unavailable for '{name}' (set-up or self-test against RCCL failed)"
     v = report.get("verify")
     if v is None:
-        return False, "no verify message in the report"
-    a, b = v["xgmi_fused_add_rmsnorm_auto"], v["rccl_allreduce_then_add_rmsnorm"]
-    return (a < b), f"verify message: xgmi fused {a} us vs rccl + add+norm {b} us"
+        return None, "no verify message in the report"
+
+    def passed(st):
+        return (isinstance(st, dict) and st.get("mismatched_elements_all_ranks", 1) == 0
+                and st.get("timeouts_all_ranks", 1) == 0 and st.get("calls", 0) >= 100)
+    b = v["rccl_allreduce_then_add_rmsnorm"]
+    why = []
+    wt_ok = passed(report.get("xgmi_stress")) and all(r.get("xgmi_timeouts", 1) == 0 for n, r in report.items()
+                                                      if n not in meta)
+    if wt_ok:
+        a = v["xgmi_fused_add_rmsnorm_auto"]
+        if a < b:
+            return "wt", f"verify message: xgmi fused {a} us vs rccl + add+norm {b} us"
+        why.append(f"write-through arm slower than rccl on the verify message ({a} vs {b} us)")
+    else:
+        why.append(f"the write-through arm did not pass (stress {report.get('xgmi_stress')}, or a spin timed out)")
+    # the fence arm: its stress ran AFTER the write-through one on the same communicator, and the status word is sticky --
+    # a time-out there is only attributable to the fence arm if the first stress ended clean
+    st_f = report.get("xgmi_fence_stress")
+    wt_clean_status = isinstance(report.get("xgmi_stress"), dict) and report["xgmi_stress"].get("timeouts_all_ranks", 1) == 0
+    if passed(st_f) and wt_clean_status and "xgmi_fence_fused_add_rmsnorm_auto" in v:
+        a = v["xgmi_fence_fused_add_rmsnorm_auto"]
+        if a < b:
+            return "fence", f"{why[0]}; fence-publish arm on the verify message: {a} us vs rccl + add+norm {b} us"
+        why.append(f"fence arm slower than rccl on the verify message ({a} vs {b} us)")
+    else:
+        why.append(f"the fence arm did not pass either ({st_f})")
+    return None, "; ".join(why)
 
 
 def collective_microbench(group, shapes, dev, iters=30):
@@ -786,6 +968,11 @@ def collective_microbench(group, shapes, dev, iters=30):
             r["xgmi_oneshot"] = timed(lambda: ar.all_reduce_(buf, oneshot.ALGO_ONESHOT))
             r["xgmi_twoshot"] = timed(lambda: ar.all_reduce_(buf, oneshot.ALGO_TWOSHOT))
             r["xgmi_fused_add_rmsnorm_auto"] = timed(lambda: ar.all_reduce_add_rmsnorm(x, res, w, 1e-5))
+            # third arm (round 6): the same fused kernel with the RELEASE-FENCE publish (md_ar_set_publish) -- what a
+            # run degrades to if the write-through hand-off fails its stress on real links
+            ar.set_publish(oneshot.PUBLISH_FENCE)
+            r["xgmi_fence_fused_add_rmsnorm_auto"] = timed(lambda: ar.all_reduce_add_rmsnorm(x, res, w, 1e-5))
+            ar.set_publish(oneshot.PUBLISH_WRITE_THROUGH)
             r["xgmi_timeouts"] = ar.status()
         else:
             r["xgmi"] = "unavailable (set-up or self-test against RCCL failed on some rank)"
@@ -800,36 +987,44 @@ def collective_microbench(group, shapes, dev, iters=30):
         sizes = sorted({rows * dim for _, rows, dim in shapes} | {2048})
         algos = (oneshot.ALGO_ONESHOT, oneshot.ALGO_TWOSHOT, oneshot.ALGO_AUTO)
         world, rk = dist.get_world_size(group), dist.get_rank(group)
-        mism = calls = 0
-        gen = torch.Generator(device=dev).manual_seed(4321 + rk)
-        for rnd in range(40):
-            xs, wants = [], []
-            for j in range(16):
-                n = sizes[(rnd + j) % len(sizes)]
-                x = (torch.randn(n, device=dev, generator=gen, dtype=torch.float32) * 3).to(torch.bfloat16)
-                if dist.get_backend(group) == "nccl":
-                    parts = [torch.empty_like(x) for _ in range(world)]
-                    dist.all_gather(parts, x, group=group)
-                else:                         # gloo (the shared-GPU test): all_gather takes host tensors only
-                    host = [torch.empty(n, dtype=torch.bfloat16) for _ in range(world)]
-                    dist.all_gather(host, x.cpu(), group=group)
-                    parts = [h.to(dev) for h in host]
-                acc = parts[0].float()
-                for r in range(1, world):
-                    acc = acc + parts[r].float()
-                xs.append(x)
-                wants.append(acc.to(torch.bfloat16))
-            torch.cuda.synchronize()
-            dist.barrier(group=group)
-            for j, x in enumerate(xs):
-                ar.all_reduce_(x, algos[(rnd + j) % 3])
-            torch.cuda.synchronize()
-            for x, w_ in zip(xs, wants):
-                mism += int((x.view(torch.int16) != w_.view(torch.int16)).sum())
-                calls += 1
-        t = torch.tensor([mism, ar.status()], dtype=torch.int64, device=dev)
-        dist.all_reduce(t, group=group)
-        out["xgmi_stress"] = {"calls": calls, "mismatched_elements_all_ranks": int(t[0]), "timeouts_all_ranks": int(t[1])}
+
+        def stress(rounds, seed):
+            mism = calls = 0
+            gen = torch.Generator(device=dev).manual_seed(seed + rk)
+            for rnd in range(rounds):
+                xs, wants = [], []
+                for j in range(16):
+                    n = sizes[(rnd + j) % len(sizes)]
+                    x = (torch.randn(n, device=dev, generator=gen, dtype=torch.float32) * 3).to(torch.bfloat16)
+                    if dist.get_backend(group) == "nccl":
+                        parts = [torch.empty_like(x) for _ in range(world)]
+                        dist.all_gather(parts, x, group=group)
+                    else:                         # gloo (the shared-GPU test): all_gather takes host tensors only
+                        host = [torch.empty(n, dtype=torch.bfloat16) for _ in range(world)]
+                        dist.all_gather(host, x.cpu(), group=group)
+                        parts = [h.to(dev) for h in host]
+                    acc = parts[0].float()
+                    for r in range(1, world):
+                        acc = acc + parts[r].float()
+                    xs.append(x)
+                    wants.append(acc.to(torch.bfloat16))
+                torch.cuda.synchronize()
+                dist.barrier(group=group)
+                for j, x in enumerate(xs):
+                    ar.all_reduce_(x, algos[(rnd + j) % 3])
+                torch.cuda.synchronize()
+                for x, w_ in zip(xs, wants):
+                    mism += int((x.view(torch.int16) != w_.view(torch.int16)).sum())
+                    calls += 1
+            t = torch.tensor([mism, ar.status()], dtype=torch.int64, device=dev)
+            dist.all_reduce(t, group=group)
+            return {"calls": calls, "mismatched_elements_all_ranks": int(t[0]), "timeouts_all_ranks": int(t[1])}
+
+        out["xgmi_stress"] = stress(40, 4321)
+        # the fence arm's own stress (status is sticky: only meaningful while the first arm left it at 0)
+        ar.set_publish(oneshot.PUBLISH_FENCE)
+        out["xgmi_fence_stress"] = stress(20, 8765)
+        ar.set_publish(oneshot.PUBLISH_WRITE_THROUGH)
         ar.close()
     return out
 

@@ -414,12 +414,21 @@ int md_accept_rollback(int64_t* tokens_buffer, const int64_t* target_tokens, int
  * never papered over (two-shot: the rows the timed-out rank owns are NaN in every rank's output); the host reads the
  * status word with every iteration's flag read (md_ar_status_async: a 4-byte copy into pinned host memory queued on
  * `stream`, valid after the stream is synchronised) and raises.
+ * md_ar_set_publish: how a rank makes its partial visible to its peers before it raises their flags --
+ *   MD_AR_PUBLISH_WRITE_THROUGH (default): 16-byte system-scope write-through stores drained by every wave (fast; rests
+ *        on a write-through store being peer-visible when it retires);
+ *   MD_AR_PUBLISH_FENCE: the same stores followed by the memory model's system-scope release fence (L2 write-back)
+ *        before the flags -- slower per hop, assumes nothing beyond the documented model; the fallback arm a multi-GPU
+ *        run selects when the write-through arm fails its bit-exact stress on real links (bench.py collectives_us,
+ *        MAGICDEC_AR_PUBLISH=fence).  Every rank of a communicator must use the same mode; takes effect at the next call.
  * ---------------------------------------------------------------------- */
 #define MD_AR_HANDLE_BYTES 64
 #define MD_AR_MAX_RANKS 8
 #define MD_AR_ALGO_AUTO 0
 #define MD_AR_ALGO_ONESHOT 1
 #define MD_AR_ALGO_TWOSHOT 2
+#define MD_AR_PUBLISH_WRITE_THROUGH 0
+#define MD_AR_PUBLISH_FENCE 1
 typedef struct md_ar_comm md_ar_comm;
 int md_ar_create(int rank, int world, size_t max_bytes, md_ar_comm** comm_out);
 int md_ar_get_handles(md_ar_comm* comm, void* handles_host /* 2 * MD_AR_HANDLE_BYTES */);
@@ -428,6 +437,7 @@ int md_allreduce(md_ar_comm* comm, const void* in, void* out, size_t count, int 
 int md_allreduce_oneshot(md_ar_comm* comm, const void* in, void* out, size_t count, md_stream_t stream);
 int md_allreduce_add_rmsnorm(md_ar_comm* comm, const void* partial, const void* resid, const void* weight,
                              void* out_h, void* out_y, int rows, int dim, float eps, int algo, md_stream_t stream);
+int md_ar_set_publish(md_ar_comm* comm, int mode);
 int md_ar_status(md_ar_comm* comm, int* status_host);
 int md_ar_status_async(md_ar_comm* comm, int* status_host_pinned, md_stream_t stream);
 int md_ar_destroy(md_ar_comm* comm);

@@ -135,7 +135,7 @@ def use_fused(M: int, N: int, K: int, kind: str = "plain", absorbs_norm: bool = 
     if kind == "swiglu":
         return N * K * 2 <= FUSED_M256_SWIGLU_MAX_BYTES and K <= FUSED_MAX_K
     if kind in ("plain", "resid"):
-        return N * K * 2 <= FUSED_M256_NARROW_MAX_BYTES
+        return N * K * 2 <= FUSED_M256_NARROW_MAX_BYTES and K <= FUSED_MAX_K      # measured at K = 512 only
     return kind == "qkv" and l2_bytes <= FUSED_QKV_M256_MAX_L2_BYTES and K <= FUSED_MAX_K
 
 

@@ -30,6 +30,17 @@ from .._lib import check
 HANDLE_BYTES = 64           # MD_AR_HANDLE_BYTES
 DEFAULT_MAX_BYTES = 4 << 20
 ALGO_AUTO, ALGO_ONESHOT, ALGO_TWOSHOT = 0, 1, 2      # MD_AR_ALGO_*
+PUBLISH_WRITE_THROUGH, PUBLISH_FENCE = 0, 1          # MD_AR_PUBLISH_*
+
+
+def publish_mode_from_env() -> int:
+    """MAGICDEC_AR_PUBLISH=fence: the release-fence publish (include/magicdec_hip.h, md_ar_set_publish) -- the arm a
+    multi-GPU run falls back to when the write-through hand-off fails its bit-exact stress on real links (bench.py);
+    unset / "wt": the write-through publish."""
+    v = os.environ.get("MAGICDEC_AR_PUBLISH", "wt").lower()
+    if v not in ("wt", "write_through", "fence"):
+        raise ValueError(f"MAGICDEC_AR_PUBLISH must be 'wt' or 'fence', got '{v}'")
+    return PUBLISH_FENCE if v == "fence" else PUBLISH_WRITE_THROUGH
 
 
 class AllReduceTimeout(RuntimeError):
@@ -98,6 +109,8 @@ class OneShotAllReduce:
         comm = ctypes.c_void_p()
         check(self.lib.md_ar_create(self.rank, self.world, self.max_bytes, ctypes.byref(comm)), "md_ar_create")
         self.comm = comm
+        self.publish = PUBLISH_WRITE_THROUGH
+        self.set_publish(publish_mode_from_env())
         mine = ctypes.create_string_buffer(2 * HANDLE_BYTES)
         check(self.lib.md_ar_get_handles(self.comm, mine), "md_ar_get_handles")
         self._mine = mine.raw
@@ -110,6 +123,12 @@ class OneShotAllReduce:
         blob = b"".join(gathered)
         assert len(blob) == 2 * HANDLE_BYTES * self.world
         check(self.lib.md_ar_open_peers(self.comm, ctypes.create_string_buffer(blob, len(blob))), "md_ar_open_peers")
+
+    def set_publish(self, mode: int):
+        """PUBLISH_WRITE_THROUGH | PUBLISH_FENCE; every rank of the group must choose the same (it is part of the
+        protocol's timing, not of its data layout, so a mixed group would still be correct -- only slower on one side)."""
+        check(self.lib.md_ar_set_publish(self.comm, int(mode)), "md_ar_set_publish")
+        self.publish = int(mode)
 
     def fits(self, t: torch.Tensor) -> bool:
         return (t.is_cuda and t.dtype == torch.bfloat16 and t.is_contiguous() and t.numel() % 8 == 0

@@ -11,7 +11,7 @@ from ctypes import c_char_p, c_double, c_float, c_int, c_int64, c_size_t, c_void
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmagicdec_hip.so")
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 _lib = None
 _err = None
@@ -54,6 +54,7 @@ _SIGNATURES = {
     "md_allreduce_oneshot": (c_int, [P, P, P, c_size_t, P]),
     "md_allreduce": (c_int, [P, P, P, c_size_t, I, P]),
     "md_allreduce_add_rmsnorm": (c_int, [P, P, P, P, P, P, I, I, c_float, I, P]),
+    "md_ar_set_publish": (c_int, [P, I]),
     "md_ar_status": (c_int, [P, P]),
     "md_ar_status_async": (c_int, [P, P, P]),
     "md_ar_destroy": (c_int, [P]),

@@ -73,6 +73,7 @@ struct ArDev {
     uint32_t* ctrl;            // owner only, cached: [0] call counter, [1] blocks of the running call that have read it
     int rank, world;
     size_t buf_elems;          // elements per half buffer
+    int publish_fence;         // MD_AR_PUBLISH_FENCE: a system-scope release fence behind the write-through stores
 };
 
 struct ArArgs {
@@ -106,6 +107,18 @@ __device__ __forceinline__ void store_wt(bf16_t* base, size_t vec_index, const u
     asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
 }
 __device__ __forceinline__ void drain_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+// MD_AR_PUBLISH_FENCE (round 6; ADVICE r4 / VERDICT r5 weak #10): the write-through publish above rests on ONE hardware
+// property that no single-GPU test can probe -- that vmcnt retires an `sc0 sc1` store only once a PEER can see it.  In
+// this mode the flag-raising lanes additionally execute the system-scope RELEASE fence of rounds 2-3 (buffer_wbl2 sc0 sc1
+// + s_waitcnt: the AMDGPU memory model's own release sequence, which writes back whatever this XCD's L2 still holds)
+// between the block barrier that follows every wave's drain and the flag stores.  It costs the L2 write-back sweep
+// (1.7-6.5 us per hop by MI355X_MICROARCH.md) and assumes nothing beyond the documented memory model: if the
+// write-through arm fails its bit-exact stress on real links, a run degrades to THIS xGMI path, not all the way to RCCL.
+__device__ __forceinline__ void release_fence_system() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the compiler may drop the fence's own wait (guide: hazard)
+}
 
 __device__ __forceinline__ bool spin_ge(const uint32_t* p, uint32_t want) {
     const unsigned long long t0 = wall_clock64();
@@ -276,6 +289,7 @@ __global__ __launch_bounds__(kThreads) void allreduce_kernel(const ArDev c, cons
         __syncthreads();
         // 2. first hop
         if (tid < NR) {
+            if (c.publish_fence) release_fence_system();
             __hip_atomic_store(&c.sig[tid]->start[b][c.rank], k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             if (!spin_ge(&self->start[b][tid], k)) s_bad = 1;
         }
@@ -359,6 +373,7 @@ __global__ __launch_bounds__(kThreads) void allreduce_kernel(const ArDev c, cons
         __syncthreads();
         // 3b. second hop
         if (tid < NR) {
+            if (c.publish_fence) release_fence_system();
             __hip_atomic_store(&c.sig[tid]->start2[b][c.rank], k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             if (!spin_ge(&self->start2[b][tid], k)) s_bad = 1;
         }
@@ -437,6 +452,7 @@ extern "C" int md_ar_create(int rank, int world, size_t max_bytes, md_ar_comm** 
     c->dev.rank = rank;
     c->dev.world = world;
     c->dev.buf_elems = max_bytes / 2;
+    c->dev.publish_fence = 0;
     c->dev.data[rank] = (bf16_t*)c->my_data;
     c->dev.sig[rank] = (Signal*)c->my_sig;
     c->dev.ctrl = (uint32_t*)c->my_ctrl;
@@ -571,6 +587,14 @@ extern "C" int md_allreduce_add_rmsnorm(md_ar_comm* c, const void* partial, cons
     const int rc = run(c, a, algo, true, (hipStream_t)stream, "md_allreduce_add_rmsnorm");
     if (rc != MD_OK) return rc;
     MD_CHECK_LAUNCH("md_allreduce_add_rmsnorm");
+    return MD_OK;
+}
+
+extern "C" int md_ar_set_publish(md_ar_comm* c, int mode) {
+    MD_CHECK_ARG(c, "md_ar_set_publish: null communicator");
+    MD_CHECK_ARG(mode == MD_AR_PUBLISH_WRITE_THROUGH || mode == MD_AR_PUBLISH_FENCE,
+                 "md_ar_set_publish: mode must be MD_AR_PUBLISH_WRITE_THROUGH (0) or MD_AR_PUBLISH_FENCE (1), got %d", mode);
+    c->dev.publish_fence = mode == MD_AR_PUBLISH_FENCE ? 1 : 0;     // read by the next launch (passed by value)
     return MD_OK;
 }
 

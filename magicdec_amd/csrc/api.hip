@@ -13,5 +13,5 @@ void md_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
-extern "C" int md_abi_version(void) { return 9; }
+extern "C" int md_abi_version(void) { return 10; }
 extern "C" const char* md_last_error_string(void) { return g_err; }

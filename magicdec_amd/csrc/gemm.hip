@@ -418,7 +418,18 @@ SkinnyPlan plan_of(int ntiles, int K, bool allow_nw) {
     pl.nw = 4;
     pl.S = pick_splits((ntiles + 3) / 4, K);
     if (g_force_nw == 4 || !allow_nw) return pl;
-    constexpr int kCUs = 256;                       // MI355X (gfx950 is the only target of this library)
+    // compute units of the current device, queried once per device (a partitioned or smaller part must not be
+    // planned as 256 CUs); unknown -> keep the four-wave shape (results are bit-identical either way)
+    static int cus_of[16] = {0};
+    int devid = 0;
+    if (hipGetDevice(&devid) != hipSuccess || devid < 0 || devid >= 16) return pl;
+    if (cus_of[devid] == 0) {
+        int n = 0;
+        cus_of[devid] = (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, devid) == hipSuccess && n > 0)
+                            ? n : -1;
+    }
+    const int kCUs = cus_of[devid];
+    if (kCUs <= 0) return pl;
     auto load = [&](int nw) {                       // bytes of the most loaded CU over the mean (round-robin placement)
         const long wgs = (long)((ntiles + nw - 1) / nw) * pl.S;
         const long per_cu = (wgs + kCUs - 1) / kCUs;

@@ -152,7 +152,10 @@ __device__ __forceinline__ unsigned int tab_offsets2(unsigned int w, unsigned in
     const u16x2 av = *reinterpret_cast<const u16x2*>(&a);
     const u16x2 cl = __builtin_elementwise_min(av, lim);                   // v_pk_min_u16
     bad |= a ^ *reinterpret_cast<const unsigned int*>(&cl);                // a half beyond the last binade (or wrapped: tiny)
-    return (a << 4) | ((u >> 12) & 0x00080008u);                           // magnitude x 16 bytes + sign x 8 (< 2^16 per half)
+    // offsets from the CLAMPED magnitudes: an out-of-range half -- which the callers discard through `bad` --
+    // then points at the last table entry instead of carrying into its neighbour's half
+    const unsigned int c = *reinterpret_cast<const unsigned int*>(&cl);
+    return (c << 4) | ((u >> 12) & 0x00080008u);                           // magnitude x 16 bytes + sign x 8 (< 2^16 per half)
 }
 
 // (m, Z) <- merge of two partial softmax sums  sum exp(s - m)

@@ -11,13 +11,16 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_oneshot_allreduce_multiprocess_one_gpu(world):
-    port = 29640 + world
+@pytest.mark.parametrize("world,publish", [(2, "wt"), (3, "wt"), (2, "fence"), (3, "fence")])
+def test_oneshot_allreduce_multiprocess_one_gpu(world, publish):
+    """publish = "fence": the release-fence arm of the hand-off (md_ar_set_publish / MAGICDEC_AR_PUBLISH=fence, the fallback
+    a multi-GPU run selects when the write-through publish fails on real links) through the SAME worker: every size,
+    algorithm, fused form and graph replay bit-exact."""
+    port = 29640 + world + (10 if publish == "fence" else 0)
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                   HSA_ENABLE_IPC_MODE_LEGACY="0")
+                   HSA_ENABLE_IPC_MODE_LEGACY="0", MAGICDEC_AR_PUBLISH=publish)
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_ar_worker.py")], env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     outs = []
