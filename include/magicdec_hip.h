@@ -346,6 +346,26 @@ typedef struct md_fused_linear_args {
 int md_linear_fused_supported(int M, int N, int K, int epilogue);
 int md_linear_fused(const md_fused_linear_args* args, md_stream_t stream);
 
+/* md_linear_fused_split (round 6): the K8b tile kernel with the K range ALSO split over S workgroups, for the deep narrow
+ * products of a <= 64-row draft step (the 1B model's w2: N = 2048, K = 8192 -- Engine/SnapKV/model.py:451-455 followed by
+ * the residual add and the next RMSNorm, :260-278,464-469).  A workgroup owns a (32|64)-row x (32|64)-column tile and K / S
+ * of the depth, its 8 wavefronts K / (8 S) each -- at the 1B w2 that is 128 KB of W + 128 KB of x per CU, all requested
+ * by the first instructions of the launch; fp32 partial planes [S][M][N] go to `workspace` and a second launch adds them
+ * IN SLICE ORDER (deterministic) and applies the epilogue -- the combine launches of md_linear:
+ *   md_linear_fused_split              out = bf16(sum_s partial_s + bias)
+ *   md_linear_fused_split_add_rmsnorm  o as above; h_out = bf16(resid + o); y_out = rmsnorm(h) * norm_weight
+ *                                      -- bit-identical to md_linear_fused_split followed by md_add_rmsnorm.
+ * Shapes as md_linear_fused (M <= 256, K % 128 == 0, N % 32 == 0; bf16 weights in the streaming layout, not packed for
+ * SwiGLU); the add_rmsnorm form needs N % 8 == 0, N <= 8192.  workspace: md_linear_fused_split_workspace_bytes() bytes,
+ * 16-byte aligned. */
+size_t md_linear_fused_split_workspace_bytes(int M, int N, int K);
+int md_linear_fused_split(const void* x, int64_t ldx, const void* w_packed, const void* bias, void* out, int64_t ldo,
+                          int M, int N, int K, void* workspace, size_t workspace_bytes, md_stream_t stream);
+int md_linear_fused_split_add_rmsnorm(const void* x, int64_t ldx, const void* w_packed, const void* bias,
+                                      const void* resid, int64_t ldr, const void* norm_weight, float eps, void* h_out,
+                                      void* y_out, int M, int N, int K, void* workspace, size_t workspace_bytes,
+                                      md_stream_t stream);
+
 /* ------------------------------------------------------------------------
  * K10  argmax over a vocab shard / TP merge
  *     reference: Engine/SnapKV/model.py:175-188

@@ -30,6 +30,8 @@ void md_debug_set_gemm_waves(int nw);
 /* md_linear_fused: wavefronts (K slices) per workgroup, 8 | 16; 11 / 22 = 1 x 1 / 2 x 2 MFMA tiles per workgroup with 8 K
  * slices (bit-identical results); 0 = the measured rules */
 void md_debug_set_fused_nw(int nw);
+/* md_linear_fused_split: K slices over workgroups, forced where (K / 16) % (8 S) == 0; 0 = the rule (about one workgroup per CU) */
+void md_debug_set_fused_split(int S);
 /* md_linear_block: workgroups to aim for when K is split (0 = default 256); non-temporal weight DMA (1 = default) */
 void md_debug_set_block_gemm(int target_blocks, int weights_nontemporal);
 

@@ -110,14 +110,14 @@ def want_packed(N: int, K: int, swiglu: bool = False, int8: bool = False) -> boo
         return False
     if int8:
         return K % 128 == 0            # int8 rows are only streamed by md_linear, at every row count
-    if _MODE == "hip" or _BLOCK == "1" or _FUSED == "1":
+    if _MODE == "hip" or _BLOCK == "1" or _FUSED == "1" or _SPLIT == "1":
         return True
     kinds = ("swiglu",) if swiglu else ("plain", "resid", "qkv")
     for M in (1,) + tuple(range(32, 257, 32)):      # every 32-row tile count a rule can depend on
         if use_skinny(M, N, K, swiglu, False, True):
             return True
         for kind in kinds:
-            if use_block(M, N, K, kind) or use_fused(M, N, K, kind, absorbs_norm=True):
+            if use_block(M, N, K, kind) or use_fused(M, N, K, kind, absorbs_norm=True) or use_split(M, N, K, kind):
                 return True
     return False
 
@@ -152,6 +152,31 @@ def use_skinny(M: int, N: int, K: int, swiglu: bool, int8: bool, packed: bool) -
     if M <= 128:
         return nbytes >= MIN_STREAM_BYTES_M128
     return K >= 8192 and nbytes >= MIN_STREAM_BYTES_M128
+
+
+# round 6: md_linear_fused_split (csrc/tilegemm.hip, FL_PARTIAL) -- the tile kernel with K ALSO split over workgroups, for the
+# deep narrow output projections of a <= 128-row step whose combine launch is the residual add + RMSNorm launch anyway: the 1B
+# model's w2 (N = 2048, K = 8192, 33.5 MB), which every single-launch decomposition leaves per-CU-ingest-bound (fused tile
+# kernel 22-24 us, library 15.7 + 5 for the add + norm, md_linear 17 + 5).  Rule from tools/split_bench.py
+# (profiles/r06_split_ab.txt).
+SPLIT_MIN_K = 8192
+SPLIT_MAX_M = 128
+_SPLIT = os.environ.get("MAGICDEC_SPLIT", "auto")      # "0": never, "1": every output projection it supports
+
+
+def set_split(mode: str):
+    global _SPLIT
+    assert mode in ("auto", "0", "1")
+    _SPLIT = mode
+
+
+def use_split(M: int, N: int, K: int, kind: str) -> bool:
+    """md_linear_fused_split_add_rmsnorm for this output projection (kind "resid")?"""
+    if _MODE == "lib" or _SPLIT == "0" or kind != "resid" or M > 256 or K % 128 or N % 32 or N > 8192:
+        return False
+    if _SPLIT == "1":
+        return True
+    return M <= SPLIT_MAX_M and K >= SPLIT_MIN_K and N * K * 2 < MIN_STREAM_BYTES
 
 
 BLOCK_MIN_TILES = 160          # 128-column tiles that fill the chip without a K split (w1|w3: 224, lm head: 1002)

@@ -459,10 +459,15 @@ class Transformer(nn.Module):
             return h, ops.DeferredNorm(h, ssq, norm.weight, norm.eps)
         if group is None and inp.is_cuda and x.stride(-1) == 1:
             # the weight-streaming kernel's split-K combine launch also adds the residual and normalises
-            from .gemm_policy import choose
+            from .gemm_policy import choose, use_split
             w = lin.weight
             M, K = inp.shape
             pk = self._packed.get(id(w))
+            if (pk is not None and w.dtype == torch.bfloat16 and inp.stride(-1) == 1
+                    and use_split(M, w.shape[0], K, "resid") and ops.fused_split_supported(M, w.shape[0], K)):
+                # deep narrow projection of a draft step (the 1B w2): the tile kernel with K split over workgroups; its
+                # combine launch IS the residual add + RMSNorm launch (md_linear_fused_split_add_rmsnorm)
+                return ops.fused_split_linear_add_rmsnorm(inp, pk, x, norm.weight, norm.eps, lin.bias, self.workspace)
             how = choose(M, w.shape[0], K, False, w.dtype == torch.int8, pk is not None, "resid")
             if how == "block" and ops.linear_block_supported(M, w.shape[0], K) and inp.stride(-1) == 1:
                 # 129..256 rows: the block-tile GEMM, same combine launch (residual add + RMSNorm)

@@ -72,6 +72,9 @@ _SIGNATURES = {
     "md_linear_block_add_rmsnorm": (c_int, [P, L, P, P, P, L, P, c_float, P, P, I, I, I, P, c_size_t, P]),
     "md_linear_fused_supported": (c_int, [I, I, I, I]),
     "md_linear_fused": (c_int, [ctypes.POINTER(FusedLinearArgs), P]),
+    "md_linear_fused_split_workspace_bytes": (c_size_t, [I, I, I]),
+    "md_linear_fused_split": (c_int, [P, L, P, P, P, L, I, I, I, P, c_size_t, P]),
+    "md_linear_fused_split_add_rmsnorm": (c_int, [P, L, P, P, P, L, P, c_float, P, P, I, I, I, P, c_size_t, P]),
     "md_rmsnorm": (c_int, [P, P, P, I, I, c_float, P]),
     "md_add_rmsnorm": (c_int, [P, P, P, P, P, I, I, c_float, P]),
     "md_silu_mul": (c_int, [P, P, L, L, P, I, I, P]),
@@ -93,6 +96,7 @@ _DEV_SIGNATURES = {
     "md_debug_set_gemm_target_blocks": (None, [I]),
     "md_debug_set_gemm_waves": (None, [I]),
     "md_debug_set_fused_nw": (None, [I]),
+    "md_debug_set_fused_split": (None, [I]),
     "md_debug_set_block_gemm": (None, [I, I]),
 }
 DEV_SYMBOLS = tuple(_DEV_SIGNATURES)

@@ -60,7 +60,8 @@ constexpr int kKC = 128;                 // k depth of one activation chunk
 constexpr int kPitch = kKC * 2 + 16;     // LDS row pitch (272 B: consecutive rows start 4 banks apart)
 constexpr int kWaveLds = 32 * kPitch;    // wave-private activation image (8704 B >= the 4 KiB partial tile)
 
-enum { FL_NONE = 0, FL_SWIGLU = 1, FL_RESID = 2, FL_ROPE_APPEND = 3 };
+enum { FL_NONE = 0, FL_SWIGLU = 1, FL_RESID = 2, FL_ROPE_APPEND = 3,
+       FL_PARTIAL = 4 };      // internal: the K range is ALSO split over workgroups; fp32 partial tiles -> workspace
 
 struct KvTable {
     void* cache;
@@ -91,6 +92,9 @@ struct TileParams {
     const bf16_t* pro_w;      // PRO: RMSNorm weight [K]
     float pro_eps;
     int pro_tiles;
+    // FL_PARTIAL (md_linear_fused_split): S K-slices over workgroups, fp32 partial planes [S][M][N]
+    float* partial;
+    int S;
 };
 
 __device__ __forceinline__ float silu_bf16(float h1) {
@@ -162,13 +166,25 @@ __global__ __launch_bounds__(64 * NW, MT * NT > 1 ? 2 : 4) void tile_gemm_kernel
     // block id -> (weight tile group, M tile group): block b runs on XCD b % 8; the M groups of one weight tile group
     // stay on one XCD
     const int m_groups = (p.m_tiles + MT - 1) / MT, n_groups = p.n_tiles / NT;
-    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-    const int tng = (slot / m_groups) * 8 + xcd, tmg = slot % m_groups;
+    int tng, tmg, slice = 0;
+    if constexpr (EPI == FL_PARTIAL) {
+        // K slice in the FAST index: with S = 8 a slice -- i.e. the Kt columns of x it reads -- lives on one XCD's L2
+        // (block b runs on XCD b % 8), and the partial planes of a slice are written by one XCD
+        slice = blockIdx.x % p.S;
+        const int rest = blockIdx.x / p.S;
+        tmg = rest % m_groups;
+        tng = rest / m_groups;
+    } else {
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        tng = (slot / m_groups) * 8 + xcd;
+        tmg = slot % m_groups;
+    }
     if (tng >= n_groups) return;
     const int m0 = tmg * 32 * MT, tn0 = tng * NT;
 
-    const int ksteps_w = (p.K >> 4) / kNW;          // 16-deep MFMA k-steps of this wavefront's slice
-    const int ks0 = wave * ksteps_w;
+    // 16-deep MFMA k-steps of this wavefront's slice (FL_PARTIAL: of this workgroup's K slice, then of the wavefront)
+    const int ksteps_w = (p.K >> 4) / (kNW * (EPI == FL_PARTIAL ? p.S : 1));
+    const int ks0 = (slice * kNW + wave) * ksteps_w;
     const bf16_t* wbase[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
@@ -341,7 +357,13 @@ __global__ __launch_bounds__(64 * NW, MT * NT > 1 ? 2 : 4) void tile_gemm_kernel
             return s;
         };
 
-        if constexpr (EPI == FL_SWIGLU) {
+        if constexpr (EPI == FL_PARTIAL) {
+            // this workgroup's K slice of the tile, fp32, into plane `slice`: 16 lanes write one 128-B row segment
+            const f32x2 s = tile_sum2(2 * cp);
+            if (gm < p.M)
+                *reinterpret_cast<f32x2*>(p.partial + ((int64_t)slice * p.M + gm) * p.N + tn * 32 + 2 * cp) = s;
+            continue;
+        } else if constexpr (EPI == FL_SWIGLU) {
             const int I = p.N >> 1;
             const int i = tn * 16 + cp;
             const float h1 = bf16_to_f32(f32_to_bf16(tile_sum1(cp)));
@@ -477,7 +499,145 @@ int launch_tile(const TileParams& p, hipStream_t st) {
 
 bool aligned16(const void* q) { return ((uintptr_t)q & 15) == 0; }
 
+// ---- md_linear_fused_split: the tile kernel with the K range ALSO split over S workgroups (FL_PARTIAL) ----------------
+// Why (round 6): the deep narrow products of a 64-row draft step -- the 1B w2, N = 2048, K = 8192 -- are per-CU-ingest
+// bound on every single-launch decomposition (a workgroup that owns the whole K range re-reads a 32-row x 8192 slab of x
+// per 32 columns: 1 MB per CU, 22-24 us; hipBLASLt: 768 KB per CU, 15.7 us + 5 for the add + norm behind it) and
+// latency-bound on md_linear (4 waves x 8 KiB of W in flight per CU: 17 + 5).  A 64 x 64 tile x K / 8 per workgroup
+// ingests 128 KB of W + 128 KB of x, ALL of it requested in the first instructions of its 8 wavefronts (8 k-steps each:
+// the W ring and one activation chunk cover the whole slice), on every CU; the 4 MB of fp32 partial planes stay in L2 /
+// MALL for the combine launch, which is the launch that adds the residual and normalises anyway (reduce_add_rmsnorm,
+// elementwise.hip: the same launch md_linear_add_rmsnorm ends with, slices added in order -> deterministic).
+struct SplitPlan { int mt, nt, S; };
+int g_force_split = 0;       // dev knob (md_debug_set_fused_split): force S where the shape allows
+
+SplitPlan split_plan(int M, int N, int K) {
+    SplitPlan pl;
+    const int m_tiles = (M + 31) / 32, n_tiles = N / 32;
+    pl.mt = m_tiles >= 2 ? 2 : 1;
+    pl.nt = (n_tiles % 2 == 0 && n_tiles >= 16) ? 2 : 1;
+    const int groups = (n_tiles / pl.nt) * ((m_tiles + pl.mt - 1) / pl.mt);
+    const int ksteps = K >> 4;
+    int best = 1;
+    for (int S = 1; S <= 32; ++S) {                  // the smallest S that gives every CU a workgroup, 8 K-slices per
+        if (ksteps % (S * 8)) continue;              // workgroup (waves) x S workgroups must divide the k-steps
+        best = S;
+        if (groups * S >= 256) break;
+    }
+    pl.S = best;
+    if (g_force_split > 0 && ksteps % (g_force_split * 8) == 0) pl.S = g_force_split;
+    return pl;
+}
+
+template <int MT, int NT>
+int launch_split_cfg(const TileParams& p, hipStream_t st) {
+    constexpr int lds = 8 * MT * kWaveLds;
+    auto k = tile_gemm_kernel<FL_PARTIAL, false, 8, true, false, MT, NT>;
+    static MdPerDeviceOnce once;
+    if (once.first()) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds) !=
+            hipSuccess) {
+            once.undo();
+            md_set_error("md_linear_fused_split: hipFuncSetAttribute(%d B LDS) failed", lds);
+            return MD_ERR_LAUNCH;
+        }
+    }
+    const int m_groups = (p.m_tiles + MT - 1) / MT, n_groups = p.n_tiles / NT;
+    hipLaunchKernelGGL(k, dim3(n_groups * m_groups * p.S), dim3(512), lds, st, p);
+    return MD_OK;
+}
+
+int launch_split(const TileParams& p, const SplitPlan& pl, hipStream_t st) {
+    if (pl.mt == 2) return pl.nt == 2 ? launch_split_cfg<2, 2>(p, st) : launch_split_cfg<2, 1>(p, st);
+    return pl.nt == 2 ? launch_split_cfg<1, 2>(p, st) : launch_split_cfg<1, 1>(p, st);
+}
+
+int split_check(const char* who, const void* x, int64_t ldx, const void* w, int M, int N, int K, const void* ws,
+                size_t ws_bytes) {
+    MD_CHECK_ARG(x && w, "%s: null pointer argument", who);
+    MD_CHECK_ARG(M >= 1 && M <= 256 && K >= 128 && K % 128 == 0 && N >= 32 && N % 32 == 0,
+                 "%s: unsupported shape M=%d N=%d K=%d (need 1 <= M <= 256, K %% 128 == 0, N %% 32 == 0)", who, M, N, K);
+    MD_CHECK_ARG(aligned16(x) && aligned16(w) && ldx % 8 == 0, "%s: x / w must be 16-byte aligned, ldx %% 8 == 0", who);
+    MD_CHECK_ARG(ldx > 0 && ((int64_t)(M - 1) * ldx + K) * 2 < ((int64_t)1 << 32),
+                 "%s: x spans more than 4 GiB (M=%d, ldx=%lld)", who, M, (long long)ldx);
+    const SplitPlan pl = split_plan(M, N, K);
+    MD_CHECK_ARG(ws && aligned16(ws) && ws_bytes >= (size_t)pl.S * M * N * 4,
+                 "%s: workspace of %zu bytes needed (md_linear_fused_split_workspace_bytes), got %zu", who,
+                 (size_t)pl.S * M * N * 4, ws_bytes);
+    return MD_OK;
+}
+
+int split_main(const void* x, int64_t ldx, const void* w, int M, int N, int K, void* ws, hipStream_t st, int* S_out) {
+    const SplitPlan pl = split_plan(M, N, K);
+    TileParams p = {};
+    p.x = (const bf16_t*)x;
+    p.w = (const bf16_t*)w;
+    p.ldx = ldx;
+    p.M = M;
+    p.N = N;
+    p.K = K;
+    p.n_tiles = N / 32;
+    p.m_tiles = (M + 31) / 32;
+    p.partial = (float*)ws;
+    p.S = pl.S;
+    *S_out = pl.S;
+    return launch_split(p, pl, st);
+}
+
 }  // namespace
+
+// gemm.hip / elementwise.hip: the split-K combine launches shared with md_linear / md_linear_block
+int md_internal_launch_skinny_reduce(const float* partial, int S, int M, int N, int epilogue, const void* bias, void* out,
+                                     int64_t ldo, hipStream_t st);
+int md_internal_launch_reduce_add_rmsnorm(const float* partial, int S, int M, int N, const void* bias, const void* scales,
+                                          const void* x, int64_t ldx, const void* w, void* h_out, void* y, float eps,
+                                          hipStream_t st);
+
+#ifdef MD_DEV_KNOBS
+extern "C" void md_debug_set_fused_split(int S) { g_force_split = S > 0 ? S : 0; }
+#endif
+
+extern "C" size_t md_linear_fused_split_workspace_bytes(int M, int N, int K) {
+    if (M < 1 || M > 256 || K < 128 || K % 128 || N < 32 || N % 32) return 0;
+    return (size_t)split_plan(M, N, K).S * M * N * 4;
+}
+
+extern "C" int md_linear_fused_split(const void* x, int64_t ldx, const void* w_packed, const void* bias, void* out,
+                                     int64_t ldo, int M, int N, int K, void* workspace, size_t workspace_bytes,
+                                     md_stream_t stream) {
+    const int rc0 = split_check("md_linear_fused_split", x, ldx, w_packed, M, N, K, workspace, workspace_bytes);
+    if (rc0 != MD_OK) return rc0;
+    MD_CHECK_ARG(out && ((uintptr_t)out & 7) == 0 && ldo % 4 == 0, "md_linear_fused_split: out must be 8-byte aligned, ldo %% 4 == 0");
+    int S = 1;
+    int rc = split_main(x, ldx, w_packed, M, N, K, workspace, (hipStream_t)stream, &S);
+    if (rc != MD_OK) return rc;
+    rc = md_internal_launch_skinny_reduce((const float*)workspace, S, M, N, 0 /* EPI_NONE */, bias, out, ldo,
+                                          (hipStream_t)stream);
+    if (rc != MD_OK) return rc;
+    MD_CHECK_LAUNCH("md_linear_fused_split");
+    return MD_OK;
+}
+
+extern "C" int md_linear_fused_split_add_rmsnorm(const void* x, int64_t ldx, const void* w_packed, const void* bias,
+                                                 const void* resid, int64_t ldr, const void* norm_weight, float eps,
+                                                 void* h_out, void* y_out, int M, int N, int K, void* workspace,
+                                                 size_t workspace_bytes, md_stream_t stream) {
+    const int rc0 = split_check("md_linear_fused_split_add_rmsnorm", x, ldx, w_packed, M, N, K, workspace, workspace_bytes);
+    if (rc0 != MD_OK) return rc0;
+    MD_CHECK_ARG(resid && norm_weight && h_out && y_out, "md_linear_fused_split_add_rmsnorm: null pointer argument");
+    MD_CHECK_ARG(N % 8 == 0 && N <= 8192 && ldr % 8 == 0,
+                 "md_linear_fused_split_add_rmsnorm: N %% 8 == 0, N <= 8192 (a row is normalised by one workgroup), ldr %% 8 == 0");
+    MD_CHECK_ARG(aligned16(resid) && aligned16(norm_weight) && aligned16(h_out) && aligned16(y_out),
+                 "md_linear_fused_split_add_rmsnorm: resid / norm_weight / h_out / y_out must be 16-byte aligned");
+    int S = 1;
+    int rc = split_main(x, ldx, w_packed, M, N, K, workspace, (hipStream_t)stream, &S);
+    if (rc != MD_OK) return rc;
+    rc = md_internal_launch_reduce_add_rmsnorm((const float*)workspace, S, M, N, bias, nullptr, resid, ldr, norm_weight,
+                                               h_out, y_out, eps, (hipStream_t)stream);
+    if (rc != MD_OK) return rc;
+    MD_CHECK_LAUNCH("md_linear_fused_split_add_rmsnorm");
+    return MD_OK;
+}
 
 #ifdef MD_DEV_KNOBS
 extern "C" void md_debug_set_fused_nw(int nw) {

@@ -399,6 +399,58 @@ def linear_add_rmsnorm(x, weight, resid, norm_weight, eps, bias=None, scales=Non
     return h, y
 
 
+# ----------------------------------------------------------------------------- K8b, K split over workgroups
+def fused_split_supported(M, N, K):
+    """md_linear_fused_split takes this shape (M <= 256, K % 128 == 0, N % 32 == 0)."""
+    return 1 <= M <= 256 and K >= 128 and K % 128 == 0 and N >= 32 and N % 32 == 0
+
+
+def _split_ws(lib, M, N, K, workspace):
+    nbytes = lib.md_linear_fused_split_workspace_bytes(M, N, K)
+    if not nbytes or workspace is None:
+        raise ValueError("fused_split_linear: needs a workspace and a supported shape")
+    ws = workspace.get(nbytes + 256)
+    return ctypes.c_void_p(ws.data_ptr() + (-ws.data_ptr()) % 256), nbytes
+
+
+def fused_split_linear(x, weight: "PackedWeight", bias=None, workspace: "AttnWorkspace" = None):
+    """F.linear(x, W, bias) on the tile kernel with K also split over workgroups + the fixed-order combine launch
+    (md_linear_fused_split; csrc/tilegemm.hip)."""
+    _gpu(x, weight.data, bias)
+    if x.dim() != 2 or x.stride(1) != 1 or weight.swiglu:
+        raise ValueError("fused_split_linear expects a 2-D x with unit inner stride and a plain packed weight")
+    M, K = x.shape
+    N = weight.N
+    lib = _lib.load()
+    wsp, nbytes = _split_ws(lib, M, N, K, workspace)
+    out = torch.empty((M, N), dtype=x.dtype, device=x.device)
+    check(lib.md_linear_fused_split(_p(x), x.stride(0), _p(weight.data), _p(bias), _p(out), out.stride(0), M, N, K, wsp,
+                                    nbytes, _stream()), "md_linear_fused_split")
+    return out
+
+
+def fused_split_linear_add_rmsnorm(x, weight: "PackedWeight", resid, norm_weight, eps, bias=None,
+                                   workspace: "AttnWorkspace" = None):
+    """(h, y) = (resid + F.linear(x, W, bias), rmsnorm(h) * norm_weight): the split tile kernel + ONE combine launch that
+    adds the slices in order, the residual, and normalises (md_linear_fused_split_add_rmsnorm) -- bit-identical to
+    fused_split_linear() followed by add_rmsnorm()."""
+    _gpu(x, weight.data, bias, resid, norm_weight)
+    if x.dim() != 2 or x.stride(1) != 1 or resid.dim() != 2 or resid.stride(1) != 1 or weight.swiglu:
+        raise ValueError("fused_split_linear_add_rmsnorm expects 2-D x / resid with unit inner stride and a plain packed weight")
+    M, K = x.shape
+    N = weight.N
+    if resid.shape != (M, N) or norm_weight.numel() != N:
+        raise ValueError("fused_split_linear_add_rmsnorm: resid must be [M, N], norm_weight [N]")
+    lib = _lib.load()
+    wsp, nbytes = _split_ws(lib, M, N, K, workspace)
+    h = torch.empty((M, N), dtype=x.dtype, device=x.device)
+    y = torch.empty((M, N), dtype=x.dtype, device=x.device)
+    check(lib.md_linear_fused_split_add_rmsnorm(_p(x), x.stride(0), _p(weight.data), _p(bias), _p(resid), resid.stride(0),
+                                                _p(norm_weight), float(eps), _p(h), _p(y), M, N, K, wsp, nbytes, _stream()),
+          "md_linear_fused_split_add_rmsnorm")
+    return h, y
+
+
 # ----------------------------------------------------------------------------- K8c
 def linear_block_supported(M, N, K, swiglu=False):
     """True when md_linear_block (csrc/blockgemm.hip: the block-tile GEMM of the 129..256-row verify linears) takes

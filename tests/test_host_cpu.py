@@ -1288,7 +1288,15 @@ def test_gemm_policy_encodes_the_measured_ab_table():
         assert not g.skinny_absorbs_norm(65) and not g.skinny_absorbs_norm(128) and not g.skinny_absorbs_norm(256)
     # a streaming-layout copy only for weights some hand-written kernel can be chosen for
     assert g.want_packed(28672, 4096, True) and g.want_packed(4096, 14336) and g.want_packed(3072, 2048)
-    assert not g.want_packed(1024, 16384) and not g.want_packed(4100, 4096)
+    assert not g.want_packed(1000, 16384) and not g.want_packed(4100, 4096)
+    # round 6 (profiles/r06_split_ab.txt): the deep narrow output projection of a draft step -- the 1B w2 -- runs on the tile
+    # kernel with K split over workgroups (its combine launch is the add + norm launch); not the 8B w2 (a long stream:
+    # md_linear), not a verify-sized M, not a K <= 4096 projection (the single-launch fused kernel)
+    if os.environ.get("MAGICDEC_SPLIT", "auto") == "auto":
+        assert g.use_split(64, 2048, 8192, "resid") and g.use_split(128, 2048, 8192, "resid")
+        assert not g.use_split(64, 4096, 14336, "resid") and not g.use_split(256, 2048, 8192, "resid")
+        assert not g.use_split(64, 2048, 2048, "resid") and not g.use_split(64, 2048, 8192, "plain")
+        assert g.want_packed(2048, 8192)
     # autoregressive 8B steps (M = 64)
     assert c(64, 6144, 4096, "qkv") == "lib" and c(64, 4096, 4096, "resid") == "fused"
     assert c(64, 28672, 4096, "swiglu") == "skinny" and c(64, 4096, 14336, "resid") == "skinny"
