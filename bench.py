@@ -94,7 +94,7 @@ def parse(argv=None):
                          "verify-attention launch at this run's shard shape in a subprocess (tools/attn_bench.py); "
                          "default: on for the cfg* workloads on rank 0")
     ap.add_argument("--no-pmc", dest="pmc", action="store_false")
-    ap.add_argument("--weights", default="random", metavar="random|peaked[:emb_rms[:peak]]",
+    ap.add_argument("--weights", default="random", metavar="random|peaked[:emb_rms[:peak]][:miss=f]",
                     help="synthetic weights when no checkpoint exists on the box: 'random' = seeded normal(0, 0.02) "
                          "(acceptance ~0: `value` comes from the fixed-acceptance replay); 'peaked' = the same layers "
                          "with a dominant embedding and a head tied to it through a permutation (Engine/utils._peak_) "
@@ -534,6 +534,24 @@ def run(args, dev):
         dt_al, tok_al = run_spec(2, sens_steps, f_al)
         sens_raw[al] = (dt_al / sens_steps, tok_al / sens_steps)
 
+    # ---- measured acceptance at KNOWN draft quality: with `--weights peaked[...]` the draft's head is
+    # rewritten in place (Engine/utils.repeak_head_: same storage, so the captured graphs stay valid; the draft cache does not
+    # depend on the head) to mispredict a seeded fraction `miss` of the vocabulary, i.e. a draft whose per-step acceptance
+    # rate is ~1 - miss, and the SAME loop runs with the accept kernel's own decisions.  Each point sits beside the
+    # fixed-acceptance replay at alpha = 1 - miss: equal tokens/s there shows the replay is a timing-neutral stand-in.
+    acc_sweep = None
+    if weights.startswith("peaked") and draft is not None and hasattr(draft.model, "_peak_params"):
+        from magicdec_amd.Engine.utils import parse_peaked, repeak_head_
+        miss_cfg = parse_peaked(weights)[2]
+        acc_sweep = {}
+        for miss in (0.4, 0.3, 0.2):
+            if in_draft:
+                repeak_head_(draft.model, miss)
+            dt_m, tok_m = run_spec(2, sens_steps, None)
+            acc_sweep[miss] = (dt_m / sens_steps, tok_m / sens_steps)
+        if in_draft:
+            repeak_head_(draft.model, miss_cfg)
+
     # ---- autoregressive baseline (tests/baseline_benchmark.py loop: one token per target step)
     target_step = engine.verify if selfspec else engine.inference
     restore()
@@ -557,6 +575,8 @@ def run(args, dev):
         return float(t.item())
     dt_replay, dt_meas, dt_base = allmax(dt_replay), allmax(dt_meas), allmax(dt_base)
     sens_raw = {al: (allmax(dt), tok) for al, (dt, tok) in sens_raw.items()}
+    if acc_sweep is not None:
+        acc_sweep = {m: (allmax(dt), tok) for m, (dt, tok) in acc_sweep.items()}
 
     value = tok_replay / dt_replay
     base_tps = B * base_steps / dt_base
@@ -638,6 +658,9 @@ def run(args, dev):
                                     "speedup_vs_autoregressive": round(tok_meas / dt_meas / base_tps, 4),
                                     "ms_per_step": round(dt_meas / meas_steps * 1e3, 4),
                                     "weights": weights},
+        "measured_acceptance_sweep": (None if acc_sweep is None else {
+            f"miss={m:.1f}": acceptance_point(dt, tok, B, G, base_tps, sens_raw.get(round(1.0 - m, 1)))
+            for m, (dt, tok) in sorted(acc_sweep.items(), reverse=True)}),
         "prefill_s": round(t_pf, 2), "load_s": round(t_load, 2),
         # what "identical to the reference" means for this path (checked by `pytest -m gpu` and smoke(), not here)
         "parity": {"tokens": "identity with the CPU oracle; zero flips over 16 832 positions at the real layer widths and "
@@ -786,6 +809,35 @@ def layout_roofline(engine, timer, B, n, L_kv, H, KH, D, fp8, layout, attn_bytes
             "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "bytes_per_launch": attn_bytes,
             "avg_launch_ms": round(ms, 4), "launches_timed": cnt}
+
+
+def alpha_of(tokens_per_iter, gamma):
+    """The per-step acceptance rate a of a truncated-geometric draft with E[tokens / iteration] = sum_{j<=gamma} a^j."""
+    lo, hi = 0.0, 1.0
+    for _ in range(60):
+        mid = 0.5 * (lo + hi)
+        if sum(mid ** j for j in range(gamma + 1)) < tokens_per_iter:
+            lo = mid
+        else:
+            hi = mid
+    return 0.5 * (lo + hi)
+
+
+def acceptance_point(dt, tok, B, gamma, base_tps, replay):
+    """One point of measured_acceptance_sweep: the loop run with the accept kernel's own decisions on a draft of known
+    quality, and the fixed-acceptance replay (dt, tokens per step) at the matching alpha beside it."""
+    tpi = tok / B
+    out = {"tokens_per_s": round(tok / dt, 1), "ms_per_step": round(dt * 1e3, 3), "tokens_per_iter_per_seq": round(tpi, 3),
+           "accepted_drafts_per_drafted": round((tpi - 1) / gamma, 4),
+           "alpha_equivalent": round(alpha_of(tpi, gamma), 4),
+           "speedup_vs_autoregressive": round(tok / dt / base_tps, 3)}
+    if replay is not None:
+        rdt, rtok = replay
+        out["replay_at_matching_alpha"] = {"tokens_per_s": round(rtok / rdt, 1), "ms_per_step": round(rdt * 1e3, 3),
+                                           "tokens_per_iter_per_seq": round(rtok / B, 3)}
+        # the quantity the replay stands in for: time per iteration (tokens per iteration differ by sampling noise)
+        out["ms_per_step_vs_replay"] = round(dt / rdt, 4)
+    return out
 
 
 def speedup_condition(speedup_by_alpha, alpha, targets=(1.0, 1.8)):

@@ -32,6 +32,11 @@ void md_debug_set_gemm_waves(int nw);
 void md_debug_set_fused_nw(int nw);
 /* md_linear_fused_split: K slices over workgroups, forced where (K / 16) % (8 S) == 0; 0 = the rule (about one workgroup per CU) */
 void md_debug_set_fused_split(int S);
+/* md_linear_fused / md_linear_fused_split: phase timestamps.  buf = device pointer to [workgroups x wavefronts][6] uint64, or
+ * NULL = off: every wavefront records the 100 MHz wall clock at (0) entry, (1) first loads issued (after the deferred-norm
+ * prologue), (2) first activation chunk staged, (3) K slice consumed, (4) partial tiles in LDS (after the barrier),
+ * (5) epilogue stores issued -- tools/tile_timing.py */
+void md_debug_set_tile_timing(void* buf);
 /* md_linear_block: workgroups to aim for when K is split (0 = default 256); non-temporal weight DMA (1 = default) */
 void md_debug_set_block_gemm(int target_blocks, int weights_nontemporal);
 

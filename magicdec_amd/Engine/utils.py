@@ -40,7 +40,7 @@ def setup_seed(seed):
     random.seed(seed)
 
 
-def _random_init_(model, seed, device, dtype, std=0.02):
+def _random_init_(model, seed, device, dtype, std=0.02, is_draft=False):
     """Deterministic per-parameter init (each tensor from its own generator stream: identical on every rank)."""
     for j, (name, p) in enumerate(sorted(model.named_parameters())):
         g = torch.Generator(device="cpu").manual_seed(seed * 100003 + j)
@@ -58,12 +58,49 @@ def _random_init_(model, seed, device, dtype, std=0.02):
     import os
     mode = os.environ.get("MAGICDEC_SYNTH_WEIGHTS", "random")
     if mode.startswith("peaked"):
-        _peak_(model, seed, dtype, *[float(x) for x in mode.split(":")[1:3]])
+        emb_rms, peak, miss = parse_peaked(mode)
+        _peak_(model, seed, dtype, emb_rms, peak, miss if is_draft else 0.0)
     elif mode != "random":
-        raise ValueError(f"MAGICDEC_SYNTH_WEIGHTS must be 'random' or 'peaked[:emb_rms[:peak]]', got {mode!r}")
+        raise ValueError(f"MAGICDEC_SYNTH_WEIGHTS must be 'random' or 'peaked[:emb_rms[:peak]][:miss=f]', got {mode!r}")
 
 
-def _peak_(model, seed, dtype, emb_rms=40.0, peak=12.0):
+def parse_peaked(mode):
+    """'peaked[:emb_rms[:peak]][:miss=f]' -> (emb_rms, peak, miss)."""
+    emb_rms, peak, miss = 40.0, 12.0, 0.0
+    pos = []
+    for part in mode.split(":")[1:]:
+        if part.startswith("miss="):
+            miss = float(part[5:])
+        elif part:
+            pos.append(float(part))
+    if len(pos) > 2 or not 0.0 <= miss < 1.0:
+        raise ValueError(f"MAGICDEC_SYNTH_WEIGHTS must be 'random' or 'peaked[:emb_rms[:peak]][:miss=f]', got {mode!r}")
+    if pos:
+        emb_rms = pos[0]
+    if len(pos) > 1:
+        peak = pos[1]
+    return emb_rms, peak, miss
+
+
+def _peak_perm(seed, V, miss):
+    """pi of _peak_: ids 0..3 fixed, the rest a seeded permutation that depends on (seed, V) only; with `miss` = f a
+    seeded fraction f of the OUTPUT rows (ids >= 4) is rotated among themselves -- row j of the miss set answers to the
+    token whose true successor is the PREVIOUS member of the set, i.e. the model confidently predicts a wrong token
+    whenever the true next token lies in the set (the `miss_every` construction of tests/test_gpu_engine._peaked_wide
+    with a random instead of a strided set)."""
+    g = torch.Generator(device="cpu").manual_seed(seed * 7919 + V)
+    perm = torch.arange(V)
+    perm[4:] = 4 + torch.randperm(V - 4, generator=g)          # ids 0..3 (BOS / EOT ids of the tests) stay fixed
+    if miss > 0.0:
+        gm = torch.Generator(device="cpu").manual_seed(seed * 104729 + V + 17)
+        sel = torch.nonzero(torch.rand(V - 4, generator=gm) < miss).view(-1) + 4
+        if sel.numel() >= 2:
+            perm = perm.clone()
+            perm[sel] = perm[torch.roll(sel, 1)]
+    return perm
+
+
+def _peak_(model, seed, dtype, emb_rms=40.0, peak=12.0, miss=0.0):
     """Seeded weights with PEAKED next-token distributions (MAGICDEC_SYNTH_WEIGHTS=peaked; bench.py --weights peaked):
     the construction of tests/golden_cfg.py:peaked_pair at any size.  Random-init heads give `vocab` nearly tied
     Gaussian logits, so a draft never agrees with its target and measured acceptance is ~0 whatever the kernels do.
@@ -72,19 +109,47 @@ def _peak_(model, seed, dtype, emb_rms=40.0, peak=12.0):
     vocab) only -- `output[j] = c emb[pi(j)]`, logit ~`peak` for the one j with pi(j) == current token, the others
     ~N(0, peak^2 / dim) -- so that every model of a run with the same vocabulary (target, draft, self-speculation's
     sparse-cache draft) predicts through the same map and acceptance is decided by what the kernels compute: the
-    attention / FFN branches of all layers still run at full strength as the perturbation."""
+    attention / FFN branches of all layers still run at full strength as the perturbation.
+    `miss` (draft models only; 'peaked:...:miss=f'): the head mispredicts whenever the true next token lies in a seeded
+    fraction f of the vocabulary (_peak_perm), so a draft step is rejected with probability ~f -- a draft of KNOWN
+    acceptance rate alpha ~ 1 - f, measured by the accept kernel's own decisions (VERDICT r5 next #4)."""
     emb = model.tok_embeddings.weight
     V, dim = emb.shape
-    g = torch.Generator(device="cpu").manual_seed(seed * 7919 + V)
-    perm = torch.arange(V)
-    perm[4:] = 4 + torch.randperm(V - 4, generator=g)          # ids 0..3 (BOS / EOT ids of the tests) stay fixed
-    e = emb.data.float() * (emb_rms / 0.02)
+    e = (emb.data.float() * (emb_rms / 0.02)).to(dtype)
+    model.tok_embeddings.weight = torch.nn.Parameter(e, requires_grad=False)
+    model._peak_params = (seed, emb_rms, peak)
+    model.output.weight = torch.nn.Parameter(_peaked_head_rows(e, seed, emb_rms, peak, miss, 0, V).to(dtype),
+                                             requires_grad=False)
+
+
+def _peaked_head_rows(e, seed, emb_rms, peak, miss, row0, rows):
+    V, dim = e.shape
+    perm = _peak_perm(seed, V, miss)[row0:row0 + rows].to(e.device)
     c = peak / (dim * emb_rms)                                  # tied row: c |e|^2 / rms(h) ~ peak
-    model.tok_embeddings.weight = torch.nn.Parameter(e.to(dtype), requires_grad=False)
-    model.output.weight = torch.nn.Parameter((e[perm.to(e.device)] * c).to(dtype), requires_grad=False)
+    return e[perm].float() * c
 
 
-def _load(transformer_cls, checkpoint_path, device, precision, use_tp, rank_group, group, seed=1234):
+def repeak_head_(model, miss):
+    """Rewrite the lm head of a model built by _peak_ for another `miss` fraction IN PLACE (same storage: captured
+    hipGraphs and the streaming-layout copy keep their addresses) -- bench.py sweeps a draft's acceptance rate without
+    reloading or re-prefilling anything (the SnapKV / StreamingLLM draft cache does not depend on the head).  Under
+    tensor parallelism the head is vocab-chunked (Engine/tp.py): this rank's rows are regenerated."""
+    seed, emb_rms, peak = model._peak_params
+    e = model.tok_embeddings.weight.data
+    w = model.output.weight
+    rows = w.shape[0]
+    rank = getattr(model, "rank", None) or 0
+    world = getattr(model, "world_size", None) or 1
+    row0 = rank * rows if world > 1 else 0
+    new = _peaked_head_rows(e, seed, emb_rms, peak, miss, row0, rows).to(w.dtype)
+    w.data.copy_(new)
+    pk = getattr(model, "_packed", {}).get(id(w))
+    if pk is not None:
+        from .. import ops
+        pk.data.copy_(ops.PackedWeight(w.data).data)
+
+
+def _load(transformer_cls, checkpoint_path, device, precision, use_tp, rank_group, group, seed=1234, is_draft=False):
     checkpoint_path = Path(checkpoint_path)
     with torch.device("meta"):
         model = transformer_cls.from_name(checkpoint_path.parent.name)
@@ -100,7 +165,7 @@ def _load(transformer_cls, checkpoint_path, device, precision, use_tp, rank_grou
         model.load_state_dict(checkpoint, assign=True)
     else:
         print(f"[magicdec_amd] {checkpoint_path} not found: seeded random weights for '{checkpoint_path.parent.name}'")
-        _random_init_(model, seed, device, precision)
+        _random_init_(model, seed, device, precision, is_draft=is_draft)
         if int8:                                   # quantise the seeded weights the way the reference's quantize.py does
             print("Using int8 weight-only quantization!")
             from .quantize import WeightOnlyInt8QuantHandler
@@ -123,7 +188,7 @@ def load_model_snapKV(checkpoint_path, device, precision, use_tp, rank_group=Non
 
 def load_model_draft_snapKV(checkpoint_path, device, precision, use_tp, rank_group=None, group=None):
     from .SnapKV.model_draft import Transformer
-    return _load(Transformer, checkpoint_path, device, precision, use_tp, rank_group, group)
+    return _load(Transformer, checkpoint_path, device, precision, use_tp, rank_group, group, is_draft=True)
 
 
 def load_model_streamingLLM(checkpoint_path, device, precision, use_tp, rank_group=None, group=None):
@@ -133,4 +198,4 @@ def load_model_streamingLLM(checkpoint_path, device, precision, use_tp, rank_gro
 
 def load_model_draft_streamingLLM(checkpoint_path, device, precision, use_tp, rank_group=None, group=None):
     from .StreamingLLM.model_draft import Transformer
-    return _load(Transformer, checkpoint_path, device, precision, use_tp, rank_group, group)
+    return _load(Transformer, checkpoint_path, device, precision, use_tp, rank_group, group, is_draft=True)

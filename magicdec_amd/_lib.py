@@ -10,7 +10,8 @@ import os
 from ctypes import c_char_p, c_double, c_float, c_int, c_int64, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmagicdec_hip.so")
+# MAGICDEC_HIP_LIB: development only -- another build of the same sources (e.g. `make TIMING=1`'s instrumented library)
+LIB_PATH = os.environ.get("MAGICDEC_HIP_LIB") or os.path.join(_HERE, "libmagicdec_hip.so")
 ABI_VERSION = 10
 
 _lib = None
@@ -97,6 +98,7 @@ _DEV_SIGNATURES = {
     "md_debug_set_gemm_waves": (None, [I]),
     "md_debug_set_fused_nw": (None, [I]),
     "md_debug_set_fused_split": (None, [I]),
+    "md_debug_set_tile_timing": (None, [P]),
     "md_debug_set_block_gemm": (None, [I, I]),
 }
 DEV_SYMBOLS = tuple(_DEV_SIGNATURES)

@@ -95,7 +95,16 @@ struct TileParams {
     // FL_PARTIAL (md_linear_fused_split): S K-slices over workgroups, fp32 partial planes [S][M][N]
     float* partial;
     int S;
+    unsigned long long* dbg;  // dev builds: per-wave phase timestamps (md_debug_set_tile_timing), or null
 };
+
+#ifdef MD_TILE_TIMING
+// `make TIMING=1` only (libmagicdec_hip_timing.so, tools/tile_timing.py): phase timestamps of a wavefront (100 MHz wall
+// clock: comparable across CUs), kept in registers and written once at the end.  The product build has none of it.
+#define MD_TS(i) do { if (p.dbg) ts[i] = wall_clock64(); } while (0)
+#else
+#define MD_TS(i) do { } while (0)
+#endif
 
 __device__ __forceinline__ float silu_bf16(float h1) {
     return bf16_to_f32(f32_to_bf16(h1 / (1.0f + expf(-h1))));     // same expression as md_silu_mul / md_linear
@@ -163,6 +172,10 @@ __global__ __launch_bounds__(64 * NW, MT * NT > 1 ? 2 : 4) void tile_gemm_kernel
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];   // NW x kWaveLdsT (+ 32 MT floats rstd when PRO)
     const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, kh = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // provably wave-uniform: scalar base addresses
+#ifdef MD_TILE_TIMING
+    unsigned long long ts[6] = {0, 0, 0, 0, 0, 0};
+#endif
+    MD_TS(0);
     // block id -> (weight tile group, M tile group): block b runs on XCD b % 8; the M groups of one weight tile group
     // stay on one XCD
     const int m_groups = (p.m_tiles + MT - 1) / MT, n_groups = p.n_tiles / NT;
@@ -292,10 +305,14 @@ __global__ __launch_bounds__(64 * NW, MT * NT > 1 ? 2 : 4) void tile_gemm_kernel
         }
     const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
     const unsigned char* a_frag = my_lds + j * kPitch + kh * 16;
+    MD_TS(1);                                     // every first load is issued
 #pragma unroll 1
     for (int c = 0; c < nchunk; ++c) {
         const int nst = min(ksteps_w - c * 8, 8);
         a_store();
+#ifdef MD_TILE_TIMING
+        if (c == 0) MD_TS(2);                     // the first activation chunk has landed and is staged
+#endif
         if (c + 1 < nchunk) a_load(c + 1);
 #pragma unroll
         for (int st = 0; st < 8; ++st) {
@@ -327,6 +344,7 @@ __global__ __launch_bounds__(64 * NW, MT * NT > 1 ? 2 : 4) void tile_gemm_kernel
     // ---- the NW partial tiles (x MT x NT sub-tiles) -> LDS (each wavefront overwrites its own, fully consumed,
     // activation image).  acc[mt][nt][r] = D[row mt*32 + (r&3) + 8*(r>>2) + 4*kh][column nt*32 + j]
     float* red = reinterpret_cast<float*>(my_lds);
+    MD_TS(3);                                     // the wavefront's K slice is consumed (last W fragment has landed)
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -335,7 +353,19 @@ __global__ __launch_bounds__(64 * NW, MT * NT > 1 ? 2 : 4) void tile_gemm_kernel
             for (int r = 0; r < 16; ++r)
                 red[(mt * NT + nt) * 1024 + ((r & 3) + 8 * (r >> 2) + 4 * kh) * 32 + j] = acc[mt][nt][r];
     __syncthreads();
+    MD_TS(4);                                     // every wavefront's partial tile is in LDS
 
+#ifdef MD_TILE_TIMING
+    auto ts_flush = [&]() {
+        if (p.dbg && lane == 0) {
+            ts[5] = wall_clock64();
+            unsigned long long* d = p.dbg + ((int64_t)blockIdx.x * kNW + wave) * 6;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) d[i] = ts[i];
+        }
+    };
+    if (NW > 8 && tid >= 512) ts_flush();
+#endif
     if (NW > 8 && tid >= 512) return;                     // 512 threads finish each 32 x 32 sub-tile (one column pair each)
     const int row = tid >> 4, cp = tid & 15;
 #pragma unroll 1
@@ -439,6 +469,9 @@ __global__ __launch_bounds__(64 * NW, MT * NT > 1 ? 2 : 4) void tile_gemm_kernel
             }
         }
     }
+#ifdef MD_TILE_TIMING
+    ts_flush();
+#endif
 }
 
 template <int EPI, bool FP8, int NW, bool WNT, bool PRO, int MT = 1, int NT = 1>
@@ -459,6 +492,8 @@ int launch_tile_cfg(const TileParams& p, hipStream_t st) {
     hipLaunchKernelGGL(k, dim3(grid), dim3(64 * NW), lds, st, p);
     return MD_OK;
 }
+
+unsigned long long* g_tile_dbg = nullptr;    // dev knob (md_debug_set_tile_timing): per-wave phase timestamps
 
 int g_force_nw = 0;   // dev knob (md_debug_set_fused_nw): 0 = the rule below, 8 / 16 = forced where the shape allows
 
@@ -580,6 +615,7 @@ int split_main(const void* x, int64_t ldx, const void* w, int M, int N, int K, v
     p.m_tiles = (M + 31) / 32;
     p.partial = (float*)ws;
     p.S = pl.S;
+    p.dbg = g_tile_dbg;
     *S_out = pl.S;
     return launch_split(p, pl, st);
 }
@@ -595,6 +631,7 @@ int md_internal_launch_reduce_add_rmsnorm(const float* partial, int S, int M, in
 
 #ifdef MD_DEV_KNOBS
 extern "C" void md_debug_set_fused_split(int S) { g_force_split = S > 0 ? S : 0; }
+extern "C" void md_debug_set_tile_timing(void* buf) { g_tile_dbg = (unsigned long long*)buf; }
 #endif
 
 extern "C" size_t md_linear_fused_split_workspace_bytes(int M, int N, int K) {
@@ -690,6 +727,7 @@ extern "C" int md_linear_fused(const md_fused_linear_args* a, md_stream_t stream
     }
     MD_CHECK_ARG(!a->ssq_out || a->epilogue == FL_RESID, "md_linear_fused: ssq_out belongs to the residual epilogue");
     p.ssq_out = a->ssq_out;
+    p.dbg = g_tile_dbg;
     hipStream_t st = (hipStream_t)stream;
     int rc = MD_OK;
     switch (a->epilogue) {
