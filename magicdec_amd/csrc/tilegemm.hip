@@ -119,6 +119,19 @@ __device__ __forceinline__ f32x2 unpack2(unsigned int v) {          // the two b
     return f32x2{__uint_as_float(v << 16), __uint_as_float(v & 0xffff0000u)};
 }
 
+// lane l of every 16-lane group receives the value lane `i` of ITS group holds (v_mov_b32_dpp row_newbcast:i; `i` is a
+// constant after unrolling -- the builtin wants a literal)
+__device__ __forceinline__ float row_bcast(float v, int i) {
+    const int x = (int)__float_as_uint(v);
+#define MD_BC(I) case I: return __uint_as_float((unsigned int)__builtin_amdgcn_update_dpp(0, x, 0x150 + I, 0xf, 0xf, true));
+    switch (i & 15) {
+        MD_BC(0) MD_BC(1) MD_BC(2) MD_BC(3) MD_BC(4) MD_BC(5) MD_BC(6) MD_BC(7)
+        MD_BC(8) MD_BC(9) MD_BC(10) MD_BC(11) MD_BC(12) MD_BC(13) MD_BC(14) MD_BC(15)
+    }
+#undef MD_BC
+    return v;
+}
+
 template <bool NT>
 __device__ __forceinline__ u32x4 ld_w(const bf16_t* p) {
     if constexpr (NT) return __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
@@ -167,6 +180,17 @@ __device__ __forceinline__ int64_t kv_elem_offset(const KvTable& t, int b, int r
 template <int EPI, bool FP8, int NW, bool WNT, bool PRO, int MT, int NT>
 __global__ __launch_bounds__(64 * NW, MT * NT > 1 ? 2 : 4) void tile_gemm_kernel(const TileParams p) {
     constexpr int kNW = NW;
+    // Round 6, the deferred-norm prologue on 2 x 2 tiles (the 1B w1|w3 at 64 rows).  Phase timestamps of the 1 x 1 form
+    // (tools/tile_timing.py, profiles/r06_tile_phase_timing.txt) show where its 6 us go: ~1 us of prologue in front of the
+    // first load, +2.4 us per activation chunk between "landed" and "staged" (four wavefronts per SIMD normalising at
+    // once, 11 vector instructions per dword), and every column tile normalising the same rows (512 x).  The 2 x 2 form
+    // halves the last; it used to sit at 256 registers and spill.  A CU keeps ~64 KB of loads in flight whoever issues
+    // them, so 8 wavefronts need 8 KB each, not 32: the W ring of this form is FOUR deep (kRD), which
+    // frees 32 registers; the row scales' partial sums are requested FIRST, the W ring and the first activation chunk
+    // behind them, and the workgroup meets at a bare s_barrier (no vmcnt(0) drain); the norm weights of a chunk are
+    // unpacked once, both roundings are one v_cvt_pk_bf16_f32.
+    constexpr bool kNewPro = PRO && MT * NT > 1;
+    constexpr int kRD = kNewPro ? 4 : 8;                  // W fragments in flight per column tile and wavefront
     constexpr int kWaveLdsT = MT * kWaveLds;               // wave-private activation image of 32 x MT rows
     static_assert(MT * NT * 4096 <= kWaveLdsT, "the partial tiles of a wave must fit its activation image");
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];   // NW x kWaveLdsT (+ 32 MT floats rstd when PRO)
@@ -221,7 +245,24 @@ __global__ __launch_bounds__(64 * NW, MT * NT > 1 ? 2 : 4) void tile_gemm_kernel
     // (the row scales are formed BEFORE the first loads are issued: with the loads in flight first, the barrier below
     // drains them -- 1B w1|w3 at 64 rows 29.2 us against 25.8, profiles/r04_fused_pro_prologue_ab.txt.  What the
     // deferred norm costs is the VALU work of normalising the same rows in every column tile: 18.9 -> 25.8 us there.)
-    if constexpr (PRO) {
+    float my_rs = 0.f;                              // kNewPro: the row scale this lane keeps for its 16-lane group
+    float pv[MT][8];                                // kNewPro: this thread's partial sums of squares (in flight)
+    if constexpr (kNewPro) {
+#pragma unroll
+        for (int mi = 0; mi < MT; ++mi) {
+            const int r = (tid >> 4) + 32 * mi, part = tid & 15;
+            const int gr = m0 + r < p.M ? m0 + r : p.M - 1;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {              // unconditional (clamped) loads: no branch per value
+                const int i = part + 16 * u < p.pro_tiles ? part + 16 * u : p.pro_tiles - 1;
+                pv[mi][u] = p.pro_ssq[(int64_t)gr * p.pro_tiles + i];
+            }
+        }
+        // every one of these loads in FRONT of the W / x loads below: the scheduler otherwise sinks the last one behind
+        // them, and its wait (vmcnt(0)) drains the whole prefetch
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if constexpr (PRO && !kNewPro) {
         float* rstd_lds = reinterpret_cast<float*>(lds + NW * kWaveLdsT);
         if (tid < 512) {
 #pragma unroll
@@ -247,6 +288,8 @@ __global__ __launch_bounds__(64 * NW, MT * NT > 1 ? 2 : 4) void tile_gemm_kernel
         const int klen = min(ksteps_w - c * 8, 8) * 16;               // k elements of this chunk (wave-uniform)
         const unsigned int cc = (unsigned int)(c * kKC + (c16 * 8 < klen ? c16 : 0) * 8) * 2u;   // lanes past a short
                                                                       // tail chunk re-read its column 0
+        if constexpr (kNewPro)        // the chunk's norm weights FIRST: a_store unpacks them before it touches a row
+            nwv = *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned char*>(p.pro_w + ks0 * 16) + cc);
 #pragma unroll
         for (int i = 0; i < 8 * MT; ++i) {
             unsigned int ro;
@@ -258,14 +301,32 @@ __global__ __launch_bounds__(64 * NW, MT * NT > 1 ? 2 : 4) void tile_gemm_kernel
             }
             xa[i] = *reinterpret_cast<const u32x4*>(xbase + (ro + cc));
         }
-        if constexpr (PRO)
+        if constexpr (PRO && !kNewPro)
             nwv = *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned char*>(p.pro_w + ks0 * 16) + cc);
     };
     auto a_store = [&]() {
+        f32x2 nwf[4];                                 // kNewPro: the chunk's norm weights, unpacked once
+        if constexpr (kNewPro) {
+#pragma unroll
+            for (int w = 0; w < 4; ++w) nwf[w] = unpack2(nwv[w]);
+        }
 #pragma unroll
         for (int i = 0; i < 8 * MT; ++i) {
             u32x4 v = xa[i];
-            if constexpr (PRO) {
+            if constexpr (kNewPro) {
+                // rows 0..31 of the tile from the 16 instructions i = 0..15?  no: instruction i covers rows 4 i + ar of
+                // the 64-row image (i < 16), and its scale sits in lane 16 ar + i of the lane's own 16-lane group
+                const float rs = row_bcast(my_rs, i);                                    // row_newbcast:i
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    const f32x2 t = unpack2(v[w]) * f32x2{rs, rs};
+                    unsigned int pk, po;
+                    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(pk) : "v"(t[0]), "v"(t[1]));
+                    const f32x2 o = unpack2(pk) * nwf[w];
+                    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(po) : "v"(o[0]), "v"(o[1]));
+                    v[w] = po;
+                }
+            } else if constexpr (PRO) {
                 float rs;
                 if constexpr (MT == 1) rs = rs8[i];
                 else rs = reinterpret_cast<const float*>(lds + NW * kWaveLdsT)[4 * i + ar];
@@ -294,15 +355,40 @@ __global__ __launch_bounds__(64 * NW, MT * NT > 1 ? 2 : 4) void tile_gemm_kernel
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
 
-    bf16x8 wr[NT][8];
+    bf16x8 wr[NT][kRD];
     a_load(0);
 #pragma unroll
-    for (int s = 0; s < 8; ++s)
+    for (int s = 0; s < kRD; ++s)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             const u32x4 v = ld_w<WNT>(wbase[nt] + (s < ksteps_w ? s : ksteps_w - 1) * 512 + lane * 8);
             wr[nt][s] = *reinterpret_cast<const bf16x8*>(&v);
         }
+    if constexpr (kNewPro) {
+        // the row scales, from the partial sums requested in front of everything above (they return first): the order
+        // of the additions is the old prologue's (i = part, part + 16, ...), then the 16-lane butterfly
+        float* rstd_lds = reinterpret_cast<float*>(lds + NW * kWaveLdsT);
+#pragma unroll
+        for (int mi = 0; mi < MT; ++mi) {
+            const int r = (tid >> 4) + 32 * mi, part = tid & 15;
+            float t = 0.f;
+#pragma unroll
+            for (int u = 0; u < 8; ++u)                // pro_tiles <= 128 (K <= 4096): the launcher's condition for this form
+                if (part + 16 * u < p.pro_tiles) t += pv[mi][u];
+            t += __shfl_xor(t, 1);
+            t += __shfl_xor(t, 2);
+            t += __shfl_xor(t, 4);
+            t += __shfl_xor(t, 8);
+            if (part == 0) rstd_lds[r] = rsqrtf(t / (float)p.K + p.pro_eps);      // md_rmsnorm's expression
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the LDS writes only: the global loads stay in flight
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        // staging instruction i of a lane covers row 4 i + (lane >> 4): lane 16 a + i keeps the scale of row 4 i + a, so
+        // that ONE row_newbcast:i DPP move hands every lane of the 16-lane group a its scale of instruction i -- no LDS
+        // read (and no lgkmcnt wait) per staged row
+        my_rs = rstd_lds[4 * (lane & 15) + (lane >> 4)];
+    }
     const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
     const unsigned char* a_frag = my_lds + j * kPitch + kh * 16;
     MD_TS(1);                                     // every first load is issued
@@ -317,13 +403,13 @@ __global__ __launch_bounds__(64 * NW, MT * NT > 1 ? 2 : 4) void tile_gemm_kernel
 #pragma unroll
         for (int st = 0; st < 8; ++st) {
             const bool live = st < nst;                               // wave-uniform; only the last chunk can be short
-            const int nxt = c * 8 + st + 8;
+            const int nxt = c * 8 + st + kRD;
             bf16x8 b[NT], a[MT];
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
-                b[nt] = wr[nt][st];
+                b[nt] = wr[nt][st % kRD];
                 const u32x4 v = ld_w<WNT>(wbase[nt] + (nxt < ksteps_w ? nxt : ksteps_w - 1) * 512 + lane * 8);
-                wr[nt][st] = *reinterpret_cast<const bf16x8*>(&v);
+                wr[nt][st % kRD] = *reinterpret_cast<const bf16x8*>(&v);
             }
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) a[mt] = *reinterpret_cast<const bf16x8*>(a_frag + mt * 32 * kPitch + st * 32);
@@ -506,11 +592,14 @@ int launch_tile_pro(const TileParams& p, hipStream_t st) {
     // w1|w3: 256 groups).  Narrow products keep 1 x 1 tiles: more, smaller workgroups matter more there.
     // (not with the deferred-RMSNorm prologue: that instantiation sits at the 256-register cap, re-reads rstd from LDS per
     // chunk, and measured 25.9 us in the cfg3 iteration against 24.5 for the 1 x 1 form -- profiles/r04_bench_cfg3_iter_breakdown.csv)
-    if constexpr ((EPI == FL_SWIGLU || EPI == FL_NONE || EPI == FL_RESID) && !PRO) {
+    // round 6: also WITH the deferred-RMSNorm prologue (SwiGLU consumer), now that that instantiation has a four-deep W
+    // ring, no spills, and its own prologue (kNewPro in the kernel)
+    if constexpr ((EPI == FL_SWIGLU || EPI == FL_NONE || EPI == FL_RESID) && (!PRO || EPI == FL_SWIGLU)) {
         const int groups = (p.n_tiles / 2) * ((p.m_tiles + 1) / 2);
         bool t22 = p.m_tiles >= 2 && p.n_tiles % 2 == 0 && p.K % 128 == 0 && groups >= 192;
         if (g_force_tile == 11) t22 = false;
         if (g_force_tile == 22) t22 = p.n_tiles % 2 == 0 && p.K % 128 == 0;
+        if (PRO && p.pro_tiles > 128) t22 = false;       // the 2 x 2 prologue keeps <= 8 partial sums per thread in flight
         if (t22) return launch_tile_cfg<EPI, FP8, 8, false, PRO, 2, 2>(p, st);
     }
     // 16 wavefronts (K/16 slices) when the grid is too small to put two 8-wave workgroups on every CU

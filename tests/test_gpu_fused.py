@@ -263,8 +263,10 @@ def test_fused_2x2_tiles_bit_identical_to_1x1(ops, M, N, K):
     """Round 4: a workgroup may own 2 x 2 MFMA tiles (64 rows x 64 columns: half the per-CU ingest of the wide 64-row
     products).  The K slices, their summation order and the epilogues are those of the 1 x 1 form, so every output --
     plain, residual (+ the partial sums of squares), SwiGLU -- must be BIT-IDENTICAL between the two decompositions
-    (md_debug_set_fused_nw 11 / 22 force them).  The deferred-RMSNorm form always runs 1 x 1 tiles and
-    is checked for being unaffected by the knob."""
+    (md_debug_set_fused_nw 11 / 22 force them).  Round 6: the deferred-RMSNorm SwiGLU form has a 2 x 2 instantiation
+    of its own (four-deep W ring, partial sums of squares requested in front of the first loads, a bare s_barrier): the
+    row scales are added in the 1 x 1 form's order and both roundings of y = bf16(bf16(h * rstd) * w) are RNE, so
+    "swiglu+norm" must be bit-identical across the knob too."""
     lib = ops._lib.load()
     g = torch.Generator().manual_seed(M * 7 + N + K)
     x = d(torch.randn(M, K, generator=g).to(BF))

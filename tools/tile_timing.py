@@ -29,7 +29,8 @@ ws = ops.AttnWorkspace(dev)
 NAMES = ["entry", "loads issued", "x chunk 0 staged", "K slice consumed", "partials in LDS", "stores issued"]
 
 # name, kind, M, N, K
-CASES = [("1B w13 swiglu", "swiglu", 64, 16384, 2048), ("1B w13 swiglu+pro", "swiglu_pro", 64, 16384, 2048),
+CASES = [("1B w13 swiglu", "swiglu", 64, 16384, 2048), ("1B w13 swiglu+pro 1x1", "swiglu_pro11", 64, 16384, 2048),
+         ("1B w13 swiglu+pro", "swiglu_pro", 64, 16384, 2048),
          ("1B w13 swiglu 2x2", "swiglu22", 64, 16384, 2048),
          ("1B wo resid", "resid", 64, 2048, 2048), ("1B wqkv plain", "plain", 64, 3072, 2048),
          ("1B w2 split", "split", 64, 2048, 8192), ("1B w2 fused resid", "resid", 64, 2048, 8192),
@@ -56,6 +57,9 @@ for name, kind, M, N, K in CASES:
         if kind == "swiglu22":
             lib.md_debug_set_fused_nw(ctypes.c_int(22))
             return ops.fused_linear(x, wl[i % ncopy], swiglu=True)
+        if kind == "swiglu_pro11":
+            lib.md_debug_set_fused_nw(ctypes.c_int(11))
+            return ops.fused_linear(x, wl[i % ncopy], swiglu=True, pro=pro)
         if kind == "swiglu_pro":
             return ops.fused_linear(x, wl[i % ncopy], swiglu=True, pro=pro)
         if kind == "resid":
