@@ -94,12 +94,17 @@ def parse(argv=None):
                          "verify-attention launch at this run's shard shape in a subprocess (tools/attn_bench.py); "
                          "default: on for the cfg* workloads on rank 0")
     ap.add_argument("--no-pmc", dest="pmc", action="store_false")
-    ap.add_argument("--weights", default="random", metavar="random|peaked[:emb_rms[:peak]][:miss=f]",
+    ap.add_argument("--weights", default="peaked:40:12:miss=0.2", metavar="random|peaked[:emb_rms[:peak]][:miss=f]",
                     help="synthetic weights when no checkpoint exists on the box: 'random' = seeded normal(0, 0.02) "
                          "(acceptance ~0: `value` comes from the fixed-acceptance replay); 'peaked' = the same layers "
                          "with a dominant embedding and a head tied to it through a permutation (Engine/utils._peak_) "
                          "-- peaked next-token distributions, so measured_acceptance_run reports what the draft / "
-                         "verify kernels really accept; timings are weight-value independent")
+                         "verify kernels really accept; ':miss=f' makes a separate DRAFT model mispredict a seeded "
+                         "fraction f of the vocabulary (per-step acceptance ~1 - f), and measured_acceptance_sweep "
+                         "runs the loop at miss = 0.4 / 0.3 / 0.2 beside the replay at alpha = 0.6 / 0.7 / 0.8.  "
+                         "Default (round 6): peaked with miss = 0.2, so that the driver's line carries a MEASURED "
+                         "acceptance next to the replay that defines `value`; timings are weight-value independent "
+                         "(ms_per_step of the two agree to 0.1 %%: profiles/r06_bench_cfg3_peaked_miss_sweep_c7.json)")
     return ap.parse_args(argv)
 
 
@@ -540,7 +545,7 @@ def run(args, dev):
     # rate is ~1 - miss, and the SAME loop runs with the accept kernel's own decisions.  Each point sits beside the
     # fixed-acceptance replay at alpha = 1 - miss: equal tokens/s there shows the replay is a timing-neutral stand-in.
     acc_sweep = None
-    if weights.startswith("peaked") and draft is not None and hasattr(draft.model, "_peak_params"):
+    if on_gpu and weights.startswith("peaked") and draft is not None and hasattr(draft.model, "_peak_params"):
         from magicdec_amd.Engine.utils import parse_peaked, repeak_head_
         miss_cfg = parse_peaked(weights)[2]
         acc_sweep = {}
@@ -631,9 +636,16 @@ def run(args, dev):
                    "fused_linear": {"auto": "md_linear_fused (linear + rope/append | residual add | SiLU*mul in one "
                                             "launch) for the launch-bound small products (Engine/gemm_policy.py)",
                                     "0": "off", "1": "forced on"}[gemm_policy.fused_mode()],
+                   # weights held TWICE during decode (streaming layout + row-major): after prefill the row-major tensor of
+                   # every weight that decode reads in the streaming layout only is released (Transformer.release_rowmajor);
+                   # what remains is read in both layouts at different row counts (the 8B wo: fused kernel at 64 rows,
+                   # library GEMM at 256)
                    "packed_weight_copies_bytes": int(getattr(engine.model, "packed_bytes", 0)
                                                      + (getattr(draft.model, "packed_bytes", 0) if draft is not None
                                                         else 0)),
+                   "rowmajor_weight_bytes_released_after_prefill": int(
+                       getattr(engine.model, "released_bytes", 0)
+                       + (getattr(draft.model, "released_bytes", 0) if draft is not None else 0)),
                    **({"emulated_tp_rank0_of": emu} if emu > 1 else {}),
                    "allreduce": (None if not use_tp else
                                  "oneshot-ipc" if getattr(engine.model, "_oneshot", None) is not None else "rccl"),

@@ -116,6 +116,23 @@ class _BackendBase:
     def _qo(self, n):
         return self.qo_indptr * n
 
+    def _decode_rows(self, *per_request):
+        """Row counts of this engine's decode / verify steps: batch x (1, 2 -- the two-token draft step --, dec_len ...);
+        the model packs / releases weight copies for exactly these (Transformer.setup_caches(decode_rows=...))."""
+        B = self.batch_size
+        return sorted({B * int(n) for n in (1, 2) + tuple(per_request) if n})
+
+    def _prefill_begin(self):
+        """Prefill-sized products run on the library GEMM over the row-major weights: re-materialise the ones released
+        after the previous prefill (Transformer.restore_rowmajor)."""
+        if hasattr(self.model, "restore_rowmajor"):
+            self.model.restore_rowmajor()
+
+    def _prefill_end(self):
+        """Decode reads most weights in the streaming layout only: free their row-major tensors (one resident copy)."""
+        if hasattr(self.model, "release_rowmajor"):
+            self.model.release_rowmajor()
+
     def _reset_kv_calibration(self):
         """fp8 caches re-calibrate their static scales on the first prefill chunk of every encode()."""
         for b in self.model.layers:
@@ -137,6 +154,7 @@ class SnapKVTargetBackend(_BackendBase):
         super().__init__(dtype, device)
         self.dec_len = dec_len
         self.is_spec = draft_dec_len is not None
+        self.draft_dec_len = draft_dec_len
         self.draft_cachelens = None
 
     @torch.no_grad()
@@ -166,10 +184,12 @@ class SnapKVTargetBackend(_BackendBase):
             self.model.setup_caches(num_pages=self.max_num_pages, page_size=PAGE_SIZE, spec=True,
                                     draft_num_pages=self.draft_num_pages, draft_budget=draft_budget,
                                     window_size=window_size, max_positions=max_seq_length + 256, kv_dtype=kv_dtype,
-                                    kv_layout=kv_layout)
+                                    kv_layout=kv_layout,
+                                    decode_rows=self._decode_rows(self.dec_len, getattr(self, "draft_dec_len", None)))
         else:
             self.model.setup_caches(num_pages=self.max_num_pages, page_size=PAGE_SIZE,
-                                    max_positions=max_seq_length + 256, kv_dtype=kv_dtype, kv_layout=kv_layout)
+                                    max_positions=max_seq_length + 256, kv_dtype=kv_dtype, kv_layout=kv_layout,
+                                    decode_rows=self._decode_rows(self.dec_len))
 
     @torch.no_grad()
     def clear_kv(self):
@@ -189,6 +209,7 @@ class SnapKVTargetBackend(_BackendBase):
     def encode(self, input_ids: torch.LongTensor, benchmark=False):
         """Chunked prefill (backend.py:232-268)."""
         self.clear_kv()
+        self._prefill_begin()
         seq_len = input_ids.shape[1]
         tokens = None
         num_chunks = (seq_len + CHUNK - 1) // CHUNK
@@ -212,6 +233,7 @@ class SnapKVTargetBackend(_BackendBase):
                 raise ValueError("SnapKV self-speculation: prefix_len is a multiple of 128, so no last chunk ran the "
                                  "select and the draft cache is empty (need (prefix_len - window_size) % 128 == 0)")
             self.draft_cachelens.copy_(self.cachelens)
+        self._prefill_end()
         return tokens
 
     @torch.no_grad()
@@ -285,10 +307,11 @@ class SnapKVDraftBackend(_BackendBase):
             self._d.reset(last_page_len_init=1, full_table=True)
             self.model.setup_caches(num_pages=self.max_num_pages, page_size=PAGE_SIZE, spec=True,
                                     draft_num_pages=self.draft_num_pages, draft_budget=draft_budget,
-                                    window_size=window_size, max_positions=max_seq_length + 256)
+                                    window_size=window_size, max_positions=max_seq_length + 256,
+                                    decode_rows=self._decode_rows())
         else:
             self.model.setup_caches(num_pages=self.max_num_pages, page_size=PAGE_SIZE,
-                                    max_positions=max_seq_length + 256)
+                                    max_positions=max_seq_length + 256, decode_rows=self._decode_rows())
 
     @torch.no_grad()
     def clear_kv(self):
@@ -307,6 +330,7 @@ class SnapKVDraftBackend(_BackendBase):
     def encode(self, input_ids: torch.LongTensor, benchmark=False):
         """backend_draft.py:176-209."""
         self.clear_kv()
+        self._prefill_begin()
         seq_len = input_ids.shape[1]
         tokens = None
         num_chunks = (seq_len + CHUNK - 1) // CHUNK
@@ -328,6 +352,7 @@ class SnapKVDraftBackend(_BackendBase):
         if self.is_compress and not is_last:
             raise ValueError("SnapKV draft: prefix_len is a multiple of 128, so no last chunk ran the select and the "
                              "draft cache is empty (need (prefix_len - window_size) % 128 == 0)")
+        self._prefill_end()
         return tokens
 
     @torch.no_grad()
@@ -362,6 +387,7 @@ class _StreamingMixin:
     """Sink(16)+window prefill shared by the stand-alone StreamingLLM draft and the self-spec engine."""
 
     def _stream_encode(self, input_ids, state: _PagedState, lens_attr, which):
+        self._prefill_begin()
         seq_len = input_ids.shape[1]
         tokens = None
         num_chunks = (seq_len + CHUNK - 1) // CHUNK
@@ -385,6 +411,7 @@ class _StreamingMixin:
                 ctx = self.draft_budget
                 lens.fill_(self.draft_budget)
         self.model.skip_head = False
+        self._prefill_end()
         return tokens
 
 
@@ -407,7 +434,8 @@ class StreamingDraftBackend(_BackendBase, _StreamingMixin):
         self._t = _PagedState(self, "", self.max_num_pages_per_request)
         self._t.reset()
         self.model.setup_caches(num_pages=self.max_num_pages, page_size=PAGE_SIZE, draft_budget=draft_budget,
-                                streaming=True, max_positions=self.max_num_pages_per_request * PAGE_SIZE + 256)
+                                streaming=True, max_positions=self.max_num_pages_per_request * PAGE_SIZE + 256,
+                                decode_rows=self._decode_rows())
 
     @torch.no_grad()
     def clear_kv(self):
@@ -470,7 +498,8 @@ class StreamingSelfSpecBackend(_BackendBase, _StreamingMixin):
         self._d.reset(indptr_stride=self.draft_max_num_pages_per_request)
         self.model.setup_caches(num_pages=self.max_num_pages, page_size=PAGE_SIZE, spec=True,
                                 draft_num_pages=self.draft_max_num_pages, draft_budget=draft_budget, streaming=True,
-                                max_positions=max_seq_length + 256, kv_dtype=kv_dtype, kv_layout=kv_layout)
+                                max_positions=max_seq_length + 256, kv_dtype=kv_dtype, kv_layout=kv_layout,
+                                decode_rows=self._decode_rows(self.dec_len))
 
     @torch.no_grad()
     def clear_kv(self):
@@ -488,6 +517,7 @@ class StreamingSelfSpecBackend(_BackendBase, _StreamingMixin):
     def encode(self, input_ids: torch.LongTensor, benchmark=False):
         """Target prefill (StreamingLLM/backend.py:190-211)."""
         self.clear_kv()
+        self._prefill_begin()
         seq_len = input_ids.shape[1]
         tokens = None
         num_chunks = (seq_len + CHUNK - 1) // CHUNK
@@ -499,6 +529,7 @@ class StreamingSelfSpecBackend(_BackendBase, _StreamingMixin):
             tokens = self.model.prefill(ids, self.cachelens, self._qo(n), self._t.table())
             self.cachelens += n
         self.model.skip_head = False
+        self._prefill_end()
         return tokens
 
     @torch.no_grad()

@@ -102,10 +102,12 @@ def set_packed_copies(mode: str):
     _PACKED = mode
 
 
-def want_packed(N: int, K: int, swiglu: bool = False, int8: bool = False) -> bool:
+def want_packed(N: int, K: int, swiglu: bool = False, int8: bool = False, rows=None) -> bool:
     """Re-pack this weight into the streaming layout at load time?  Only when a hand-written kernel may actually be
-    chosen for it at some row count of a decode / verify step (1..256): the copy doubles the weight's HBM footprint
-    (round 3 packed every bf16 weight with K % 128 == 0)."""
+    chosen for it at some row count of a decode / verify step: `rows` = the counts the engine will run (the back-end knows
+    them: batch x {1, 2, dec_len}), or None = any of 1..256 (round 3 packed every bf16 weight with
+    K % 128 == 0; round 6: the 8B wqkv, served by the library at 64 and 256 rows, is no longer packed for the 32-row
+    steps configs[2] never runs)."""
     if _MODE == "lib" or _PACKED == "0" or K % 64:
         return False
     if int8:
@@ -113,7 +115,8 @@ def want_packed(N: int, K: int, swiglu: bool = False, int8: bool = False) -> boo
     if _MODE == "hip" or _BLOCK == "1" or _FUSED == "1" or _SPLIT == "1":
         return True
     kinds = ("swiglu",) if swiglu else ("plain", "resid", "qkv")
-    for M in (1,) + tuple(range(32, 257, 32)):      # every 32-row tile count a rule can depend on
+    for M in ((1,) + tuple(range(32, 257, 32)) if rows is None else tuple(m for m in rows if m <= 256)):
+        # (default: every 32-row tile count a rule can depend on -- ADVICE r4)
         if use_skinny(M, N, K, swiglu, False, True):
             return True
         for kind in kinds:
@@ -129,7 +132,15 @@ def use_fused(M: int, N: int, K: int, kind: str = "plain", absorbs_norm: bool = 
         return False
     if _FUSED == "1":
         return True
-    l2_bytes = ((M + 31) // 32) * N * K * 2
+    m_tiles = (M + 31) // 32
+    # a product the kernel runs with 2 x 2 tiles (csrc/tilegemm.hip launch_tile_pro: two M tiles, an even number of column
+    # tiles, >= 192 tile groups; with the deferred-norm prologue since round 6, K <= 4096) re-reads the weights once per
+    # PAIR of M tiles: the 1B w1|w3 -- 18.4-18.9 us at 64 rows against md_linear's 22.8-23.2, and with the norm absorbed
+    # 20.3 (profiles/r06_fused_pro22_ab.txt); at 128 rows (the two-token draft step) 32.0 with the norm against the library
+    # + rmsnorm + SiLU*mul launches (20.5 + 5.1 + 5.4 in the trace), which also frees that weight's row-major copy
+    t22 = (kind in ("swiglu", "plain", "resid") and m_tiles >= 2 and (N // 32) % 2 == 0
+           and (N // 64) * ((m_tiles + 1) // 2) >= 192 and (not absorbs_norm or (kind == "swiglu" and K <= 4096)))
+    l2_bytes = ((m_tiles + 1) // 2 if t22 else m_tiles) * N * K * 2
     if M <= 128:
         return l2_bytes <= (FUSED_MAX_L2_BYTES_WITH_NORM if absorbs_norm else FUSED_MAX_L2_BYTES) and K <= FUSED_MAX_K
     if kind == "swiglu":

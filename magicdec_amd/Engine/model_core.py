@@ -264,7 +264,7 @@ class Transformer(nn.Module):
 
     # ------------------------------------------------------------------ setup
     def setup_caches(self, num_pages, page_size=128, spec=False, draft_num_pages=0, draft_budget=0, window_size=32,
-                     max_positions=None, streaming=False, kv_dtype="bf16", kv_layout="NHD"):
+                     max_positions=None, streaming=False, kv_dtype="bf16", kv_layout="NHD", decode_rows=None):
         """Allocates the per-layer KV slabs and the device-side constants of the step
         (Engine/SnapKV/model.py:127-169 / StreamingLLM/model_draft.py:157-189 without the op registration)."""
         c = self.config
@@ -292,6 +292,9 @@ class Transformer(nn.Module):
                                         c.original_max_position_embeddings if llama31 else None, device=dev)
         self.workspace = ops.AttnWorkspace(dev)
         self._rot_scratch = None
+        # row counts of the decode / verify steps this engine will run (the back-end knows: batch x {1, 2, dec_len}); None =
+        # unknown: every count 1..256 is assumed (the streaming-layout copies and the row-major tensors are both kept)
+        self.decode_rows = tuple(sorted(set(int(r) for r in decode_rows))) if decode_rows else None
         self._fuse_weights()
         self._ready = True
 
@@ -313,24 +316,27 @@ class Transformer(nn.Module):
             self._w13.append(w13)
         self._pack_weights()
 
-    def _pack_weights(self):
+    def _pack_weights(self, force=False):
         """Streaming-layout copies (ops.PackedWeight) of the weights the hand-written GEMMs serve in decode / verify
         steps -- md_linear for the long weight streams, md_linear_fused for the launch-bound small products
         (Engine/gemm_policy.py); keyed by the id of the row-major tensor the step would otherwise use.  The row-major
         tensors stay for the prefill-sized library GEMMs; the extra bytes are reported once (`packed_bytes`)."""
         from .gemm_policy import want_packed
         self._packed = {}
-        self.packed_bytes = 0
-        if not self.output.weight.is_cuda:
+        self._released, self._by_id, self._roles = set(), {}, {}
+        if not self.output.weight.is_cuda and not force:      # force: host tests of the bookkeeping (no kernel runs)
             return
 
         todo = []
+        self._roles = {}                                # id(weight) -> (role, layer index | None)
         for i, b in enumerate(self.layers):
-            todo += [(self._w13[i], True), (b.attention.wqkv.weight, False), (b.attention.wo.weight, False),
-                     (b.feed_forward.w2.weight, False)]
+            for w, sw, role in ((self._w13[i], True, "w13"), (b.attention.wqkv.weight, False, "wqkv"),
+                                (b.attention.wo.weight, False, "wo"), (b.feed_forward.w2.weight, False, "w2")):
+                todo.append((w, sw))
+                self._roles[id(w)] = (role, i)
         todo.append((self.output.weight, False))
-        todo = [(w, sw) for w, sw in todo
-                if w.shape[1] % 16 == 0 and want_packed(w.shape[0], w.shape[1], sw, w.dtype == torch.int8)]
+        self._roles[id(self.output.weight)] = ("head", None)
+        todo = [(w, sw) for w, sw in todo if w.shape[1] % 16 == 0 and self._wants_packed(self._roles[id(w)][0], w)]
         # headroom check (VERDICT r3 weak #9): the copies double the served weights' footprint (17 GB for the 8B + 1B pair)
         # and are made AFTER the KV slabs exist; if they do not fit beside them with a margin for the step's workspaces,
         # serve everything from the row-major tensors (library GEMMs / row-major md_linear) instead of failing later.
@@ -368,7 +374,139 @@ class Transformer(nn.Module):
         for w, sw in todo:
             pw = ops.PackedWeight(w.data if isinstance(w, nn.Parameter) else w, swiglu=sw)
             self._packed[id(w)] = pw
-            self.packed_bytes += pw.data.numel() * pw.data.element_size()
+        self._released = set()          # ids of weights whose row-major tensor is currently released (release_rowmajor)
+        self._by_id = {id(w): w for w, _ in todo}
+
+    @property
+    def packed_bytes(self):
+        """Bytes of weights held TWICE right now: a streaming-layout copy beside a resident row-major tensor.  After
+        release_rowmajor() that is only what decode reads in both layouts (at different row counts)."""
+        pk = getattr(self, "_packed", None)
+        if not pk:
+            return 0
+        rel = getattr(self, "_released", set())
+        return sum(p.data.numel() * p.data.element_size() for k, p in pk.items() if k not in rel)
+
+    @property
+    def released_bytes(self):
+        """Bytes of row-major weight tensors currently released (their streaming-layout copy is the one resident copy)."""
+        return sum(self._by_id[k].shape[0] * self._by_id[k].shape[1] * self._by_id[k].element_size()
+                   for k in getattr(self, "_released", ()))
+
+    @packed_bytes.setter
+    def packed_bytes(self, v):          # legacy assignment in _pack_weights: ignored (the property is computed)
+        pass
+
+    # ------------------------------------------------------------------ one resident copy per weight (round 6)
+    def _decode_hows(self, role, N, K, int8, M, packed=True):
+        """The implementations a decode / verify step of M rows may run this weight on ("fused" | "split" | "block" |
+        "skinny" | "lib"), assuming a streaming-layout copy exists iff `packed` -- the decisions of _std_step /
+        _proj_add_norm / _linear, through the same policy and shape-support functions, without running anything."""
+        from .gemm_policy import choose, use_split
+        pk = True if packed else None
+        tp = self.process_group is not None
+        l0 = self.layers[0]
+
+        def resid_fused(w):          # is the residual epilogue (-> a DEFERRED norm for its consumer) taken for this projection?
+            n, k = w.shape
+            return not tp and w.dtype != torch.int8 and self._fused_ok(M, n, k, True, False, "resid", False)
+        if role == "w13":
+            pros = {resid_fused(l0.attention.wo.weight)}                       # its input comes from the wo sub-layer
+            return {self._linear_how(M, N, K, True, int8, pk, "swiglu", pro) for pro in pros}
+        if role == "wqkv":
+            pros = {False, resid_fused(l0.feed_forward.w2.weight)}             # layer 0 reads a materialised norm
+            hows = set()
+            for pro in pros:
+                fused = self.config.head_dim in (64, 128) and self._fused_ok(M, N, K, pk, int8, "qkv", pro)
+                hows.add("fused" if fused else self._linear_how(M, N, K, False, int8, pk, "plain", False))
+            return hows
+        if role in ("wo", "w2"):
+            if not tp and self._fused_ok(M, N, K, pk, int8, "resid", False):
+                return {"fused"}
+            if not tp and pk is not None and not int8 and use_split(M, N, K, "resid") and ops.fused_split_supported(M, N, K):
+                return {"split"}
+            if not tp:
+                how = choose(M, N, K, False, int8, pk is not None, "resid")
+                if how == "block" and ops.linear_block_supported(M, N, K):
+                    return {"block"}
+                if how in ("skinny", "block") and ops.linear_add_rmsnorm_supported(M, N, K):
+                    return {"skinny"}
+        return {self._linear_how(M, N, K, False, int8, pk, "plain", False)}          # wo / w2 fall-through, lm head
+
+    def _wants_packed(self, role, w):
+        """A streaming-layout copy of this weight?  With known decode row counts: iff some step of this engine runs it on a
+        hand-written kernel; unknown: gemm_policy.want_packed (any row count 1..256)."""
+        from .gemm_policy import want_packed, _MODE, _PACKED
+        N, K = w.shape
+        int8 = w.dtype == torch.int8
+        if self.decode_rows is None or _MODE != "auto" or int8:
+            return want_packed(N, K, role == "w13", int8)
+        if _PACKED == "0" or K % 64:
+            return False
+        return any(self._decode_hows(role, N, K, int8, M) - {"lib"} for M in self.decode_rows if M <= 256)
+
+    def _rowmajor_in_decode(self, w):
+        """Does some decode / verify step of this engine hand the ROW-MAJOR tensor of `w` to a kernel (the library GEMM)?"""
+        role, _ = self._roles[id(w)]
+        if self._packed.get(id(w)) is None or w.dtype == torch.int8 or self.decode_rows is None:
+            return True
+        N, K = w.shape
+        return any(M > 256 or "lib" in self._decode_hows(role, N, K, False, M) for M in self.decode_rows)
+
+    def release_rowmajor(self):
+        """After prefill: free the row-major tensor of every weight that decode only ever reads in the streaming layout
+        (every packed weight used to be held twice, 16.9 GB at configs[2]).  The Parameter objects stay
+        (same id, shape and dtype: a zero-stride view of one element) so that every look-up keyed on them keeps working;
+        restore_rowmajor() re-materialises them from the streaming copy before the next prefill.  MAGICDEC_KEEP_ROWMAJOR=1
+        switches this off."""
+        import os
+        if not getattr(self, "_packed", None) or os.environ.get("MAGICDEC_KEEP_ROWMAJOR", "0") == "1":
+            return 0
+        freed = 0
+        for k, w in self._by_id.items():
+            if k in self._released or self._rowmajor_in_decode(w):
+                continue
+            N, K = w.shape
+            fake = torch.empty(1, dtype=w.dtype, device=w.device).expand(N, K)
+            role, i = self._roles[k]
+            freed += N * K * w.element_size()
+            if role == "w13":
+                ff = self.layers[i].feed_forward
+                inter = N // 2
+                w.set_(fake)
+                ff.w1.weight.data = fake[:inter]
+                ff.w3.weight.data = fake[inter:]
+            else:
+                w.data = fake
+            self._released.add(k)
+        return freed
+
+    def restore_rowmajor(self):
+        """Before a prefill: every released row-major tensor back from its streaming-layout copy (one permute each)."""
+        for k in list(getattr(self, "_released", ())):
+            w = self._by_id[k]
+            rows = self._packed[k].unpack().contiguous()
+            role, i = self._roles[k]
+            if role == "w13":
+                ff = self.layers[i].feed_forward
+                inter = rows.shape[0] // 2
+                w.set_(rows)
+                ff.w1.weight.data = w[:inter]
+                ff.w3.weight.data = w[inter:]
+            else:
+                w.data = rows
+            self._released.discard(k)
+
+    def _resident(self, w):
+        """The row-major tensor of `w` for a library GEMM; a released one is unpacked for this call only (a decode step the
+        policy prediction did not foresee: correct, slow, and reported once)."""
+        if id(w) in getattr(self, "_released", ()):
+            if not getattr(self, "_warned_transient", False):
+                self._warned_transient = True
+                print(f"[magicdec_amd] a library GEMM needs the released row-major weight {tuple(w.shape)} in a decode step "
+                      f"of {getattr(self, '_last_M', '?')} rows (not among decode_rows={self.decode_rows}): unpacked per call")
+            return self._packed[id(w)].unpack()
+        return w
 
     # ------------------------------------------------------------------ building blocks
     def _reduce(self, y, group):
@@ -404,6 +542,7 @@ class Transformer(nn.Module):
             x2d = pro.h
         M, K = x2d.shape
         N = w.shape[0]
+        self._last_M = M
         swiglu = swiglu_w13 is not None
         pk = self._packed.get(id(w))
         kind = "swiglu" if swiglu else ("resid" if resid is not None else "plain")
@@ -429,11 +568,29 @@ class Transformer(nn.Module):
         if w.dtype == torch.int8:      # WeightOnlyInt8Linear.forward (Engine/quantize.py:84-86), dequantised on the fly
             h = F.linear(x2d, w.to(dtype=x2d.dtype)) * scales
         else:
-            h = F.linear(x2d, w, bias)
+            h = F.linear(x2d, self._resident(w), bias)
         if swiglu:
             inter = N // 2
             return ops.silu_mul(h[:, :inter], h[:, inter:])
         return h
+
+    def _linear_how(self, M, N, K, swiglu, int8, pk, kind, has_pro):
+        """Which implementation `_linear` ends up on for this shape: "fused" | "block" | "skinny" | "lib" -- the same
+        sequence of policy and shape-support checks, without running anything (release_rowmajor's prediction)."""
+        from .gemm_policy import choose
+        how = choose(M, N, K, swiglu, int8, pk is not None, kind, has_pro and swiglu)
+        if how == "fused" and ops.fused_linear_supported(M, N, K):
+            return "fused"
+        if how == "block" and ops.linear_block_supported(M, N, K, swiglu):
+            return "block"
+        if how in ("fused", "skinny", "block") and ops.linear_supported(M, N, K, swiglu):
+            return "skinny"
+        return "lib"
+
+    def _fused_ok(self, M, N, K, pk, int8, kind, absorbs_norm):
+        from .gemm_policy import choose
+        return (pk is not None and not int8 and choose(M, N, K, False, False, True, kind, absorbs_norm) == "fused"
+                and ops.fused_linear_supported(M, N, K))
 
     def _fused_here(self, x2d, w, kind, absorbs_norm=False):
         """Does the fused kernel serve the linear `w` with epilogue `kind` ("qkv" | "resid") for these rows?

@@ -142,11 +142,15 @@ def repeak_head_(model, miss):
     world = getattr(model, "world_size", None) or 1
     row0 = rank * rows if world > 1 else 0
     new = _peaked_head_rows(e, seed, emb_rms, peak, miss, row0, rows).to(w.dtype)
-    w.data.copy_(new)
+    released = id(w) in getattr(model, "_released", ())      # row-major tensor released after prefill: one resident copy
+    if not released:
+        w.data.copy_(new)
     pk = getattr(model, "_packed", {}).get(id(w))
     if pk is not None:
         from .. import ops
-        pk.data.copy_(ops.PackedWeight(w.data).data)
+        pk.data.copy_(ops.PackedWeight(new).data)
+    elif released:
+        raise RuntimeError("repeak_head_: the head's row-major tensor is released and it has no streaming copy")
 
 
 def _load(transformer_cls, checkpoint_path, device, precision, use_tp, rank_group, group, seed=1234, is_draft=False):

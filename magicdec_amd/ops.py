@@ -301,6 +301,20 @@ class PackedWeight:
         # [t, j, s, kh, e] -> [t, s, kh, j, e]
         self.data = rows.view(t, 32, K // 16, 2, 8).permute(0, 2, 3, 1, 4).contiguous()
 
+    def unpack(self):
+        """The row-major [N, K] tensor this copy was built from (the inverse permute: plumbing).  Used to re-materialise
+        a row-major weight that was released after prefill (Transformer.release_rowmajor): the streaming layout is then
+        the ONE resident copy of the weight."""
+        t, K = self.data.shape[0], self.K
+        rows = self.data.permute(0, 3, 1, 2, 4).reshape(t, 32, K)      # [t, s, kh, j, e] -> [t, j, (s, kh, e)]
+        if not self.swiglu:
+            return rows.view(t * 32, K)[:self.N] if t * 32 != self.N else rows.view(t * 32, K)
+        inter = self.N // 2
+        out = torch.empty((self.N, K), dtype=self.data.dtype, device=self.data.device)
+        out[:inter].copy_(rows[:, :16].reshape(t * 16, K)[:inter])
+        out[inter:].copy_(rows[:, 16:].reshape(t * 16, K)[:inter])
+        return out
+
 
 def linear(x, weight, bias=None, scales=None, swiglu=False, workspace: "AttnWorkspace" = None, out=None,
            pro: "DeferredNorm" = None):

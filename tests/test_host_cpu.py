@@ -1262,7 +1262,12 @@ def test_gemm_policy_encodes_the_measured_ab_table():
     c = lambda M, N, K, kind, norm=False: g.choose(M, N, K, kind == "swiglu", False, True, kind, norm)
     # 1B draft model at TP1 (M = 64; two-token step M = 128)
     assert c(64, 3072, 2048, "qkv") == "fused" and c(64, 2048, 2048, "resid") == "fused"
-    assert c(64, 16384, 2048, "swiglu") == "skinny" and c(64, 16384, 2048, "swiglu", True) == "fused"
+    # round 6 (profiles/r06_fused_pro22_ab.txt): 2 x 2 tiles re-read the weights once per PAIR of M tiles -- the 1B w1|w3 is
+    # fused with and without the absorbed norm at 64 rows (18.4-18.9 / 20.3 us against md_linear's 22.8-23.2 / 24.8) and,
+    # with the norm, at the 128 rows of the two-token step (32.0 against ~31 for library + rmsnorm + SiLU*mul launches:
+    # a tie that frees the weight's row-major copy); without the norm 128 rows stay on the library
+    assert c(64, 16384, 2048, "swiglu") == "fused" and c(64, 16384, 2048, "swiglu", True) == "fused"
+    assert c(128, 16384, 2048, "swiglu", True) == "fused" and c(128, 16384, 2048, "swiglu") == "lib"
     assert c(64, 2048, 8192, "resid") == "lib" and c(128, 3072, 2048, "qkv") == "fused"
     assert c(64, 128256, 2048, "plain") == "skinny"
     # its TP4 shards and the 8B model's TP8 shards at M = 64: everything fused
@@ -1324,3 +1329,73 @@ def test_iteration_hook_runs_after_the_body_and_before_the_host_read():
     st.before_host_read = None
     st.flags.zero_()
     assert harness._iterate(None, None, st, lambda f: None, None) == (False, False)
+
+
+def test_one_resident_copy_per_weight_release_and_restore():
+    """every weight a hand-written kernel may serve used to be held TWICE (streaming layout +
+    row-major: 16.9 GB at configs[2]).  Now (a) only weights that some step of THIS engine runs on a hand-written kernel
+    are packed (the back-end passes its decode row counts), (b) after prefill the row-major tensor of every weight that
+    decode reads in the streaming layout only is released (Transformer.release_rowmajor; the Parameter objects stay), and
+    (c) the next prefill gets them back bit-exactly from the streaming copy (restore_rowmajor).  Host test of the
+    bookkeeping on CPU tensors (`_pack_weights(force=True)`; no kernel runs): the 1B draft's shapes end with ZERO
+    duplicated bytes, an 8B layer keeps exactly its wo (library GEMM at 256 rows, fused kernel at 64)."""
+    import torch
+    from magicdec_amd.Engine import gemm_policy as g
+    from magicdec_amd.Engine import model_core
+    if g.mode() != "auto" or g.fused_mode() != "auto" or g.block_mode() != "auto" or os.environ.get("MAGICDEC_SPLIT", "auto") != "auto":
+        pytest.skip("policy overridden by the environment")
+
+    def build(name, rows, **cfg):
+        model_core.transformer_configs[name] = dict(block_size=4096, n_layer=1, vocab_size=4096, rope_base=500000.0, **cfg)
+        try:
+            torch.manual_seed(0)
+            m = model_core.Transformer.from_name(name).to(torch.bfloat16)
+            for p_ in m.parameters():
+                p_.data.normal_(0, 0.02)
+            m.setup_caches(num_pages=2, decode_rows=rows)
+            m._pack_weights(force=True)
+            return m
+        finally:
+            model_core.transformer_configs.pop(name, None)
+
+    # ---- the 1B draft's layer shapes, decode rows B = 64 and the two-token step
+    m = build("dedupe1b", (64, 128), n_head=32, n_local_heads=8, dim=2048, intermediate_size=8192)
+    lay = m.layers[0]
+    ws = {"wqkv": lay.attention.wqkv.weight, "wo": lay.attention.wo.weight, "w13": m._w13[0],
+          "w2": lay.feed_forward.w2.weight, "head": m.output.weight}
+    assert all(id(w) in m._packed for w in ws.values())
+    before = {k: w.detach().clone() for k, w in ws.items()}
+    w1_before = lay.feed_forward.w1.weight.detach().clone()
+    total = sum(p.data.numel() * 2 for p in m._packed.values())
+    assert m.packed_bytes == total
+    freed = m.release_rowmajor()
+    assert m.packed_bytes == 0 and freed == total and len(m._released) == 5       # nothing is held twice in decode
+    for k, w in ws.items():
+        assert w.shape == before[k].shape and w.stride() == (0, 0) and id(w) in m._packed, k     # same object, no storage
+    assert lay.feed_forward.w1.weight.stride() == (0, 0)
+    # a library call on a released weight (a row count nobody announced) still computes the right thing
+    x = torch.randn(3, 2048).to(torch.bfloat16)
+    assert torch.equal(torch.nn.functional.linear(x, m._resident(ws["wo"])), torch.nn.functional.linear(x, before["wo"]))
+    m.restore_rowmajor()
+    assert not m._released and m.packed_bytes == total
+    for k, w in ws.items():
+        assert torch.equal(w.detach(), before[k]), k
+    assert torch.equal(lay.feed_forward.w1.weight.detach(), w1_before)
+    assert lay.feed_forward.w1.weight.data_ptr() == m._w13[0].data_ptr()            # w1 / w3 are views of w13 again
+    assert m.release_rowmajor() == total and m.release_rowmajor() == 0              # idempotent
+
+    # ---- an 8B target layer: 64-row autoregressive steps, (128,) 256-row verify
+    m = build("dedupe8b", (64, 128, 256), n_head=32, n_local_heads=8, dim=4096, intermediate_size=14336)
+    lay = m.layers[0]
+    assert id(lay.attention.wqkv.weight) not in m._packed       # library GEMM at 64, 128 and 256 rows: never packed
+    assert id(lay.attention.wo.weight) in m._packed and id(m._w13[0]) in m._packed
+    m.release_rowmajor()
+    assert id(lay.attention.wo.weight) not in m._released       # fused at 64 rows, library at 256: both layouts in decode
+    assert id(m._w13[0]) in m._released and id(lay.feed_forward.w2.weight) in m._released
+    # what decode reads in BOTH layouts stays held twice: wo, and this test's 4096-row head (library at 256 rows; the real
+    # 128 256-row head runs on md_linear / md_linear_block at every row count)
+    assert set(m._packed) - m._released == {id(lay.attention.wo.weight), id(m.output.weight)}
+    assert m.packed_bytes == 2 * 4096 * 4096 * 2
+    # without announced row counts nothing is released (any row count may come)
+    m2 = build("dedupe_any", None, n_head=32, n_local_heads=8, dim=2048, intermediate_size=8192)
+    assert m2.release_rowmajor() == 0 and m2.packed_bytes > 0
