@@ -277,7 +277,7 @@ int md_linear_add_rmsnorm(const void* x, int64_t ldx, const void* w, int w_dtype
  * epilogue: deterministic).  Epilogues and rounding points are md_linear's (MD_EPI_NONE / MD_EPI_SWIGLU);
  * md_linear_block_add_rmsnorm is md_linear_add_rmsnorm on this kernel ((h, y) = (resid + o, rmsnorm(h) * w): the combine
  * launch of md_linear_add_rmsnorm, same rounding points).  The narrow projections of an M = 256 step (wqkv, wo) stay on
- * md_linear_fused / the library: a K split over ~256 workgroups costs them more than it saves (DESIGN.md section 3.6).
+ * md_linear_fused / the library: a K split over ~256 workgroups costs them more than it saves (DESIGN.md section 3.3).
  * workspace: md_linear_block_workspace_bytes(M, N, K, force_split) bytes, 16-B aligned (force_split = 1 for the
  * add_rmsnorm form, whose epilogue always runs in the combine launch). */
 int md_linear_block_supported(int M, int N, int K, int epilogue);

@@ -1239,7 +1239,7 @@ int launch_prefill_kt(const AttnParams& p, int grid, hipStream_t st) {
 // same box (profiles/r03_prefill_mfma32_ab.txt; B = 64, 128 tokens x 32 heads vs 16 K keys, TFLOP/s): D = 128: 668 (16x16
 // kernel, 32 keys) -> 778 (32) -> 805 (64) -> 874 (128); D = 64: 712 -> 729 (64), 667 (128).
 // Dev knob (md_debug_set_prefill_mfma32 / MAGICDEC_PREFILL_MFMA32): -1 = this rule, 0 = the 16x16x32 kernel, 32 | 64 | 128 forced
-// (halved until it divides the page size), 129 = first V pairing.  (The two timing ablations of DESIGN.md 3.5 -- no
+// (halved until it divides the page size), 129 = first V pairing.  (The two timing ablations of docs/DESIGN_r1_r5_lab_notes.md 3.5 -- no
 // softmax / no P.V, wrong results by construction -- were removed after the measurement: VERDICT r3 weak #8.)
 int g_prefill_mfma32 = -1;
 

@@ -172,7 +172,7 @@ __device__ __forceinline__ int64_t kv_elem_offset(const KvTable& t, int b, int r
 // M tiles of the same weight tile.
 // MT x NT = 32-row x 32-column MFMA tiles per workgroup (round 4).  What a CU has to ingest is W x (M tiles that
 // re-read it) + the x slab x (column tiles that re-read it), and a CU ingests ~50 GB/s whatever the kernel
-// (DESIGN.md 3.6): with 1 x 1 tiles the 1B w1|w3 at M = 64 (67 MB of W) moves 134 MB of W (two M tiles) + 134 MB of x
+// (DESIGN.md 3.3): with 1 x 1 tiles the 1B w1|w3 at M = 64 (67 MB of W) moves 134 MB of W (two M tiles) + 134 MB of x
 // (512 column tiles x 256 KB) = 1.05 MB per CU = the measured 24.5 us; a 2 x 2 tile (64 rows x 64 columns, one
 // workgroup per CU) halves both.  Each K-slice wave then owns 2 x 2 accumulators, two W fragment streams and a 64-row
 // activation image; the summation order over the K slices (wave order) and every epilogue are unchanged, so the bits
@@ -185,7 +185,7 @@ __global__ __launch_bounds__(64 * NW, MT * NT > 1 ? 2 : 4) void tile_gemm_kernel
     // first load, +2.4 us per activation chunk between "landed" and "staged" (four wavefronts per SIMD normalising at
     // once, 11 vector instructions per dword), and every column tile normalising the same rows (512 x).  The 2 x 2 form
     // halves the last; it used to sit at 256 registers and spill.  A CU keeps ~64 KB of loads in flight whoever issues
-    // them (DESIGN.md 3.4), so 8 wavefronts need 8 KB each, not 32: the W ring of this form is FOUR deep (kRD), which
+    // them (DESIGN.md 3.3), so 8 wavefronts need 8 KB each, not 32: the W ring of this form is FOUR deep (kRD), which
     // frees 32 registers; the row scales' partial sums are requested FIRST, the W ring and the first activation chunk
     // behind them, and the workgroup meets at a bare s_barrier (no vmcnt(0) drain); the norm weights of a chunk are
     // unpacked once, both roundings are one v_cvt_pk_bf16_f32.

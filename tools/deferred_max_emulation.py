@@ -7,7 +7,7 @@ data and with keys spiked against some queries (late large maxima).
 
     python tools/deferred_max_emulation.py
 
-Result: thr <= 8 leaves the error where it is (0.100 -> 0.109 of the bound; spiked: 0.717 unchanged),
+Result (docs/DESIGN_r1_r5_lab_notes.md 5.1): thr <= 8 leaves the error where it is (0.100 -> 0.109 of the bound; spiked: 0.717 unchanged),
 thr = 11.5 reaches 1.1 on the spiked data."""
 import math
 

@@ -1,5 +1,5 @@
 // What can one CU ingest?  (round 4: every M >= 32 GEMM of this repo sits at ~50 GB/s per CU once an activation slab is
-// re-read through L2 beside a weight stream -- DESIGN.md 3.6.)  Each workgroup (NW waves) streams `bytes_per_wg` from a
+// re-read through L2 beside a weight stream -- DESIGN.md 3.3.)  Each workgroup (NW waves) streams `bytes_per_wg` from a
 // buffer with 16-byte loads, DEPTH loads in flight per wave, and adds the dwords up (so nothing is optimised away).
 //   mode 0: every workgroup reads the SAME 2 MiB (L2-resident, like x)        mode 1: disjoint ranges (HBM, like W)
 //   mode 2: half of the waves read the shared 2 MiB, the other half disjoint ranges (the GEMM's mix)

@@ -9,7 +9,7 @@
 #   4. the whole -m gpu suite's parity report
 # usage: tools/profile_round.sh <tag>      outputs: gpurun_out/<tag>_*
 set -u
-TAG=${1:-r05}
+TAG=${1:-r06}
 OUT=$PWD/gpurun_out
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
@@ -39,6 +39,11 @@ timeout 400 rocprofv3 --kernel-trace --stats --output-format csv rocpd -d /tmp/p
     python3 bench.py --workload cfg2 --weights peaked --steps 20 --warmup 5 --no-cpu-baseline --no-pmc > $OUT/${TAG}_prof_cfg2.log 2>&1
 DB=$(find /tmp/prof_c -name "*.db" | head -1)
 [ -n "$DB" ] && python tools/iter_breakdown.py $DB $OUT/${TAG}_bench_cfg2_iter_breakdown.csv > /dev/null
+# round 6: the GEMM A/Bs behind Engine/gemm_policy.py's new rules and the phase timestamps behind DESIGN.md 3.3's model
+timeout 300 python tools/split_bench.py > $OUT/${TAG}_split_ab.txt 2>&1
+timeout 300 python tools/fused_bench.py --only "1B/1" --pro 1 --tiles 1 > $OUT/${TAG}_fused_pro22_ab.txt 2>&1
+timeout 300 python tools/fused_bench.py --only "8B/1 w" --tiles 1 >> $OUT/${TAG}_fused_pro22_ab.txt 2>&1
+timeout 300 python tools/tile_timing.py > $OUT/${TAG}_tile_phase_timing.txt 2>&1
 timeout 300 python tools/snapkv_bench.py --dist all > $OUT/${TAG}_snapkv_bench.txt 2>&1
 timeout 200 python tools/ar_bench.py 2>&1 | grep " x " > $OUT/${TAG}_ar_bench.txt
 for f in emulated_tp8 emulated_tp8_fused_ar bench_cfg2; do grep '^{"metric"' $OUT/${TAG}_$f.log > $OUT/${TAG}_$f.json; done
@@ -49,6 +54,6 @@ echo "suite rc=$?"; tail -1 $OUT/${TAG}_gpu_tests.log
 cp $OUT/parity_report.txt $OUT/${TAG}_parity_report.txt 2>/dev/null
 for f in bench_cfg3 bench_cfg3_under_rocprofv3 emulated_tp8 emulated_tp8_fused_ar bench_cfg2; do echo "== $f"; python3 -c "
 import json,sys
-l=json.load(open('$OUT/${TAG}_$f.json')); print(l['value'], l['ms_per_step'], l['autoregressive_ms_per_step'], l['speedup_vs_autoregressive'], l['roofline'], l['prefill_s']); print(l.get('cpu_baseline')); print(l['measured_acceptance_run']); print(l['speedup_condition'])"; done
+l=json.load(open('$OUT/${TAG}_$f.json')); print(l['value'], l['ms_per_step'], l['autoregressive_ms_per_step'], l['speedup_vs_autoregressive'], l['roofline'], l['prefill_s']); print(l.get('cpu_baseline')); print(l['measured_acceptance_run']); print(l.get('measured_acceptance_sweep')); print(l.get('roofline_nhd')); print(l['config'].get('packed_weight_copies_bytes'), l['config'].get('rowmajor_weight_bytes_released_after_prefill')); print(l['speedup_condition'])"; done
 grep -i snapkv $OUT/${TAG}_bench_cfg3_kernel_stats.csv | cut -c1-160
 head -12 $OUT/${TAG}_bench_cfg3_kernel_stats.csv | cut -c1-150

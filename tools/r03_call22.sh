@@ -1,6 +1,6 @@
 #!/bin/bash
 # NOTE: provenance only -- ran at commits 7a76d02 / 40f68c7 / d4fa652, where the knob values >= 1000 selected the ping-pong
-# kernel (prefill32p_attn_kernel, removed afterwards: DESIGN.md 3.5); on later commits those values fall back to the rule.
+# kernel (prefill32p_attn_kernel, removed afterwards: docs/DESIGN_r1_r5_lab_notes.md 3.5); on later commits those values fall back to the rule.
 # GPU call 22: the ping-pong prefill kernel (prefill32p_attn_kernel): parity of every variant, same-box A/B against the
 # shipped 32x32 kernels, SQ counters of the old 16x16 kernel / shipped / ping-pong.
 set -u

@@ -1,6 +1,6 @@
 #!/bin/bash
 # NOTE: provenance only -- ran at commits 7a76d02 / 40f68c7 / d4fa652, where the knob values >= 1000 selected the ping-pong
-# kernel (prefill32p_attn_kernel, removed afterwards: DESIGN.md 3.5); on later commits those values fall back to the rule.
+# kernel (prefill32p_attn_kernel, removed afterwards: docs/DESIGN_r1_r5_lab_notes.md 3.5); on later commits those values fall back to the rule.
 # GPU call 24: where the prefill kernel's time goes -- timing ablations (results wrong by construction), zero-filled data
 # (clock / power check), clocks and power sampled while the kernel runs.
 set -u
