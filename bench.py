@@ -545,7 +545,8 @@ def run(args, dev):
     # rate is ~1 - miss, and the SAME loop runs with the accept kernel's own decisions.  Each point sits beside the
     # fixed-acceptance replay at alpha = 1 - miss: equal tokens/s there shows the replay is a timing-neutral stand-in.
     acc_sweep = None
-    if on_gpu and weights.startswith("peaked") and draft is not None and hasattr(draft.model, "_peak_params"):
+    if (on_gpu and emu <= 1 and weights.startswith("peaked") and draft is not None
+            and hasattr(draft.model, "_peak_params")):          # (--emulate-tp: partial sums are not reduced, tokens are noise)
         from magicdec_amd.Engine.utils import parse_peaked, repeak_head_
         miss_cfg = parse_peaked(weights)[2]
         acc_sweep = {}
