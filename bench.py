@@ -545,17 +545,18 @@ def run(args, dev):
     # rate is ~1 - miss, and the SAME loop runs with the accept kernel's own decisions.  Each point sits beside the
     # fixed-acceptance replay at alpha = 1 - miss: equal tokens/s there shows the replay is a timing-neutral stand-in.
     acc_sweep = None
-    if (on_gpu and emu <= 1 and weights.startswith("peaked") and draft is not None
-            and hasattr(draft.model, "_peak_params")):          # (--emulate-tp: partial sums are not reduced, tokens are noise)
+    # (rank-independent condition: ranks outside the draft sub-group hold no draft model but run the same loops;
+    #  --emulate-tp: partial sums are not reduced, tokens are noise)
+    if on_gpu and emu <= 1 and weights.startswith("peaked") and drf_name is not None and not selfspec:
         from magicdec_amd.Engine.utils import parse_peaked, repeak_head_
         miss_cfg = parse_peaked(weights)[2]
         acc_sweep = {}
         for miss in (0.4, 0.3, 0.2):
-            if in_draft:
+            if in_draft and draft is not None:
                 repeak_head_(draft.model, miss)
             dt_m, tok_m = run_spec(2, sens_steps, None)
             acc_sweep[miss] = (dt_m / sens_steps, tok_m / sens_steps)
-        if in_draft:
+        if in_draft and draft is not None:
             repeak_head_(draft.model, miss_cfg)
 
     # ---- autoregressive baseline (tests/baseline_benchmark.py loop: one token per target step)
