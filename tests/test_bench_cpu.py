@@ -199,3 +199,49 @@ def test_peaked_synthetic_weights_predict_through_one_permutation(monkeypatch):
     finally:
         for name in ("peak_a", "peak_b"):            # the table is process-global: other tests compare it with the reference's
             model_core.transformer_configs.pop(name, None)
+
+
+def test_peaked_draft_with_a_miss_fraction_and_in_place_repeak(monkeypatch):
+    """bench.py --weights peaked:...:miss=f (round 6): a DRAFT model's head mispredicts a seeded fraction
+    f of the vocabulary (Engine/utils._peak_perm), the target's does not; repeak_head_ rewrites the head for another
+    fraction in place (same storage) so that bench.py can sweep the draft's acceptance rate without reloading; and the
+    acceptance bookkeeping of the line (alpha_of, acceptance_point) inverts the truncated-geometric expectation."""
+    import torch
+    import bench
+    from magicdec_amd.Engine import model_core, utils
+    assert utils.parse_peaked("peaked") == (40.0, 12.0, 0.0)
+    assert utils.parse_peaked("peaked:30:10:miss=0.25") == (30.0, 10.0, 0.25)
+    assert utils.parse_peaked("peaked:miss=0.1") == (40.0, 12.0, 0.1)
+    with pytest.raises(ValueError):
+        utils.parse_peaked("peaked:1:2:3")
+    monkeypatch.setenv("MAGICDEC_SYNTH_WEIGHTS", "peaked:40:12:miss=0.3")
+    name = "peak_miss"
+    model_core.transformer_configs[name] = dict(block_size=2048, n_layer=1, n_head=4, n_local_heads=2, dim=128,
+                                                intermediate_size=256, vocab_size=2000)
+    try:
+        heads = {}
+        for is_draft in (False, True):
+            with torch.device("meta"):
+                m = model_core.Transformer.from_name(name)
+            utils._random_init_(m, 1234, "cpu", torch.bfloat16, is_draft=is_draft)
+            heads[is_draft] = m.output.weight.detach().clone()
+        differ = (heads[True] != heads[False]).any(dim=1)
+        assert not bool(differ[:4].any())                                   # ids 0..3 stay fixed
+        frac = float(differ.float().mean())
+        assert 0.25 < frac < 0.35, frac                                     # ~30 % of the draft's rows answer to a wrong token
+        # every mis-tied row of the draft is SOME row of the target (a confident wrong prediction, not noise)
+        tgt_rows = {tuple(r.view(torch.int16).tolist()) for r in heads[False]}
+        assert all(tuple(r.view(torch.int16).tolist()) in tgt_rows for r in heads[True][differ][:50])
+        ptr = m.output.weight.data_ptr()
+        utils.repeak_head_(m, 0.0)                                          # in place: miss = 0 gives the target's head
+        assert m.output.weight.data_ptr() == ptr and torch.equal(m.output.weight, heads[False])
+        utils.repeak_head_(m, 0.3)
+        assert torch.equal(m.output.weight, heads[True])
+    finally:
+        model_core.transformer_configs.pop(name, None)
+    for a in (0.3, 0.6, 0.8, 0.95):
+        t = sum(a ** j for j in range(4))
+        assert abs(bench.alpha_of(t, 3) - a) < 1e-6
+    pt = bench.acceptance_point(0.030, 64 * 2.9, 64, 3, 2700.0, (0.0301, 64 * 2.95))
+    assert pt["tokens_per_iter_per_seq"] == 2.9 and abs(pt["ms_per_step_vs_replay"] - 0.9967) < 1e-3
+    assert abs(pt["alpha_equivalent"] - bench.alpha_of(2.9, 3)) < 1e-4 and pt["replay_at_matching_alpha"]["ms_per_step"] == 30.1
