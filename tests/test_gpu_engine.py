@@ -989,3 +989,38 @@ def test_full_depth_8b_and_1b_lockstep_token_identity(monkeypatch):
     assert iters >= 5 and rejected >= 0
     del e_t, e_d
     torch.cuda.empty_cache()
+
+
+def test_rowmajor_weights_are_released_after_prefill_and_restored_for_the_next(ckpt_dir):
+    """Round 6: after encode() the row-major tensor of every weight that the decode steps of THIS
+    engine read in the streaming layout only is released (Transformer.release_rowmajor) -- one resident copy; the next
+    encode() re-materialises them from the streaming copy.  On the HIP engine: bytes are really released, decode and
+    verify steps run on the released state, and a second encode + decode reproduces the first run's tokens and logits bit
+    for bit (the restored tensors are the originals)."""
+    e = _hip("target", ckpt_dir)
+    m = e.model
+    ids = gc.synthetic_batches()[0].to(DEV)
+    assert m.decode_rows == tuple(sorted({gc.B, 2 * gc.B, gc.B * (gc.GAMMA + 1)}))
+    total = sum(p.data.numel() * p.data.element_size() for p in m._packed.values())
+    assert total > 0 and m.packed_bytes == total and m.released_bytes == 0           # before the first prefill: both layouts
+    t1 = e.encode(ids).clone()
+    assert m.released_bytes > 0 and m.packed_bytes == total - m.released_bytes       # released at the end of encode()
+    released = set(m._released)
+    for k in released:
+        assert m._by_id[k].stride() == (0, 0)                                         # no storage behind the Parameter
+    step = e.inference(t1[:, -1:].clone()).clone()
+    lg_step = m._last_logits.clone()
+    ver = e.inference(torch.cat([t1[:, -1:], step, step, step], dim=1)).clone()      # a (gamma+1)-row verify
+    lg_ver = m._last_logits.clone()
+    t2 = e.encode(ids).clone()                                                        # restore -> prefill -> release again
+    assert set(m._released) == released
+    assert torch.equal(t1, t2)
+    assert torch.equal(e.inference(t2[:, -1:].clone()), step) and torch.equal(m._last_logits, lg_step)
+    assert torch.equal(e.inference(torch.cat([t2[:, -1:], step, step, step], dim=1)), ver)
+    assert torch.equal(m._last_logits, lg_ver)
+    # a row count nobody announced still computes (library GEMM on a per-call unpacked weight), it is only slower
+    odd = e.inference(torch.cat([t2[:, -1:], step, step], dim=1))
+    assert odd.shape == (gc.B, 3)
+    parity_report(f"[weights] one resident copy: {len(released)} of {len(m._packed)} packed weights released after prefill "
+                  f"({m.released_bytes} B), {m.packed_bytes} B still held in both layouts; re-encode reproduces tokens and "
+                  f"logits bit for bit")
