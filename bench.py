@@ -199,8 +199,11 @@ def main(device=None):
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (a launcher exported another world size)"
     if device is None:
         assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
-        torch.cuda.set_device(local_rank)
-        device = f"cuda:{local_rank}"
+        # MAGICDEC_TP_SINGLE_GPU=1 (development / rehearsal, Engine/tp.init_dist): every rank on GPU 0, gloo as the bootstrap
+        # transport -- the multi-rank control flow of this file end to end on a 1-GPU box (RCCL refuses two ranks per device)
+        dev_index = 0 if os.environ.get("MAGICDEC_TP_SINGLE_GPU", "0") == "1" else local_rank
+        torch.cuda.set_device(dev_index)
+        device = f"cuda:{dev_index}"
     line = run(args, device)
     # RCCL prints its version banner through C stdio, which is fully buffered on a pipe and would otherwise be
     # flushed at process exit, i.e. AFTER the JSON line: flush it first so that the JSON line is the last line

@@ -64,6 +64,9 @@ typedef void* md_stream_t; /* hipStream_t */
 int md_abi_version(void);
 /* Message of the calling thread's most recent error ("" if none). Host. */
 const char* md_last_error_string(void);
+/* Returns and clears the calling thread's sticky HIP runtime error (hipGetLastError) -- used by the hipGraph capture
+ * fall-back (magicdec_amd/Engine/graph.py): an invalidated capture otherwise fails the next, unrelated launch. Host. */
+int md_clear_last_hip_error(void);
 
 /* ------------------------------------------------------------------------
  * K4  mylib::update_kv  ->  flashinfer.append_paged_kv_cache

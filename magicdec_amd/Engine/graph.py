@@ -74,6 +74,34 @@ def _all_ranks_ok(backend, ok: bool) -> bool:
     return int(t.item()) == 0
 
 
+def _recover_from_failed_capture(g, home_stream):
+    """Leave the process able to launch eagerly after an invalidated capture.  `torch.cuda.graph.__exit__` ends the capture
+    first and restores the stream second: when the end itself raises (hipErrorStreamCaptureInvalidated) the capture stream
+    stays current, and the runtime's sticky error fails the next launch check ("operation failed due to a previous error
+    during capture" -- seen in the 2-rank rehearsal on one GPU, where gloo's collectives cannot be captured).  So: end the
+    capture again if it is still open, go back to the caller's stream, read the sticky error away, drain the device."""
+    try:
+        if torch.cuda.is_current_stream_capturing():
+            g.capture_end()
+    except Exception:  # noqa: BLE001 -- the end of an invalidated capture reports the invalidation once more
+        pass
+    torch.cuda.set_stream(home_stream)
+    from .. import _lib
+    for _ in range(4):                      # one read per queued error is enough; a few in case both calls left one
+        try:
+            if _lib.load().md_clear_last_hip_error() == 0:
+                break
+        except Exception:  # noqa: BLE001
+            break
+    try:
+        torch.cuda.synchronize()
+    except Exception:  # noqa: BLE001 -- torch's own check may still see (and thereby clear) the error
+        try:
+            torch.cuda.synchronize()
+        except Exception:  # noqa: BLE001
+            pass
+
+
 def run_captured(backend, key, fn, input_ids):
     kind = key[0]
     full_key = (key, tuple(input_ids.shape), tuple(getattr(backend, "paged_kv_indices").shape),
@@ -105,15 +133,16 @@ def run_captured(backend, key, fn, input_ids):
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
         err = None
+        home = torch.cuda.current_stream()
         try:
             # thread_local: the RCCL watchdog thread of torch.distributed polls hipEventQuery concurrently; in the
             # default "global" capture mode such a call from ANY thread invalidates the capture and kills the process
             # ("operation not permitted when stream is capturing", seen intermittently with a TP group)
             with torch.cuda.graph(g, capture_error_mode="thread_local"):
                 ent.static_out = fn(ent.static_in)
-        except Exception as e:  # noqa: BLE001 -- e.g. a collective this RCCL build cannot capture
+        except Exception as e:  # noqa: BLE001 -- e.g. a collective this RCCL build (or gloo) cannot capture
             err = e
-            torch.cuda.synchronize()
+            _recover_from_failed_capture(g, home)
         # Under tensor parallelism every rank captures the same step at the same point of the same program, but a
         # capture can fail on ONE rank only (an allocation, a watchdog race): a rank replaying a graph while another
         # launches eagerly still issues the same collectives in the same order, yet the choice must not depend on

@@ -37,6 +37,7 @@ class FusedLinearArgs(ctypes.Structure):
 _SIGNATURES = {
     "md_abi_version": (c_int, []),
     "md_last_error_string": (c_char_p, []),
+    "md_clear_last_hip_error": (c_int, []),
     "md_page_overflow_count": (c_int, [P, I]),
     "md_append_paged_kv": (c_int, [P, P, L, L, P, P, P, P, P, I, I, I, I, I, I, P, P, P]),
     "md_rope": (c_int, [P, P, L, L, P, P, P, P, I, I, I, I, I, P, I, P]),

@@ -95,7 +95,8 @@ def test_every_entry_point_rejects_null_arguments():
     import ctypes
     from magicdec_amd import _lib
     lib = _lib.load()
-    skip = {"md_abi_version", "md_last_error_string", "md_ar_destroy", "md_debug_attn_timing", "md_debug_attn_timing_read"}
+    skip = {"md_abi_version", "md_last_error_string", "md_ar_destroy", "md_debug_attn_timing", "md_debug_attn_timing_read",
+            "md_clear_last_hip_error"}      # (no arguments: returns the HIP runtime's sticky error code, e.g. "no device" here)
     assert lib.md_linear_supported(0, 0, 0, 0) == 0 and lib.md_linear_supported(64, 128, 256, 0) == 1
     assert lib.md_linear_fused_supported(0, 0, 0, 0) == 0 and lib.md_linear_fused_supported(64, 768, 2048, 3) == 1
     assert lib.md_linear_fused_supported(64, 770, 2048, 0) == 0 and lib.md_linear_fused_supported(300, 768, 2048, 0) == 0
