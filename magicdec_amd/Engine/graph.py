@@ -74,12 +74,25 @@ def _all_ranks_ok(backend, ok: bool) -> bool:
     return int(t.item()) == 0
 
 
+_FAILED_GRAPHS = []      # see _recover_from_failed_capture: graph objects of failed captures are never destroyed
+_CAPTURE_POISONED = [None]   # set to the reason once a capture was INVALIDATED in this process: this PyTorch build then
+#                              refuses every later capture ("Cannot register the state during capturing stage": the
+#                              default generator still believes it is being captured), so later steps do not try
+
+
 def _recover_from_failed_capture(g, home_stream):
     """Leave the process able to launch eagerly after an invalidated capture.  `torch.cuda.graph.__exit__` ends the capture
     first and restores the stream second: when the end itself raises (hipErrorStreamCaptureInvalidated) the capture stream
     stays current, and the runtime's sticky error fails the next launch check ("operation failed due to a previous error
     during capture" -- seen in the 2-rank rehearsal on one GPU, where gloo's collectives cannot be captured).  So: end the
-    capture again if it is still open, go back to the caller's stream, read the sticky error away, drain the device."""
+    capture again if it is still open, go back to the caller's stream, read the sticky error away, drain the device.
+    The graph object itself is LEAKED on purpose: the destructor of a `torch.cuda.CUDAGraph` whose capture was invalidated
+    throws ("The graph should be registered to the state", HIPGeneratorImpl::unregister_graph) -- from a destructor, i.e.
+    `terminate` -- whenever the garbage collector gets to it (reproduced: tests/test_gpu_engine.py::
+    test_a_failed_graph_capture_falls_back_to_eager_and_keeps_working)."""
+    import ctypes
+    _FAILED_GRAPHS.append(g)
+    ctypes.pythonapi.Py_IncRef(ctypes.py_object(g))      # never deallocated, not even at interpreter shutdown
     try:
         if torch.cuda.is_current_stream_capturing():
             g.capture_end()
@@ -134,15 +147,23 @@ def run_captured(backend, key, fn, input_ids):
         g = torch.cuda.CUDAGraph()
         err = None
         home = torch.cuda.current_stream()
-        try:
-            # thread_local: the RCCL watchdog thread of torch.distributed polls hipEventQuery concurrently; in the
-            # default "global" capture mode such a call from ANY thread invalidates the capture and kills the process
-            # ("operation not permitted when stream is capturing", seen intermittently with a TP group)
-            with torch.cuda.graph(g, capture_error_mode="thread_local"):
-                ent.static_out = fn(ent.static_in)
-        except Exception as e:  # noqa: BLE001 -- e.g. a collective this RCCL build (or gloo) cannot capture
-            err = e
-            _recover_from_failed_capture(g, home)
+        if _CAPTURE_POISONED[0] is not None:
+            # (the warm-up above and the agreement below still run: the ranks of a TP group must issue the same collectives)
+            err = RuntimeError(f"an earlier capture in this process was invalidated ({_CAPTURE_POISONED[0]}); this PyTorch "
+                               "build cannot capture again afterwards")
+        else:
+            try:
+                # thread_local: the RCCL watchdog thread of torch.distributed polls hipEventQuery concurrently; in the
+                # default "global" capture mode such a call from ANY thread invalidates the capture and kills the process
+                # ("operation not permitted when stream is capturing", seen intermittently with a TP group)
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                    ent.static_out = fn(ent.static_in)
+            except Exception as e:  # noqa: BLE001 -- e.g. a collective this RCCL build (or gloo) cannot capture
+                err = e
+                invalidated = "capture" in str(e).lower() and "hip error" in str(e).lower()
+                _recover_from_failed_capture(g, home)
+                if invalidated:
+                    _CAPTURE_POISONED[0] = f"step {key}: {type(e).__name__}"
         # Under tensor parallelism every rank captures the same step at the same point of the same program, but a
         # capture can fail on ONE rank only (an allocation, a watchdog race): a rank replaying a graph while another
         # launches eagerly still issues the same collectives in the same order, yet the choice must not depend on

@@ -1024,3 +1024,19 @@ def test_rowmajor_weights_are_released_after_prefill_and_restored_for_the_next(c
     parity_report(f"[weights] one resident copy: {len(released)} of {len(m._packed)} packed weights released after prefill "
                   f"({m.released_bytes} B), {m.packed_bytes} B still held in both layouts; re-encode reproduces tokens and "
                   f"logits bit for bit")
+
+
+@pytest.mark.parametrize("kind", ["python_error", "illegal_sync"])
+def test_a_failed_graph_capture_falls_back_to_eager_and_keeps_working(kind):
+    """Engine/graph.py: a decode step whose hipGraph capture fails -- (a) an exception raised by Python code inside the
+    capture, (b) an operation that is illegal while capturing and INVALIDATES it (a device synchronisation: what a
+    collective that cannot be captured does; found by a 2-rank bench rehearsal over gloo) -- must leave the back-end
+    running eagerly with the right results.  In a child process (tests/_graph_failure_worker.py): an invalidated capture
+    leaves this PyTorch build unable to capture again in the same process, which must not leak into the other tests."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "tests", "_graph_failure_worker.py"), kind],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert p.returncode == 0 and "OK" in p.stdout, p.stdout[-4000:]
+    parity_report(f"[graphs] capture failure ({kind}): " + [l for l in p.stdout.splitlines() if l.startswith("OK")][0])
