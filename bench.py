@@ -358,7 +358,9 @@ def run(args, dev):
         # group on the development box, profiles/r01_tp1rank_rccl_graphs.log; a capture failure falls back to
         # eager launching with a warning, Engine/graph.py).  A TP8 shard's step is ~10 us kernels: eager
         # launching would be host-bound by >2x.
-        args.graphs = on_gpu and os.environ.get("MAGICDEC_NO_GRAPHS", "0") != "1"
+        # (the one-GPU rehearsal mode bootstraps over gloo, whose collectives cannot be captured: eager steps there)
+        args.graphs = (on_gpu and os.environ.get("MAGICDEC_NO_GRAPHS", "0") != "1"
+                       and not (use_tp and os.environ.get("MAGICDEC_TP_SINGLE_GPU", "0") == "1"))
     if args.graphs:
         engine.compile()
         if draft is not None:
