@@ -27,6 +27,9 @@ void md_debug_set_prefill_kt(int kt, int nw);
 void md_debug_set_gemm_target_blocks(int n);
 /* md_linear: wavefronts per workgroup, 4 | 6 | 7 forced (bit-identical results); 0 = the balance rule (plan_of) */
 void md_debug_set_gemm_waves(int nw);
+/* md_linear: W prefetch ring depth of the four-wave, <= 64-row, bf16 form: 16 = the deep ring (bit-identical results, measured
+ * equal or 1-3 % slower: profiles/r06_ring_depth_ab.txt); 0 / 8 = the rule (8) */
+void md_debug_set_gemm_ring(int rd);
 /* md_linear_fused: wavefronts (K slices) per workgroup, 8 | 16; 11 / 22 = 1 x 1 / 2 x 2 MFMA tiles per workgroup with 8 K
  * slices (bit-identical results); 0 = the measured rules */
 void md_debug_set_fused_nw(int nw);

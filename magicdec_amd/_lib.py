@@ -97,6 +97,7 @@ _DEV_SIGNATURES = {
     "md_debug_set_prefill_mfma32": (None, [I]),
     "md_debug_set_gemm_target_blocks": (None, [I]),
     "md_debug_set_gemm_waves": (None, [I]),
+    "md_debug_set_gemm_ring": (None, [I]),
     "md_debug_set_fused_nw": (None, [I]),
     "md_debug_set_fused_split": (None, [I]),
     "md_debug_set_tile_timing": (None, [P]),

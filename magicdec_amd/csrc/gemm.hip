@@ -458,9 +458,29 @@ int md_internal_launch_reduce_add_rmsnorm(const float* partial, int S, int M, in
 
 namespace {
 
+int g_force_rd = 0;          // dev knob (md_debug_set_gemm_ring): 0 = the rule in launch(), 8 / 16 = forced where instantiated
+
+template <int MT, int EPI, bool W8, bool PRO, int NW, int RD>
+int launch_rd(const GemmParams& p, int n_blocks, hipStream_t st);
+
+// W ring depth (round 6, a measured NEGATIVE result kept as a dev knob).  The four-wave form requests 4 x 8 KiB per CU with
+// the 8-deep ring, half of what the six- / seven-wave forms and the tile kernel keep in flight, so a 16-deep ring (there is
+// room for it at <= 64 rows) looked like the fix for the K-split products that run four waves (the 8B w2 at 32 / 64 rows,
+// the lm heads).  tools/ring_bench.py (profiles/r06_ring_depth_ab.txt): 29.6 vs 29.5, 32.9 vs 33.6, 17.8 vs 18.5, lm heads
+// 101 vs 104 / 184 vs 188 us -- equal or 1-3 % slower, bits identical.  More loads per WAVE are not accepted any faster
+// (the tile kernel's phase timestamps show the same: a wave that issues 32 loads is still issuing them microseconds
+// later); what helps is more waves or fewer bytes per CU.  The rule stays at 8; md_debug_set_gemm_ring(16) selects the
+// deep form for the A/B.
 template <int MT, int EPI, bool W8, bool PRO, int NW>
 int launch(const GemmParams& p, int n_blocks, hipStream_t st) {
-    constexpr int RD = 8;
+    if constexpr (MT <= 2 && NW == 4 && !W8) {
+        if (g_force_rd == 16) return launch_rd<MT, EPI, W8, PRO, NW, 16>(p, n_blocks, st);
+    }
+    return launch_rd<MT, EPI, W8, PRO, NW, 8>(p, n_blocks, st);
+}
+
+template <int MT, int EPI, bool W8, bool PRO, int NW, int RD>
+int launch_rd(const GemmParams& p, int n_blocks, hipStream_t st) {
     const size_t lds = (size_t)2 * MT * 32 * kPitch + (PRO ? MT * 32 * 4 : 0);
     auto k = skinny_gemm_kernel<MT, EPI, W8, RD, PRO, NW>;
     if (lds > 64 * 1024) {
@@ -528,6 +548,7 @@ int md_internal_launch_skinny_reduce(const float* partial, int S, int M, int N, 
 #ifdef MD_DEV_KNOBS
 extern "C" void md_debug_set_gemm_target_blocks(int n) { g_target_blocks = n > 0 ? n : 256; }
 extern "C" void md_debug_set_gemm_waves(int nw) { g_force_nw = (nw == 4 || nw == 6 || nw == 7) ? nw : 0; }
+extern "C" void md_debug_set_gemm_ring(int rd) { g_force_rd = (rd == 8 || rd == 16) ? rd : 0; }
 #endif
 
 extern "C" size_t md_linear_workspace_bytes(int M, int N, int K, int epilogue) {
