@@ -116,11 +116,13 @@ class _BackendBase:
     def _qo(self, n):
         return self.qo_indptr * n
 
-    def _decode_rows(self, *per_request):
-        """Row counts of this engine's decode / verify steps: batch x (1, 2 -- the two-token draft step --, dec_len ...);
-        the model packs / releases weight copies for exactly these (Transformer.setup_caches(decode_rows=...))."""
+    def _decode_rows(self, *per_request, two_token_step=True):
+        """Row counts of this engine's decode / verify steps: batch x (1, dec_len ..., and 2 -- the two-token step after an
+        all-accept iteration -- for the engines that DRAFT with it: the stand-alone draft models and the StreamingLLM
+        self-speculation engine; a longspec target and the SnapKV self-speculation engine never see it); the model packs /
+        releases weight copies for exactly these (Transformer.setup_caches(decode_rows=...))."""
         B = self.batch_size
-        return sorted({B * int(n) for n in (1, 2) + tuple(per_request) if n})
+        return sorted({B * int(n) for n in (1,) + ((2,) if two_token_step else ()) + tuple(per_request) if n})
 
     def _prefill_begin(self):
         """Prefill-sized products run on the library GEMM over the row-major weights: re-materialise the ones released
@@ -185,11 +187,12 @@ class SnapKVTargetBackend(_BackendBase):
                                     draft_num_pages=self.draft_num_pages, draft_budget=draft_budget,
                                     window_size=window_size, max_positions=max_seq_length + 256, kv_dtype=kv_dtype,
                                     kv_layout=kv_layout,
-                                    decode_rows=self._decode_rows(self.dec_len, getattr(self, "draft_dec_len", None)))
+                                    decode_rows=self._decode_rows(self.dec_len, getattr(self, "draft_dec_len", None),
+                                                                 two_token_step=False))
         else:
             self.model.setup_caches(num_pages=self.max_num_pages, page_size=PAGE_SIZE,
                                     max_positions=max_seq_length + 256, kv_dtype=kv_dtype, kv_layout=kv_layout,
-                                    decode_rows=self._decode_rows(self.dec_len))
+                                    decode_rows=self._decode_rows(self.dec_len, two_token_step=False))
 
     @torch.no_grad()
     def clear_kv(self):

@@ -54,6 +54,8 @@ FUSED_QKV_M256_MAX_L2_BYTES = 110e6
 # 12.0 against 14.1 incl. the add + norm behind it); w2 (14.7 MB: 17.1 vs 16.9) and everything wider stay on the library
 FUSED_M256_SWIGLU_MAX_BYTES = 32e6
 FUSED_M256_NARROW_MAX_BYTES = 5e6
+FUSED_M256_RESID_T22_MAX_BYTES = 34e6
+_WO256 = os.environ.get("MAGICDEC_WO256", "1")        # "0": the 8B wo at 256 rows stays on the library (A/B switch)
 # a linear that can ALSO absorb the RMSNorm in front of it (deferred norm: its input is the un-normalised h of a fused
 # residual epilogue) saves that launch (~5 us + a boundary): the 1B w1|w3 at M = 64 (134 MB of tile traffic, 22.2 us
 # against md_linear's 21.9) then wins on the fused kernel
@@ -146,7 +148,14 @@ def use_fused(M: int, N: int, K: int, kind: str = "plain", absorbs_norm: bool = 
     if kind == "swiglu":
         return N * K * 2 <= FUSED_M256_SWIGLU_MAX_BYTES and K <= FUSED_MAX_K
     if kind in ("plain", "resid"):
-        return N * K * 2 <= FUSED_M256_NARROW_MAX_BYTES and K <= FUSED_MAX_K      # measured at K = 512 only
+        if N * K * 2 <= FUSED_M256_NARROW_MAX_BYTES and K <= FUSED_MAX_K:         # measured at K = 512 only
+            return True
+        # round 6: the 8B wo at 256 rows on 2 x 2 tiles (4 x 64 tile groups = 256 workgroups) WITH its residual add is a
+        # measured tie with the library + add/norm launch (25.2-25.9 vs 24.9-25.0 us, profiles/r06_fused_pro22_ab.txt;
+        # in-trace A/B profiles/r06_ab_wo256_*): taking it leaves NO weight of configs[2] held in two layouts during
+        # decode (the library read the row-major tensor) and one library kernel fewer in the verify pass
+        return (_WO256 != "0" and kind == "resid" and t22 and K <= FUSED_MAX_K
+                and N * K * 2 <= FUSED_M256_RESID_T22_MAX_BYTES)
     return kind == "qkv" and l2_bytes <= FUSED_QKV_M256_MAX_L2_BYTES and K <= FUSED_MAX_K
 
 
