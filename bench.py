@@ -645,8 +645,7 @@ def run(args, dev):
                                     "0": "off", "1": "forced on"}[gemm_policy.fused_mode()],
                    # weights held TWICE during decode (streaming layout + row-major): after prefill the row-major tensor of
                    # every weight that decode reads in the streaming layout only is released (Transformer.release_rowmajor);
-                   # what remains is read in both layouts at different row counts (the 8B wo: fused kernel at 64 rows,
-                   # library GEMM at 256)
+                   # what remains is read in both layouts at different row counts (configs[2]: nothing)
                    "packed_weight_copies_bytes": int(getattr(engine.model, "packed_bytes", 0)
                                                      + (getattr(draft.model, "packed_bytes", 0) if draft is not None
                                                         else 0)),
