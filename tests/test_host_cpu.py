@@ -1308,6 +1308,10 @@ def test_gemm_policy_encodes_the_measured_ab_table():
         assert not g.use_split(64, 4096, 14336, "resid") and not g.use_split(256, 2048, 8192, "resid")
         assert not g.use_split(64, 2048, 2048, "resid") and not g.use_split(64, 2048, 8192, "plain")
         assert g.want_packed(2048, 8192)
+    # round 6 (profiles/r06_shard70b_ab.txt): the 70B model's TP-8 shards at the 128 rows of configs[3]'s verify -- w2 on
+    # 2 x 2 tiles and the deep narrow wqkv go to the tile kernel; at 32 rows (40 workgroups) the qkv shard stays on the library
+    assert c(128, 8192, 3584, "plain") == "fused" and c(128, 1280, 8192, "qkv") == "fused"
+    assert c(32, 1280, 8192, "qkv") == "lib" and c(128, 7168, 8192, "swiglu") == "skinny"
     # autoregressive 8B steps (M = 64)
     assert c(64, 6144, 4096, "qkv") == "lib" and c(64, 4096, 4096, "resid") == "fused"
     assert c(64, 28672, 4096, "swiglu") == "skinny" and c(64, 4096, 14336, "resid") == "skinny"
