@@ -48,6 +48,7 @@ MIN_STREAM_BYTES_M128 = 100e6
 #     19.8); wo / w1|w3 / w2 shards are served faster by the library (14.4 vs 14.1, 30.2 vs 22.9, 23.0 vs 16.6).
 FUSED_MAX_L2_BYTES = 70e6
 FUSED_MAX_L2_BYTES_T22 = 120e6
+FUSED_DEEP_SWIGLU_T22_MAX_L2_BYTES = 150e6
 _SHARD70B = os.environ.get("MAGICDEC_SHARD70B", "1")     # "0": without the two round-6 rules for the 70B shards (A/B switch)
 FUSED_MAX_K = 4096
 FUSED_QKV_M256_MAX_L2_BYTES = 110e6
@@ -146,7 +147,7 @@ def use_fused(M: int, N: int, K: int, kind: str = "plain", absorbs_norm: bool = 
            and (N // 64) * ((m_tiles + 1) // 2) >= 192 and (not absorbs_norm or (kind == "swiglu" and K <= 4096)))
     l2_bytes = ((m_tiles + 1) // 2 if t22 else m_tiles) * N * K * 2
     if M <= 128:
-        # round 6, the 70B model's TP-8 shards at the 128 rows of configs[3]'s verify (tools/shard70b_bench.py,
+        # round 6, the 70B model's TP-8 shards at the 128 rows of configs[3]'s verify (tools/shard_bench.py,
         # profiles/r06_shard70b_ab.txt): w2 (8192 x 3584, 2 x 2 tiles) 22.0 us against 24.4 for the library -- wide products
         # on 2 x 2 tiles may re-read up to 120 MB; wqkv (1280 x 8192) 16.7 against 21.1 + the rope/append launch -- a deep
         # NARROW qkv shard is fused up to K = 8192 once >= 128 tile workgroups exist (at 32 rows, 40 workgroups, the
@@ -155,8 +156,15 @@ def use_fused(M: int, N: int, K: int, kind: str = "plain", absorbs_norm: bool = 
         lim = FUSED_MAX_L2_BYTES_WITH_NORM if absorbs_norm else (FUSED_MAX_L2_BYTES_T22 if wide else FUSED_MAX_L2_BYTES)
         if l2_bytes <= lim and K <= FUSED_MAX_K:
             return True
-        return (_SHARD70B != "0" and kind == "qkv" and FUSED_MAX_K < K <= 2 * FUSED_MAX_K
-                and l2_bytes <= FUSED_QKV_M256_MAX_L2_BYTES and (N // 32) * m_tiles >= 128)
+        if _SHARD70B == "0" or not (FUSED_MAX_K < K <= 2 * FUSED_MAX_K):
+            return False
+        # deep (4096 < K <= 8192) shards -- the 70B model's and Qwen2.5-32B's (dim 5120) at TP-8, tools/shard_bench.py:
+        #   qkv: 70B 1280 x 8192 at 128 rows 16.7 us against 21.1 + rope/append; Qwen 896 x 5120 11.5-12.1 against 13.7 + 5
+        #        (112 tile workgroups); with 40 workgroups (70B at 32 rows) the library wins, 15.1 vs 18.2;
+        #   w1|w3 on 2 x 2 tiles: Qwen 6912 x 5120 at 128 rows 27.0-27.2 against 36.5 for library + SiLU*mul (34.5 md_linear)
+        if kind == "qkv":
+            return l2_bytes <= FUSED_QKV_M256_MAX_L2_BYTES and (N // 32) * m_tiles >= 100
+        return kind == "swiglu" and t22 and not absorbs_norm and l2_bytes <= FUSED_DEEP_SWIGLU_T22_MAX_L2_BYTES
     if kind == "swiglu":
         return N * K * 2 <= FUSED_M256_SWIGLU_MAX_BYTES and K <= FUSED_MAX_K
     if kind in ("plain", "resid"):

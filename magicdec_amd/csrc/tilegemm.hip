@@ -603,8 +603,10 @@ int launch_tile_pro(const TileParams& p, hipStream_t st) {
         if (t22) return launch_tile_cfg<EPI, FP8, 8, false, PRO, 2, 2>(p, st);
     }
     // 16 wavefronts (K/16 slices) when the grid is too small to put two 8-wave workgroups on every CU
+    // (round 6: not below K = 1024 -- two k-steps per wavefront and a 16-way reduce cost more than they hide: the K = 512 wo
+    // shards run 4.1-4.2 us with 8 slices against 5.3-5.4 with 16, tools/shard_bench.py / profiles/r06_shard_ab.txt)
     const int wgs = p.n_tiles * p.m_tiles;
-    bool nw16 = p.K % 256 == 0 && wgs <= 384;
+    bool nw16 = p.K % 256 == 0 && p.K >= 1024 && wgs <= 384;
     if (g_force_nw == 8) nw16 = false;
     if (g_force_nw == 16) nw16 = p.K % 256 == 0;
     const bool wnt = p.m_tiles == 1;

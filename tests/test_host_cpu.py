@@ -1312,6 +1312,12 @@ def test_gemm_policy_encodes_the_measured_ab_table():
     # 2 x 2 tiles and the deep narrow wqkv go to the tile kernel; at 32 rows (40 workgroups) the qkv shard stays on the library
     assert c(128, 8192, 3584, "plain") == "fused" and c(128, 1280, 8192, "qkv") == "fused"
     assert c(32, 1280, 8192, "qkv") == "lib" and c(128, 7168, 8192, "swiglu") == "skinny"
+    # ... and Qwen2.5-32B's (dim 5120) at the 128 rows of configs[4]'s draft steps (profiles/r06_shard_ab.txt): wqkv 896 x 5120
+    # (112 tile workgroups) and w1|w3 6912 x 5120 on 2 x 2 tiles go to the tile kernel, w2 5120 x 3456 stays on the library;
+    # the UNSHARDED 1B w1|w3 at 128 rows (K = 2048) is not touched by the deep-shard rule
+    assert c(128, 896, 5120, "qkv") == "fused" and c(128, 6912, 5120, "swiglu") == "fused"
+    assert c(128, 5120, 3456, "plain") == "lib" and c(128, 5120, 640, "plain") == "fused"
+    assert c(128, 16384, 2048, "swiglu") == "lib" and c(512, 6912, 5120, "swiglu") == "lib"
     # autoregressive 8B steps (M = 64)
     assert c(64, 6144, 4096, "qkv") == "lib" and c(64, 4096, 4096, "resid") == "fused"
     assert c(64, 28672, 4096, "swiglu") == "skinny" and c(64, 4096, 14336, "resid") == "skinny"

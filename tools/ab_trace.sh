@@ -11,7 +11,7 @@ cd $GRAFT_REPO_ROOT
 export MAGICDEC_BENCH_LAYOUT_AB=0
 for V in "$@"; do
   rm -rf /tmp/prof_ab
-  env $VAR=$V timeout 600 rocprofv3 --kernel-trace --stats --output-format csv rocpd -d /tmp/prof_ab -o bench -- \
+  env $VAR=$V timeout ${AB_TIMEOUT:-600} rocprofv3 --kernel-trace --stats --output-format csv rocpd -d /tmp/prof_ab -o bench -- \
       python3 bench.py --gpus 1 --steps 16 --warmup 4 --no-cpu-baseline --no-pmc ${BENCH_ARGS:-} > $OUT/${TAG}_${V}.log 2>&1
   grep '^{"metric"' $OUT/${TAG}_${V}.log > $OUT/${TAG}_${V}_line.json
   DB=$(find /tmp/prof_ab -name "*.db" | head -1)

@@ -1,6 +1,8 @@
-"""The 70B model's TP-8 shard linears at the row counts of configs[3] (B = 32: 32-row autoregressive / draft-free steps, 128-row
-verify): library GEMM against md_linear and md_linear_fused (1 x 1 / 2 x 2 tiles), graph-captured, weights cycled.
-    python tools/shard70b_bench.py"""
+"""Tensor-parallel shard linears of a BASELINE model at the row counts of its configuration: library GEMM against md_linear
+and md_linear_fused (default rule / 1 x 1 / 2 x 2 tiles), graph-captured, weights cycled through > 600 MB.
+    python tools/shard_bench.py [--model 70b|qwen32b|8b|1b] [--tp 8] [--rows 32,128]
+(default: the 70B model's TP-8 shards at the rows of configs[3]: 32-row autoregressive steps, 128-row verify)"""
+import argparse
 import ctypes
 import os
 import sys
@@ -12,12 +14,22 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from magicdec_amd import _lib, ops                          # noqa: E402
 from magicdec_amd.Engine.utils import enable_tuned_gemms   # noqa: E402
 
+ap = argparse.ArgumentParser()
+ap.add_argument("--model", default="70b")
+ap.add_argument("--tp", type=int, default=8)
+ap.add_argument("--rows", default="32,128")
+a = ap.parse_args()
 print("tuned GEMM table loaded:", enable_tuned_gemms())
 dev = "cuda"
 lib = _lib.load()
 ws = ops.AttnWorkspace(dev)
-# 70B / 8: dim 8192, 8 q heads + 1 kv head per rank (D = 128), FFN 28672 / 8 = 3584
-SHAPES = [("wqkv", 1280, 8192, False), ("wo", 8192, 1024, False), ("w13", 7168, 8192, True), ("w2", 8192, 3584, False)]
+# name: dim, heads, kv heads, head dim, FFN width
+MODELS = {"70b": (8192, 64, 8, 128, 28672), "qwen32b": (5120, 40, 8, 128, 27648), "8b": (4096, 32, 8, 128, 14336),
+          "1b": (2048, 32, 8, 64, 8192)}
+dim, H, KH, D, I = MODELS[a.model]
+h, kh, i = H // a.tp, max(KH // a.tp, 1), I // a.tp
+SHAPES = [("wqkv", (h + 2 * kh) * D, dim, False), ("wo", dim, h * D, False), ("w13", 2 * i, dim, True), ("w2", dim, i, False)]
+print(f"model {a.model} / {a.tp}: " + ", ".join(f"{n} {N}x{K}" for n, N, K, _ in SHAPES))
 
 
 def timeit(fn, n=30):
@@ -44,7 +56,7 @@ def timeit(fn, n=30):
 
 
 print(f"{'linear':6s} {'M':>4s} {'N':>6s} {'K':>6s} {'MB':>6s} | {'lib':>7s} | {'skinny':>7s} | {'fused':>7s} | {'1x1':>7s} | {'2x2':>7s}")
-for M in (32, 128):
+for M in [int(r) for r in a.rows.split(",")]:
     for name, N, K, sw in SHAPES:
         nbytes = N * K * 2
         ncopy = max(2, int(600e6 // nbytes) + 1)
@@ -62,10 +74,12 @@ for M in (32, 128):
 
         def fused_fn(i):
             return ops.fused_linear(x, pk[i % ncopy], swiglu=sw)
-        t = [timeit(lib_fn), timeit(skinny_fn) if ops.linear_supported(M, N, K, sw) else float("nan"), timeit(fused_fn)]
+        fused_ok = ops.fused_linear_supported(M, N, K)
+        t = [timeit(lib_fn), timeit(skinny_fn) if ops.linear_supported(M, N, K, sw) else float("nan"),
+             timeit(fused_fn) if fused_ok else float("nan")]
         for knob in (11, 22):
             lib.md_debug_set_fused_nw(ctypes.c_int(knob))
-            t.append(timeit(fused_fn))
+            t.append(timeit(fused_fn) if fused_ok else float("nan"))
         lib.md_debug_set_fused_nw(ctypes.c_int(0))
         print(f"{name:6s} {M:4d} {N:6d} {K:6d} {nbytes / 1e6:6.1f} | " + " | ".join(f"{v:7.1f}" for v in t), flush=True)
         del wl, pk
