@@ -3,7 +3,7 @@
 The hand-picked cases of test_gpu_ops.py / test_gpu_gemm.py / test_gpu_fused.py cover the shapes the Engine passes and the
 edges we thought of; this file draws shapes nobody thought of.  Every case is derived from a fixed seed (the sweep is
 deterministic and a failure names its seed); MAGICDEC_FUZZ_CASES=<n> widens every sweep to n cases (default below: the whole
-file runs in well under a minute; one wide run: profiles/r06_fuzz_2150_cases.txt).
+file runs in well under a minute; one wide run: profiles/r06_fuzz_2390_cases.txt).
 
 * paged attention: request count, ragged query-row counts (0 rows included), head grouping g in {1,2,3,4,5,7,8}, D, context
   lengths from 0 to a few thousand rows, page size in {32, 64, 128}, scattered page tables, NHD / HND pages, bf16 / fp8
@@ -11,7 +11,10 @@ file runs in well under a minute; one wide run: profiles/r06_fuzz_2150_cases.txt
 * RoPE + paged append (separate ops and the fused launch, one or two caches, both layouts): BIT-EXACT against the oracle;
 * the four GEMM families on random (M, N, K) inside their *_supported ranges, strided x, optional bias: the float64 gate of
   test_gpu_gemm.py; the residual epilogue of the tile kernel and the split combine BIT-EXACT against the unfused sequence;
-* argmax with planted ties: BIT-EXACT, lowest index.
+* argmax with planted ties: BIT-EXACT, lowest index;
+* SnapKV select on integer-valued inputs (scores exact in any summation order): scores, indices, gathered rows BIT-EXACT;
+* StreamingLLM eviction + re-rotation chunk by chunk, and the fused accept / rollback kernel on random batches: BIT-EXACT
+  against the oracle functions that tests/golden pins to the real reference.
 """
 import os
 import random
@@ -333,3 +336,111 @@ def test_fuzz_snapkv_select_bit_exact_on_exact_scores(ops, seed):
             assert torch.equal(bits(rows[:, 1].reshape(-1, KH, D)[:budget]), bits(nv)), tag
     finally:
         mr.LINEAR_MODE = old
+
+
+# ----------------------------------------------------------------------------------------- StreamingLLM eviction
+@pytest.mark.parametrize("seed", cases(8))
+def test_fuzz_streaming_shift_and_rotate_bit_exact(ops, seed):
+    """KVCache.prefill of the StreamingLLM draft (sink 16 + window) chunk by chunk, for random budgets (1..5 pages, the last
+    one partly filled), kv heads, head dims, batch sizes and prefix lengths: cache bytes and rotated-cache bytes after every
+    chunk equal the oracle's (which is pinned to the real reference at budgets 129 and 513)."""
+    from oracle import magicdec_ref as mr
+    r = random.Random(2000 + seed)
+    B, KH, D = r.randint(1, 3), r.choice([1, 2, 4]), r.choice([64, 128])
+    budget = 128 * r.randint(1, 4) + r.randint(1, 127)
+    ppr = budget // 128 + 1
+    seq_len = r.randint(60, budget + 128 * r.randint(1, 5) + r.randint(0, 127))
+    table = fr.rope_table(1024, D, 10000.0, 1.0)
+    tab = ops.RopeTable(1024, D, 10000.0, 1.0, device=DEV)
+    rope = lambda q, k, indptr, offsets: fr.apply_rope(q, k, indptr, offsets, table)
+    g = torch.Generator().manual_seed(900 + seed)
+    ref = torch.zeros(B * ppr, 2, 128, KH, D, dtype=BF)
+    cache = torch.zeros(B * ppr, 2, 128, KH, D, dtype=BF, device=DEV)
+    rot = torch.empty_like(cache)
+    ctx, npr, evictions = 0, 0, 0
+    for c0 in range(0, seq_len, 128):
+        n = min(128, seq_len - c0)
+        is_last = n != 128
+        if ctx + n <= budget:                      # pre_encode (StreamingLLM/backend_draft.py:155-192): one more page
+            npr, last = npr + 1, n
+        else:
+            npr, last = ppr, budget % 128
+            evictions += 1
+        k = torch.randn(B * n, KH, D, generator=g).to(BF)
+        v = torch.randn(B * n, KH, D, generator=g).to(BF)
+        t = dict(indices=torch.cat([torch.arange(b * ppr, b * ppr + npr, dtype=torch.int32) for b in range(B)]),
+                 indptr=(torch.arange(B + 1) * npr).to(torch.int32), last=torch.full((B,), last, dtype=torch.int32))
+        want_rot = mr.streaming_prefill_kv(ref, k, v, B, ctx, n, budget, t, rope, is_last)
+        if ctx + n <= budget:
+            ops.update_kv(d(k), d(v), d((torch.arange(B + 1) * n).to(torch.int32)), cache, d(t["indices"]), d(t["indptr"]),
+                          d(t["last"]))
+            valid = ctx + n
+        else:
+            ops.streaming_shift_append(d(k), d(v), cache, n, budget, 16, ppr)
+            valid = budget
+        overflow_last = (ctx + n > budget) and is_last
+        dst = cache if overflow_last else rot
+        if not overflow_last:
+            rot.copy_(cache)
+        ops.streaming_rotate(cache, dst, B, valid, ppr, tab)
+        tag = f"seed {seed}: B{B} KH{KH} D{D} budget{budget} prefix{seq_len}, chunk at {c0} (n={n})"
+        assert torch.equal(bits(cache.cpu()), bits(ref)), tag + ": cache"
+        assert torch.equal(bits(dst.cpu()), bits(want_rot)), tag + ": rotated cache"
+        ctx = min(ctx + n, budget)
+    parity_report(f"[fuzz-stream] seed {seed} B{B} KH{KH} D{D} budget {budget} prefix {seq_len}: {evictions} evicting chunks, "
+                  f"cache and rotated cache bit-equal to the oracle after every chunk")
+
+
+# ----------------------------------------------------------------------------------------- accept / rollback
+@pytest.mark.parametrize("variant", ["longspec", "selfspec_snapkv", "selfspec_stream"])
+@pytest.mark.parametrize("seed", cases(8))
+def test_fuzz_accept_rollback_vs_oracle(ops, seed, variant):
+    """The fused accept / rollback kernel against the oracle's restatement of the three verify-loop bodies (pinned to the
+    reference's own loop by tests/golden/accept_loop*.json) on random batches: gamma 1..7, 1..300 requests (several
+    wavefronts), random match patterns, end-of-text tokens among drafts and bonus tokens, requests next to the length cap."""
+    from oracle import magicdec_ref as mr
+    r = random.Random(1000 + 31 * seed + len(variant))
+    G = r.randint(1, 7)
+    B = r.choice([1, 2, 5, 64, 65, 130, 300])
+    dr, cap, dbl = {"longspec": (G, G, True), "selfspec_snapkv": (G + 1, G + 1, False),
+                    "selfspec_stream": (G, G, True)}[variant]
+    eot_1, eot_2 = 7, 11
+    prefix = r.randint(20, 60)
+    max_nodes = prefix + 80
+    g = torch.Generator().manual_seed(77 + seed)
+    p_match = r.choice([0.3, 0.8, 0.97, 1.0])
+    tb = torch.randint(20, 1000, (B, G + 1), generator=g)
+    tt = torch.randint(20, 1000, (B, G + 1), generator=g)
+    m = torch.rand(B, G, generator=g) < p_match
+    tt[:, :G] = torch.where(m, tb[:, 1:], tt[:, :G])
+    if r.random() < 0.5:                                           # end-of-text tokens among the drafts / the targets
+        tb[torch.rand(B, G + 1, generator=g) < 0.03] = eot_1
+        tt[torch.rand(B, G + 1, generator=g) < 0.03] = eot_2
+    grown = torch.randint(0, 70, (B,), generator=g)               # tokens generated so far
+    if r.random() < 0.3:
+        grown[r.randrange(B)] = 79 - r.randint(0, G)               # next to the cap: num_nodes reaches max_nodes
+    num_nodes = prefix + grown
+    cachelens = (num_nodes - 1 + G + 1).to(torch.int32)            # the verify pass has appended gamma + 1 rows
+    lp = ((cachelens - 1) % 128 + 1).to(torch.int32)
+    dcl = torch.randint(40, 300, (B,), generator=g).to(torch.int32)
+    dlp = ((dcl - 1) % 128 + 1).to(torch.int32)
+    out_cols = prefix + 80 + G + 2
+    ref = dict(tb=tb.clone(), out=torch.zeros(B, out_cols, dtype=torch.long), nn=num_nodes.clone(), cl=cachelens.clone(),
+               lp=lp.clone(), dcl=dcl.clone(), dlp=dlp.clone())
+    res = mr.accept_step(ref["tb"], tt.clone(), ref["out"], ref["nn"], ref["cl"], ref["lp"], ref["dcl"], ref["dlp"], G, dr,
+                         cap, eot_1, eot_2, max_nodes, dbl)
+    dev = dict(tb=d(tb), out=torch.zeros(B, out_cols, dtype=torch.long, device=DEV), nn=d(num_nodes), cl=d(cachelens),
+               lp=d(lp), dcl=d(dcl), dlp=d(dlp))
+    an, bo = torch.zeros(B, dtype=torch.long, device=DEV), torch.zeros(B, dtype=torch.long, device=DEV)
+    db, cu = torch.zeros(B, 2, dtype=torch.long, device=DEV), torch.zeros(B, dtype=torch.long, device=DEV)
+    fl = torch.zeros(2, dtype=torch.int32, device=DEV)
+    ops.accept_rollback(dev["tb"], d(tt), dev["out"], dev["nn"], dev["cl"], dev["lp"], dev["dcl"], dev["dlp"], G, dr, cap,
+                        eot_1, eot_2, max_nodes, an, bo, db if dbl else None, cu if dbl else None, fl)
+    tag = f"seed {seed} {variant}: B{B} gamma{G} p_match {p_match}"
+    assert bool(fl[0]) == res["terminal"], tag
+    assert torch.equal(an.cpu(), res["accept_nums"]) and torch.equal(bo.cpu(), res["bonus"]), tag
+    for key in ("tb", "out", "nn", "cl", "lp", "dcl", "dlp"):
+        assert torch.equal(dev[key].cpu(), ref[key]), tag + f": {key}"
+    assert bool(fl[1]) == res["next_double"], tag
+    if res["next_double"]:
+        assert torch.equal(db.cpu(), res["double_buffer"]) and torch.equal(cu.cpu(), res["cachelens_update"]), tag
