@@ -426,9 +426,30 @@ def run(args, dev):
 
     debug_iters = os.environ.get("MAGICDEC_BENCH_DEBUG_ITERS", "0") == "1"
 
+    # The reference's longspec loop rolls back draft.paged_kv_last_page_len while a SnapKV draft appends through
+    # draft_paged_kv_last_page_len (tests/SnapKV/longspec_benchmark.py:247-256 vs Engine/SnapKV/backend_draft.py:113-173): the
+    # compressed cache's page length grows by one per draft step and is never rolled back, so its last page is full after
+    # page_size - budget % page_size draft steps (127 at budget 257) -- reproduced bug for bug (tests/test_gpu_engine_fuzz.py).
+    # A batch at alpha >= ~0.55 reaches prefix + 80 tokens earlier; at lower acceptance the counters are restored just before
+    # the page would overflow (rank-independent arithmetic: every rank restores at the same iteration), and the rows any run
+    # still dropped are reported (config.kv_rows_dropped_beyond_mapped_pages).
+    draft_step_cap = (128 - BUDGET % 128) if (drf_name is not None and not selfspec and not streaming) else None
+    early_restores = [0]
+
     def run_spec(n_warm, n_steps, forced_table):
         restore()
         nd = False
+        since = [0]                                   # draft steps since the counters were last restored
+
+        def guard(nd_):
+            if draft_step_cap is not None:
+                if since[0] + G + 1 > draft_step_cap:
+                    restore()
+                    early_restores[0] += 1
+                    since[0] = 0
+                    nd_ = False
+                since[0] += G + (1 if nd_ else 0)
+            return nd_
         tokens = torch.zeros((), dtype=torch.long, device=dev)
         timer.enabled = False
         # the token counter is queued behind the accept kernel, before the iteration's host read (the host is ahead of
@@ -440,10 +461,12 @@ def run(args, dev):
             # exactly the statements of a timed step: the first execution of any torch op in a process loads its code
             # object (the token counter's int sum + add cost 18.6 ms in the first timed iteration when the warm-up
             # loop did not run them: profiles/r02_bench_first_iteration.txt)
+            nd = guard(nd)
             term, nd = iteration(nd, forced_table[i] if forced_table is not None else None)
             if term:
                 restore()
                 nd = False
+                since[0] = 0
         tokens.zero_()
         timer.clear()
         timer.enabled = True
@@ -451,11 +474,13 @@ def run(args, dev):
         t0 = time.perf_counter()
         stamps = []
         for i in range(n_steps):
+            nd = guard(nd)
             term, nd = iteration(nd, forced_table[n_warm + i] if forced_table is not None else None)
             stamps.append((time.perf_counter(), bool(term), bool(nd)))   # the iteration ended with a host read
             if term:
                 restore()
                 nd = False
+                since[0] = 0
         barrier()
         dt = time.perf_counter() - t0
         timer.enabled = False
@@ -611,6 +636,12 @@ def run(args, dev):
     if on_gpu and rank == 0 and args.workload.startswith("cfg") and os.environ.get("MAGICDEC_BENCH_LAYOUT_AB", "1") != "0":
         roofline_other = layout_roofline(engine, timer, B, G + 1, L_kv, H_loc, KH_loc, D, args.kv_dtype == "fp8", other,
                                          attn_bytes, dev)
+    # rows the append kernels dropped because a request's last page was full (md_page_overflow_count; the reference would
+    # have written them into another request's page): must be 0 -- over every run of this process, not only the headline
+    kv_dropped = None
+    if on_gpu:
+        from magicdec_amd import ops as _ops
+        kv_dropped = int(_ops.page_overflow_count(reset=True))
     ar_timeouts = None
     if use_tp:
         ars = [m._oneshot for m in ([engine.model] + ([draft.model] if draft is not None else []))
@@ -652,6 +683,8 @@ def run(args, dev):
                    "rowmajor_weight_bytes_released_after_prefill": int(
                        getattr(engine.model, "released_bytes", 0)
                        + (getattr(draft.model, "released_bytes", 0) if draft is not None else 0)),
+                   "kv_rows_dropped_beyond_mapped_pages": kv_dropped,
+                   "draft_cache_restores_before_its_page_end": early_restores[0] if draft_step_cap is not None else None,
                    **({"emulated_tp_rank0_of": emu} if emu > 1 else {}),
                    "allreduce": (None if not use_tp else
                                  "oneshot-ipc" if getattr(engine.model, "_oneshot", None) is not None else "rccl"),
