@@ -3,7 +3,7 @@
 The hand-picked cases of test_gpu_ops.py / test_gpu_gemm.py / test_gpu_fused.py cover the shapes the Engine passes and the
 edges we thought of; this file draws shapes nobody thought of.  Every case is derived from a fixed seed (the sweep is
 deterministic and a failure names its seed); MAGICDEC_FUZZ_CASES=<n> widens every sweep to n cases (default below: the whole
-file runs in well under a minute; one wide run: profiles/r06_fuzz_2390_cases.txt).
+file runs in well under a minute; one wide run: profiles/r06_fuzz_2510_cases.txt).
 
 * paged attention: request count, ragged query-row counts (0 rows included), head grouping g in {1,2,3,4,5,7,8}, D, context
   lengths from 0 to a few thousand rows, page size in {32, 64, 128}, scattered page tables, NHD / HND pages, bf16 / fp8
@@ -444,3 +444,38 @@ def test_fuzz_accept_rollback_vs_oracle(ops, seed, variant):
     assert bool(fl[1]) == res["next_double"], tag
     if res["next_double"]:
         assert torch.equal(db.cpu(), res["double_buffer"]) and torch.equal(cu.cpu(), res["cachelens_update"]), tag
+
+
+# ----------------------------------------------------------------------------------------- the tile kernel's fused launches
+@pytest.mark.parametrize("seed", cases(12))
+def test_fuzz_fused_qkv_rope_append_and_tile_shapes(ops, seed):
+    """Random geometry through the checks of test_gpu_fused.py: wqkv + RoPE + paged append in one launch BIT-EXACT against the
+    plain product followed by md_rope_append (bf16 / fp8 pages, NHD / HND, one or two caches, scattered tables, bias); the
+    SwiGLU epilogue BIT-EXACT against product + md_silu_mul; 2 x 2 tiles BIT-IDENTICAL to 1 x 1 in every epilogue incl. the
+    deferred-RMSNorm prologue."""
+    from tests import test_gpu_fused as tf
+    r = random.Random(11000 + seed)
+    D = r.choice([64, 128])
+    KH = r.choice([1, 2, 4, 8])
+    H = KH * r.choice([1, 2, 4, 5, 8])
+    n = r.choice([1, 1, 2, 4, 5])
+    B = r.randint(1, min(64, 256 // n))
+    K = 128 * r.randint(1, 24)
+    lens = [n + r.randint(0, 400) for _ in range(B)]
+    layout = r.choice(["NHD", "HND"])
+    fp8 = r.random() < 0.3
+    two = r.random() < 0.3 and not fp8
+    if ops.fused_linear_supported(B * n, (H + 2 * KH) * D, K, ops.FL_ROPE_APPEND):
+        tf.test_fused_qkv_rope_append_bit_exact(ops, f"fuzz{seed}", B, n, H, KH, D, K, lens, layout, fp8, two,
+                                                r.random() < 0.6, r.random() < 0.5)
+    M, inter, K2 = r.choice([1, 5, 32, 64, 100, 128, 200, 256]), 32 * r.randint(1, 48), 128 * r.randint(1, 16)
+    if ops.fused_linear_supported(M, 2 * inter, K2, ops.FL_SWIGLU):
+        g = torch.Generator().manual_seed(seed)
+        x = d(torch.randn(M, K2, generator=g).to(BF))
+        w13 = d((torch.randn(2 * inter, K2, generator=g) * 0.08).to(BF))
+        y = ops.fused_linear(x, ops.PackedWeight(w13, swiglu=True), swiglu=True)
+        h = ops.fused_linear(x, ops.PackedWeight(w13))
+        assert torch.equal(bits(y), bits(ops.silu_mul(h[:, :inter], h[:, inter:]))), f"seed {seed}: swiglu M{M} I{inter} K{K2}"
+    M, N, K3 = r.choice([1, 33, 64, 100, 128, 256]), 64 * r.randint(1, 40), 128 * r.randint(1, 24)
+    if ops.fused_linear_supported(M, N, K3):
+        tf.test_fused_2x2_tiles_bit_identical_to_1x1(ops, M, N, K3)
