@@ -1361,13 +1361,14 @@ def test_one_resident_copy_per_weight_release_and_restore():
     if g.mode() != "auto" or g.fused_mode() != "auto" or g.block_mode() != "auto" or os.environ.get("MAGICDEC_SPLIT", "auto") != "auto":
         pytest.skip("policy overridden by the environment")
 
-    def build(name, rows, **cfg):
+    def build(name, rows, values=False, **cfg):
         model_core.transformer_configs[name] = dict(block_size=4096, n_layer=1, vocab_size=4096, rope_base=500000.0, **cfg)
         try:
             torch.manual_seed(0)
             m = model_core.Transformer.from_name(name).to(torch.bfloat16)
-            for p_ in m.parameters():
-                p_.data.normal_(0, 0.02)
+            if values:                       # only the restore check below compares values; the rest is bookkeeping
+                for p_ in m.parameters():
+                    p_.data.normal_(0, 0.02)
             m.setup_caches(num_pages=2, decode_rows=rows)
             m._pack_weights(force=True)
             return m
@@ -1375,7 +1376,7 @@ def test_one_resident_copy_per_weight_release_and_restore():
             model_core.transformer_configs.pop(name, None)
 
     # ---- the 1B draft's layer shapes, decode rows B = 64 and the two-token step
-    m = build("dedupe1b", (64, 128), n_head=32, n_local_heads=8, dim=2048, intermediate_size=8192)
+    m = build("dedupe1b", (64, 128), values=True, n_head=32, n_local_heads=8, dim=2048, intermediate_size=8192)
     lay = m.layers[0]
     ws = {"wqkv": lay.attention.wqkv.weight, "wo": lay.attention.wo.weight, "w13": m._w13[0],
           "w2": lay.feed_forward.w2.weight, "head": m.output.weight}
