@@ -3,7 +3,7 @@
 The hand-picked cases of test_gpu_ops.py / test_gpu_gemm.py / test_gpu_fused.py cover the shapes the Engine passes and the
 edges we thought of; this file draws shapes nobody thought of.  Every case is derived from a fixed seed (the sweep is
 deterministic and a failure names its seed); MAGICDEC_FUZZ_CASES=<n> widens every sweep to n cases (default below: the whole
-file runs in well under a minute; one wide run: profiles/r06_fuzz_2510_cases.txt).
+file runs in well under a minute; one wide run: profiles/r06_fuzz_11000_cases.txt).
 
 * paged attention: request count, ragged query-row counts (0 rows included), head grouping g in {1,2,3,4,5,7,8}, D, context
   lengths from 0 to a few thousand rows, page size in {32, 64, 128}, scattered page tables, NHD / HND pages, bf16 / fp8
@@ -25,7 +25,7 @@ import torch
 from oracle import flashinfer_ref as fr
 from tests.conftest import parity_report
 from tests.parity_util import check_attention, dense_attention_f64
-from tests.test_gpu_ops import bits, make_paged
+from tests.test_gpu_ops import _ulp_close, bits, make_paged
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
@@ -278,8 +278,9 @@ def test_fuzz_snapkv_select_bit_exact_on_exact_scores(ops, seed):
     """Random geometry (requests, kv heads, group size, head dim, context length off every tile boundary, window 16 / 32,
     budget, scattered source pages) on inputs whose q.k are small integers times a power of two -- exact in ANY summation
     order (the construction of test_gpu_ops.py::test_snapkv_select_every_score_magnitude_bit_exact) -- so pooled scores,
-    selected indices (stable descending, lowest index among ties) and the gathered draft-cache rows must all equal the
-    float64-linear oracle's BIT FOR BIT."""
+    selected indices (stable descending, lowest index among ties) and the gathered draft-cache rows equal the
+    float64-linear oracle's bit for bit, up to the one thing left: the fp32 summation order of the softmax denominator
+    (<= 2 pooled scores per request one ulp apart; the indices are then checked against the kernel's own scores)."""
     from oracle import magicdec_ref as mr
     r = random.Random(3000 + seed)
     W = r.choice([16, 32, 32])
@@ -329,11 +330,26 @@ def test_fuzz_snapkv_select_bit_exact_on_exact_scores(ops, seed):
     try:
         for b in range(B):
             want_idx, nk, nv, want_sc = mr.snapkv_select(q[b * W:(b + 1) * W], k[b], v[b], g, W, budget)
-            assert torch.equal(bits(sc[b]), bits(want_sc)), tag + f": pooled scores of request {b}"
-            assert torch.equal(idx[b], want_idx), tag + f": indices of request {b}"
+            neq = int((bits(sc[b]) != bits(want_sc)).sum())
+            # the q.k scores are exact; what is left is the fp32 summation order of the softmax denominator over the
+            # context (the kernel combines per-1024-column statistics, torch's CPU softmax has its own order -- as has the
+            # reference's CUDA softmax): a probability on a bf16 rounding boundary may land on either side.  Seen once in
+            # 1 150 wide-run cases: ONE of 5 100 pooled scores one ulp apart (seed 151), indices unaffected
+            assert neq <= 2 and _ulp_close(sc[b], want_sc, ulps=1), tag + f": {neq} pooled scores of request {b} differ"
             rows = dk[b * dppr:(b + 1) * dppr]
-            assert torch.equal(bits(rows[:, 0].reshape(-1, KH, D)[:budget]), bits(nk)), tag
-            assert torch.equal(bits(rows[:, 1].reshape(-1, KH, D)[:budget]), bits(nv)), tag
+            got_k, got_v = rows[:, 0].reshape(-1, KH, D)[:budget], rows[:, 1].reshape(-1, KH, D)[:budget]
+            for h in range(KH):
+                mine = idx[b, h]
+                assert torch.equal(mine, torch.sort(sc[b, h].float(), descending=True, stable=True).indices[:topk]), tag
+                assert torch.equal(bits(got_k[:topk, h]), bits(k[b][mine, h])), tag
+                assert torch.equal(bits(got_v[:topk, h]), bits(v[b][mine, h])), tag
+            if neq == 0:
+                assert torch.equal(idx[b], want_idx), tag + f": indices of request {b}"
+                assert torch.equal(bits(got_k), bits(nk)) and torch.equal(bits(got_v), bits(nv)), tag
+            else:
+                parity_report(f"[fuzz-snapkv] {tag}: request {b}: {neq} of {want_sc.numel()} pooled scores 1 ulp from the "
+                              f"oracle's (softmax denominator summation order); indices equal: {torch.equal(idx[b], want_idx)}")
+            assert torch.equal(bits(got_k[topk:]), bits(k[b][S - W:])) and torch.equal(bits(got_v[topk:]), bits(v[b][S - W:])), tag
     finally:
         mr.LINEAR_MODE = old
 
