@@ -8,7 +8,9 @@ takes the last chunk as the window), gamma 1 .. 5 and a draft budget are drawn; 
 construction: head tied to the embedding through a permutation, the draft mispredicting every k-th token id), so that the
 oracle's argmaxes are decided by hundreds of bf16 ulps and "accepted-token sequences identical" can be asserted literally:
 the HIP back-ends replay the oracle's recorded call sequence (tests/test_gpu_engine.replay: integer state bit-exact after
-every call, logits inside the measured gate) and NO token may differ.  MAGICDEC_FUZZ_CASES=<n> widens the sweep.
+every call, logits inside the measured gate) and NO token may differ; then the product's own free-running loop (hipGraph
+steps, accept kernel, one host read per iteration) must end with the oracle run's output buffer, lengths and iteration
+count.  MAGICDEC_FUZZ_CASES=<n> widens the sweep.
 """
 import os
 import random
@@ -165,3 +167,18 @@ def test_fuzz_engine_lockstep_token_identity(seed):
     # replay() admits a differing token only inside the oracle's own near-tie margin (<= 2 x the logit gate, a few ulps): on
     # the positions decided by >= 16 ulps none can differ, so the count is bounded by the narrow positions -- normally zero
     assert st.nties <= npos - wide, f"{tag}: {st.nties} tokens differ from the oracle's, {npos - wide} narrow positions"
+    # ... and the FREE-RUNNING product loop (magicdec_amd.harness: hipGraph steps, the fused accept / rollback kernel, one
+    # host read per iteration) on the same prompts: with every argmax decided by a wide margin it must end with the oracle
+    # run's output buffer, lengths and iteration count -- no teacher forcing in between
+    if wide == npos:
+        from magicdec_amd import harness
+        for e in engines.values():
+            e.compile()
+        if mode.startswith("longspec"):
+            hst, _ = harness.run_longspec_batch(engines["T"], engines["D"], ids.to(DEV), gamma, max_len, gc.EOT_1, gc.EOT_2)
+        else:
+            hst, _ = harness.run_selfspec_batch(engines["T"], ids.to(DEV), gamma, max_len, gc.EOT_1, gc.EOT_2,
+                                                mode.endswith("stream"))
+        assert hst.iters == res["iters"], (tag, hst.iters, res["iters"])
+        assert torch.equal(hst.num_nodes.cpu(), res["num_nodes"]), tag
+        assert torch.equal(hst.output.cpu(), res["output"]), f"{tag}: the free-running loop's output differs from the oracle's"
