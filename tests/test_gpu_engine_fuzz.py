@@ -38,10 +38,12 @@ def _capped_cpu_threads():
         yield
 
 
-def draw(seed):
-    r = random.Random(8000 + seed)
+def draw(seed, tp=1):
+    """tp > 1: a geometry whose kv heads (and feed-forward width) divide over `tp` tensor-parallel ranks."""
+    r = random.Random(8000 + seed + 100003 * (tp - 1))
     mode = MODES[seed % 4] if seed < 8 else r.choice(MODES)          # the first eight seeds cover every pairing twice
-    shapes = [(D, KH, g) for D in (64, 128) for KH in (1, 2, 4) for g in (1, 2, 4, 5, 8) if 256 <= D * KH * g <= 1024]
+    shapes = [(D, KH, g) for D in (64, 128) for KH in (1, 2, 4) for g in (1, 2, 4, 5, 8) if 256 <= D * KH * g <= 1024
+              and KH % tp == 0]
     if "snapkv" in mode:
         shapes = [s for s in shapes if 8 * s[2] >= 32]               # the reference raises for 8 g < window (model.py:415)
     D, KH, g = r.choice(shapes)
@@ -50,10 +52,10 @@ def draw(seed):
               original_max_position_embeddings=8192) if fam == "llama31" else \
         dict(rope_base=1000000.0, norm_eps=1e-6, qkv_bias=True) if fam == "qwen" else dict(rope_base=10000.0)
     dim = D * KH * g
-    geo = dict(n_head=KH * g, n_local_heads=KH, dim=dim, intermediate_size=128 * r.randint(3, 12),
+    geo = dict(n_head=KH * g, n_local_heads=KH, dim=dim, intermediate_size=128 * tp * r.randint(3, 12 if tp == 1 else 12 // tp + 2),
                vocab_size=r.choice([1024, 2048, 3000]))
     cfg_t = mr.RefConfig(n_layer=r.choice([1, 2, 3]), **geo, **kw)
-    cfg_d = mr.RefConfig(n_layer=1, **{**geo, "intermediate_size": 128 * r.randint(2, 8)}, **kw)
+    cfg_d = mr.RefConfig(n_layer=1, **{**geo, "intermediate_size": 128 * tp * r.randint(2, 8 if tp == 1 else 8 // tp + 1)}, **kw)
     budget = r.choice([129, 129, 257])
     # the reference's page tables do not grow during decode (Engine/SnapKV/backend.py:129-159 only bumps last_page_len): the
     # prefix's last page must have room for the 80 generated tokens + gamma + 1 verify rows + the bonus, i.e. S % 128 <= 40 here
@@ -182,3 +184,71 @@ def test_fuzz_engine_lockstep_token_identity(seed):
         assert hst.iters == res["iters"], (tag, hst.iters, res["iters"])
         assert torch.equal(hst.num_nodes.cpu(), res["num_nodes"]), tag
         assert torch.equal(hst.output.cpu(), res["output"]), f"{tag}: the free-running loop's output differs from the oracle's"
+
+
+@pytest.mark.parametrize("world,seed", [(2, s) for s in range(N_CASES or 2)] + [(4, s) for s in range(min(N_CASES, 12) or 1)])
+def test_fuzz_tensor_parallel_free_running_loop(world, seed):
+    """The same random geometry TENSOR-PARALLEL: `world` ranks sharing the box's GPU (tests/_tp_fuzz_worker.py: HIP kernels on
+    kv-head shards, weights sliced by Engine/tp.py, the per-layer all-reduces through the one-shot IPC kernel, argmax merge and
+    token broadcast over gloo) run the product's free-running loop.  Every rank must end with the same replicated state, no
+    peer time-outs -- and, the argmaxes being decided by wide margins, with the output buffer, lengths and iteration count of
+    the TP = 1 ORACLE run (a TP run rounds its partial sums to bf16 before the all-reduce, SURVEY.md section 0.9: a
+    perturbation of a few ulps, far inside the margins)."""
+    import json
+    import subprocess
+    import sys
+    c = draw(seed, tp=world)
+    mode, cfg_t, cfg_d, B, S, max_len, gamma, budget = (c[k] for k in ("mode", "cfg_t", "cfg_d", "B", "S", "max_len", "gamma",
+                                                                      "budget"))
+    sd_t, sd_d = peaked(cfg_t, cfg_d, c["wseed"], c["miss_every"])
+    g = torch.Generator().manual_seed(c["wseed"] + 3)
+    ids = torch.randint(4, cfg_t.vocab_size, (B, S), generator=g)
+    ids[:, 0] = 1
+    log = []
+    if mode.startswith("longspec"):
+        dkind = "snapkv_draft" if mode.endswith("snapkv") else "stream_draft"
+        dargs = (B, max_len, budget) if dkind == "snapkv_draft" else (B, 0, budget)
+        tgt = Recorder(mr.RefEngine("target", cfg_t, sd_t, B, max_len), "T", log)
+        drf = Recorder(mr.RefEngine(dkind, cfg_d, sd_d, *dargs), "D", log)
+        res = hr.longspec_batch(tgt, drf, ids, gamma, max_len, gc.EOT_1, gc.EOT_2)
+    else:
+        streaming = mode.endswith("stream")
+        eng = Recorder(mr.RefEngine("stream_self" if streaming else "snapkv_self", cfg_t, sd_t, B, max_len, budget), "T", log)
+        res = hr.selfspec_batch(eng, ids, gamma, max_len, gc.EOT_1, gc.EOT_2, streaming)
+    narrow = 0
+    for rec in log:
+        lg = rec["logits"].view(-1, rec["logits"].shape[-1])
+        top2 = lg.topk(2, dim=-1).values
+        ulp = torch.tensor([_ulp_at(float(v)) for v in top2[:, 0]])
+        narrow += int(((top2[:, 0] - top2[:, 1]) < 16 * ulp).sum())
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = tempfile.mkdtemp(prefix="md_tpfuzz_out_")
+    port = 29900 + (os.getpid() % 300) + 7 * seed + world
+    procs = []
+    for r_ in range(world):
+        env = dict(os.environ, LOCAL_RANK=str(r_), LOCAL_WORLD_SIZE=str(world), RANK=str(r_), WORLD_SIZE=str(world),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), MD_OUT=out, MD_SEED=str(seed),
+                   MAGICDEC_TP_SINGLE_GPU="1", MAGICDEC_ONESHOT_AR="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(root, "tests", "_tp_fuzz_worker.py")], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    logs = []
+    try:
+        for p_ in procs:
+            logs.append(p_.communicate(timeout=600)[0])
+    finally:
+        for p_ in procs:
+            if p_.poll() is None:
+                p_.kill()
+    assert all(p_.returncode == 0 for p_ in procs), "\n".join(l[-3000:] for l in logs)
+    rs = [json.load(open(os.path.join(out, f"rank{r_}.json"))) for r_ in range(world)]
+    tag = (f"tp{world} fuzz-{seed} {mode} {c['fam']} H{cfg_t.n_head} KH{cfg_t.n_local_heads} D{cfg_t.head_dim} "
+           f"ffn{cfg_t.intermediate_size} V{cfg_t.vocab_size} B{B} S{S} gamma{gamma} budget{budget}")
+    for r_ in rs:
+        assert r_["local_heads"] == [cfg_t.n_head // world, cfg_t.n_local_heads // world], tag
+        assert all(r_["oneshot"]) and all(s_ == 0 for s_ in r_["ar_status"]), (tag, r_["oneshot"], r_["ar_status"])
+        assert r_["output"] == rs[0]["output"] and r_["num_nodes"] == rs[0]["num_nodes"] and r_["iters"] == rs[0]["iters"], tag
+    same = (rs[0]["iters"] == res["iters"] and rs[0]["num_nodes"] == res["num_nodes"].tolist()
+            and rs[0]["output"] == res["output"].tolist())
+    parity_report(f"[tp-fuzz] {tag}: {world} ranks agree; output / lengths / {rs[0]['iters']} iterations equal to the TP = 1 "
+                  f"oracle run: {same} ({narrow} narrow positions in the oracle run)")
+    assert same or narrow > 0, f"{tag}: the tensor-parallel loop's output differs from the oracle's"
