@@ -48,7 +48,7 @@ MIN_STREAM_BYTES_M128 = 100e6
 #     19.8); wo / w1|w3 / w2 shards are served faster by the library (14.4 vs 14.1, 30.2 vs 22.9, 23.0 vs 16.6).
 FUSED_MAX_L2_BYTES = 70e6
 FUSED_MAX_L2_BYTES_T22 = 120e6
-FUSED_DEEP_SWIGLU_T22_MAX_L2_BYTES = 150e6
+FUSED_DEEP_SWIGLU_T22_MAX_L2_BYTES = float(os.environ.get("MAGICDEC_DEEP_SWIGLU_L2", "150e6"))   # (env: A/B switch)
 _SHARD70B = os.environ.get("MAGICDEC_SHARD70B", "1")     # "0": without the two round-6 rules for the 70B shards (A/B switch)
 FUSED_MAX_K = 4096
 FUSED_QKV_M256_MAX_L2_BYTES = 110e6
